@@ -1,0 +1,267 @@
+"""CPU ORACLE for the VL-SAT eval forward path  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may
+import this module, and only as the checker / timed CPU baseline.  The product path
+(``cvpr2023-vlsat_amd``) never imports it and has no CPU fallback.
+
+What it is: a plain-PyTorch (CPU, fp32 or fp64) restatement of the reference algorithm,
+function by function, each citing the reference file:line it follows.  It has no
+torch_geometric / clip / .cuda() dependency, so it runs on the GPU box where the reference
+does not exist.
+
+Parity status: PINNED.  ``tests/test_oracle_golden.py`` checks every function here against
+golden vectors produced by the real reference imported in the build container
+(``tests/golden/make_golden.py``; reference has no tests or fixtures of its own),
+including the reference's single executable example of the gather/scatter conventions
+(``network_util.py:75-99``).  Third-party arithmetic not vendored in the reference:
+``torch_geometric`` (unpinned, README.md:31) / ``torch-scatter`` (README.md:28) -- only
+``index_select`` gather and scatter add/mean/max (empty segment -> 0) are used; restated in
+``gen_index`` / ``aggre_index`` below.
+
+Batch contract: one *scene* per reference call (``validation()`` uses batch_size=1,
+reference ``src/model/model.py:185``); a batch is evaluated scene by scene (the
+reference's own batched edge cross-attention leaks across scenes, so per-scene is the
+contract).  ``forward`` therefore loops over scenes and concatenates.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+W = Dict[str, Tensor]
+
+
+def lin(x: Tensor, w: W, name: str) -> Tensor:
+    weight = w[name + ".weight"]
+    if weight.dim() == 3:            # Conv1d(k=1) == per-point Linear
+        weight = weight[:, :, 0]
+    return F.linear(x, weight, w[name + ".bias"])
+
+
+# ---------------------------------------------------------------------------------------------
+def pointnet_feat(pts: Tensor, w: W, prefix: str) -> Tensor:
+    """PointNetfeat.forward with global_feat=True, no STN, BN result discarded (F11).
+    reference src/model/model_utils/network_PointNet.py:141-164.
+    pts [N,C,P] -> [N,out]: max_p relu(conv3(relu(conv2(relu(conv1 x)))))."""
+    h = pts.transpose(1, 2)
+    h = torch.relu(lin(h, w, prefix + ".conv1"))
+    h = torch.relu(lin(h, w, prefix + ".conv2"))
+    h = torch.relu(lin(h, w, prefix + ".conv3"))
+    return h.max(dim=1)[0]
+
+
+def node_embed(feat: Tensor, desc: Tensor, w: W) -> Tensor:
+    """mlp_3d (Linear + BatchNorm1d eval + ReLU + Dropout=id) then the spatial concat.
+    reference src/model/SGFN_MMG/model.py:106-111 (definition), :294-299 (use)."""
+    y = lin(feat, w, "mlp_3d.0")
+    y = (y - w["mlp_3d.1.running_mean"]) / torch.sqrt(w["mlp_3d.1.running_var"] + 1e-5)
+    y = torch.relu(y * w["mlp_3d.1.weight"] + w["mlp_3d.1.bias"])
+    s = desc[:, 3:].clone()
+    s[:, 6:] = s[:, 6:].log()
+    return torch.cat([y, s], -1)
+
+
+def gen_index(x: Tensor, ei: Tensor, flow: str = "target_to_source"):
+    """Gen_Index (reference network_util.py:50-62) under PyG semantics:
+    source_to_target -> x_i = x[ei[1]], x_j = x[ei[0]]; target_to_source -> swapped."""
+    i, j = (1, 0) if flow == "source_to_target" else (0, 1)
+    return x[ei[i]], x[ei[j]]
+
+
+def aggre_index(x: Tensor, ei: Tensor, dim_size: int, aggr: str = "max",
+                flow: str = "target_to_source") -> Tensor:
+    """Aggre_Index (reference network_util.py:64-73): scatter-reduce rows of x onto
+    index ei[i] (i as in gen_index); empty segments give 0 (torch_scatter semantics)."""
+    i = 1 if flow == "source_to_target" else 0
+    idx = ei[i]
+    out = torch.zeros(dim_size, x.shape[1], dtype=x.dtype)
+    red = {"add": "sum", "mean": "mean", "max": "amax"}[aggr]
+    return out.scatter_reduce(0, idx[:, None].expand_as(x), x, reduce=red, include_self=False)
+
+
+def edge_descriptor(desc: Tensor, ei: Tensor) -> Tensor:
+    """Gen_edge_descriptor.message with flow='target_to_source'
+    (reference src/utils/op_utils.py:78-97; flow set at SGFN_MMG/model.py:44,303)."""
+    a, b = gen_index(desc, ei, "target_to_source")
+    return torch.cat([a[:, 0:6] - b[:, 0:6], torch.log(a[:, 6:11] / b[:, 6:11])], -1)
+
+
+def adapter(x: Tensor, w: W) -> Tensor:
+    """AdapterModel.forward, alpha = 0.5 (reference clip_adapter/model.py:25-32)."""
+    y = lin(torch.relu(lin(x, w, "clip_adapter.fc1")), w, "clip_adapter.fc2")
+    return 0.5 * y + 0.5 * x
+
+
+def distance_bias(centre: Tensor, w: W) -> Tensor:
+    """MMG.forward preamble for ONE scene (reference network_MMG.py:190-203) and
+    self_attn_fc (:165-173).  centre [n,3] -> bias [H,n,n] with bias[h,a,b] for query a, key b;
+    the 4-vector is (c_b - c_a, ||c_b - c_a||)."""
+    d = centre[None, :, :] - centre[:, None, :]
+    x = torch.cat([d, d.pow(2).sum(-1, keepdim=True).sqrt()], -1)
+    p = "mmg.self_attn_fc."
+    t = torch.relu(lin(x, w, p + "0"))
+    t = F.layer_norm(t, (32,), w[p + "2.weight"], w[p + "2.bias"], 1e-5)
+    t = torch.relu(lin(t, w, p + "3"))
+    t = F.layer_norm(t, (32,), w[p + "5.weight"], w[p + "5.bias"], 1e-5)
+    return lin(t, w, p + "6").permute(2, 0, 1).contiguous()
+
+
+def mha(q_in: Tensor, kv_in: Tensor, w: W, prefix: str, n_heads: int,
+        bias: Optional[Tensor] = None, q_chunk: int = 1024) -> Tensor:
+    """MultiHeadAttention.forward (post-LN residual; reference transformer/attention.py:105-126)
+    around ScaledDotProductAttention.forward (:41-78) for one scene: no mask needed (the
+    block-diagonal mask of network_MMG.py:188-193 only separates scenes), additive ``bias``.
+    Queries are processed in chunks so the E x E score matrix of the edge cross-attention
+    (network_MMG.py:231) is never materialised whole (cfg 5)."""
+    nq, nk = q_in.shape[0], kv_in.shape[0]
+    p = prefix + ".attention."
+    dk = q_in.shape[1] // n_heads
+    q = lin(q_in, w, p + "fc_q").view(nq, n_heads, dk).permute(1, 0, 2)
+    k = lin(kv_in, w, p + "fc_k").view(nk, n_heads, dk).permute(1, 2, 0)
+    v = lin(kv_in, w, p + "fc_v").view(nk, n_heads, dk).permute(1, 0, 2)
+    outs = []
+    for s in range(0, nq, q_chunk):
+        att = torch.matmul(q[:, s:s + q_chunk], k) / math.sqrt(dk)
+        if bias is not None:
+            att = att + bias[:, s:s + q_chunk]
+        att = torch.softmax(att, -1)
+        outs.append(torch.matmul(att, v))
+    o = torch.cat(outs, 1).permute(1, 0, 2).reshape(nq, n_heads * dk)
+    o = lin(o, w, p + "fc_o")
+    return F.layer_norm(q_in + o, (q_in.shape[1],), w[prefix + ".layer_norm.weight"],
+                        w[prefix + ".layer_norm.bias"], 1e-5)
+
+
+def edge_atten(x: Tensor, e: Tensor, ei: Tensor, w: W, prefix: str, n_heads: int,
+               taps: Optional[dict] = None):
+    """MultiHeadedEdgeAttention.forward, attention='fat', use_edge=True
+    (reference network_MMG.py:84-112).  Returns (gated [E,A], edge' [E,512], prob [E,A/H,H]).
+    NOTE the head-minor layout: view(E, d, heads) (:97-98)."""
+    xi, xj = gen_index(x, ei, "target_to_source")
+    E = e.shape[0]
+    p = prefix + ".edgeatten."
+    e_new = lin(torch.relu(lin(torch.cat([xi, e, xj], 1), w, p + "nn_edge.0")), w, p + "nn_edge.2")
+    v = lin(xj, w, p + "proj_value.0")
+    q = lin(xi, w, p + "proj_query.0").view(E, -1, n_heads)
+    k = lin(e, w, p + "proj_edge.0").view(E, -1, n_heads)
+    z = torch.cat([q, k], 1)                                             # [E, dn+de, H]
+    w0, b0 = w[p + "nn.0.weight"][:, :, 0], w[p + "nn.0.bias"]
+    w3, b3 = w[p + "nn.3.weight"][:, :, 0], w[p + "nn.3.bias"]
+    z = torch.relu(torch.einsum("oc,ech->eoh", w0, z) + b0[None, :, None])
+    z = torch.einsum("oc,ech->eoh", w3, z) + b3[None, :, None]
+    prob = z.softmax(1)
+    gated = prob.reshape(E, -1) * v
+    return gated, e_new, prob
+
+
+def gcn_layer(x: Tensor, e: Tensor, ei: Tensor, w: W, prefix: str, n_heads: int, aggr: str,
+              taps: Optional[dict] = None, tapname: str = ""):
+    """GraphEdgeAttenNetwork.forward (reference network_MMG.py:34-41)."""
+    gated, e_new, prob = edge_atten(x, e, ei, w, prefix, n_heads)
+    agg = aggre_index(gated, ei, x.shape[0], aggr, "target_to_source")
+    x_new = lin(torch.relu(lin(torch.cat([x, agg], 1), w, prefix + ".prop.0")), w, prefix + ".prop.2")
+    if taps is not None and tapname:
+        taps[tapname + ".gated"] = gated
+        taps[tapname + ".prob"] = prob
+        taps[tapname + ".agg"] = agg
+        taps[tapname + ".node"] = x_new
+        taps[tapname + ".edge"] = e_new
+    return x_new, e_new
+
+
+def mmg(x3: Tensor, x2: Tensor, e3: Tensor, e2: Tensor, ei: Tensor, centre: Tensor, w: W,
+        n_layers: int, n_heads: int, aggr: str, taps: Optional[dict] = None):
+    """MMG.forward for ONE scene (reference network_MMG.py:178-250)."""
+    bias = distance_bias(centre, w)
+    if taps is not None:
+        taps["dist_bias"] = bias
+    for l in range(n_layers):
+        x3 = mha(x3, x3, w, f"mmg.self_attn.{l}", n_heads, bias)              # :217
+        x2 = mha(x2, x3, w, f"mmg.cross_attn.{l}", n_heads, bias)             # :218 (updated x3)
+        if taps is not None and l == 0:
+            taps["self_attn0"], taps["cross_attn0"] = x3, x2
+        x3, e3 = gcn_layer(x3, e3, ei, w, f"mmg.gcn_3ds.{l}", n_heads, aggr, taps, "gcn3d0" if l == 0 else "")
+        x2, e2 = gcn_layer(x2, e2, ei, w, f"mmg.gcn_2ds.{l}", n_heads, aggr, taps, "gcn2d0" if l == 0 else "")
+        e2 = mha(e2, e3, w, f"mmg.cross_attn_rel.{l}", n_heads)               # :231 no mask, no bias
+        if taps is not None and l == 0:
+            taps["cross_attn_rel0"] = e2
+        if l < n_layers - 1 or n_layers == 1:                                   # :236
+            x3, x2, e3, e2 = torch.relu(x3), torch.relu(x2), torch.relu(e3), torch.relu(e2)
+    return x3, x2, e3, e2
+
+
+def rel_head(e: Tensor, w: W, prefix: str) -> Tensor:
+    """PointNetRelClsMulti.forward, use_bn=False, dropout=id (reference network_PointNet.py:328-341)."""
+    h = torch.relu(lin(e, w, prefix + ".fc1"))
+    h = torch.relu(lin(h, w, prefix + ".fc2"))
+    return torch.sigmoid(lin(h, w, prefix + ".fc3"))
+
+
+def obj_head(x: Tensor, w: W, prefix: str, logit_scale: float) -> Tensor:
+    """exp(s) * Linear(x / ||x||)  (reference SGFN_MMG/model.py:327-330)."""
+    return math.exp(logit_scale) * lin(x / x.norm(dim=-1, keepdim=True), w, prefix)
+
+
+def forward_scene(w: W, cfg, obj_points: Tensor, obj_2d_feats: Tensor, edge_indices: Tensor,
+                  descriptor: Tensor, taps: Optional[dict] = None):
+    """Mmgnet.forward(istrain=False) for one scene (reference SGFN_MMG/model.py:288-335).
+    The dead generate_object_pair_features / triplet_projector_2d (:319,322) are skipped:
+    their result is unused at eval."""
+    f = pointnet_feat(obj_points, w, "obj_encoder")                              # :290
+    x3 = node_embed(f, descriptor, w)                                            # :294-299
+    ed = edge_descriptor(descriptor, edge_indices)                               # :302-303
+    e2 = pointnet_feat(ed[:, :, None], w, "rel_encoder_2d")                      # :305
+    e3 = pointnet_feat(ed[:, :, None], w, "rel_encoder_3d")                      # :306
+    x2 = adapter(obj_2d_feats, w)                                                # :309-310
+    if taps is not None:
+        taps.update(obj_encoder=f, node_embed=x3, edge_descriptor=ed, rel_encoder_2d=e2,
+                    rel_encoder_3d=e3, clip_adapter=x2)
+    x3, x2, e3, e2 = mmg(x3, x2, e3, e2, edge_indices, descriptor[:, :3], w,
+                         cfg.N_LAYERS, cfg.NUM_HEADS, cfg.GCN_AGGR, taps)        # :314-316
+    if taps is not None:
+        taps.update({"mmg.0": x3, "mmg.1": x2, "mmg.2": e3, "mmg.3": e2})
+    rel3 = rel_head(e3, w, "rel_predictor_3d")                                   # :324
+    rel2 = rel_head(e2, w, "rel_predictor_2d")                                   # :325
+    obj3 = obj_head(x3, w, "obj_predictor_3d", cfg.obj_logit_scale)              # :329
+    obj2 = obj_head(x2, w, "obj_predictor_2d", cfg.obj_logit_scale)              # :330
+    return obj3, obj2, rel3, rel2
+
+
+@torch.no_grad()
+def forward(w: W, cfg, obj_points: Tensor, obj_2d_feats: Tensor, edge_indices: Tensor,
+            descriptor: Tensor, batch_ids: Optional[Tensor] = None, taps: Optional[dict] = None):
+    """Batch entry with the reference's tensor signature; evaluates scene by scene.
+    Scenes must be contiguous in node order; each edge belongs to the scene of its source."""
+    n = obj_points.shape[0]
+    if batch_ids is None:
+        batch_ids = torch.zeros(n, 1, dtype=torch.long)
+    bid = batch_ids.view(-1)
+    e_scene = bid[edge_indices[0]]
+    outs = [[], [], [], []]
+    rel_order = []
+    for s in torch.unique_consecutive(bid).tolist():
+        nodes = torch.nonzero(bid == s).view(-1)
+        lo, hi = int(nodes[0]), int(nodes[-1]) + 1
+        assert hi - lo == nodes.numel(), "scene nodes must be contiguous"
+        eids = torch.nonzero(e_scene == s).view(-1)
+        ei = edge_indices[:, eids] - lo
+        o = forward_scene(w, cfg, obj_points[lo:hi], obj_2d_feats[lo:hi], ei, descriptor[lo:hi],
+                          taps if len(outs[0]) == 0 else None)
+        for a, b in zip(outs, o):
+            a.append(b)
+        rel_order.append(eids)
+    obj3, obj2 = torch.cat(outs[0]), torch.cat(outs[1])
+    order = torch.cat(rel_order)
+    rel3 = torch.empty(edge_indices.shape[1], outs[2][0].shape[1], dtype=obj3.dtype)
+    rel2 = torch.empty_like(rel3)
+    rel3[order] = torch.cat(outs[2])
+    rel2[order] = torch.cat(outs[3])
+    return obj3, obj2, rel3, rel2
+
+
+def to_torch(weights_np: dict, dtype=torch.float32) -> W:
+    return {k: torch.from_numpy(v).to(dtype) for k, v in weights_np.items()}
