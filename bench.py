@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""bench.py -- scenes/s of the VL-SAT eval forward on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path (Mmgnet.forward eval, all four outputs) over one batch of
+synthetic 3RScan-shaped scenes per GPU: BASELINE.json configs[1] = 64 scenes x 40 objects x 256
+points, fully-connected edges (E = 1560 per scene), 3 GNN layers, fp32 (exact-fp32 MFMA).
+Inputs and weights are resident in HBM before the timed region.  Multi-GPU: scenes are sharded
+(weak scaling, 64 scenes per GPU, no data-path collective); the metrics vector is all-reduced
+once per step over RCCL.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import vlsat_amd  # noqa: E402
+from vlsat_amd import VLSATConfig, synth, dist as vdist  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
+
+
+def f_alg(n, p, e, l):
+    """Algorithmic (minimal-algebra, eval-live) FLOPs per scene: SURVEY.md §8a/§8d F_alg."""
+    return (213376 * n * p + 774144 * n + 297728 * e + 524288 * n + 2816 * n * n
+            + l * (2 * (2097152 * n + 2048 * n * n) + 2 * (2949120 * e + 4849664 * n) + (2097152 * e + 2048 * e * e))
+            + 2 * 799744 * e + 2 * 163840 * n)
+
+
+def cpu_baseline(cfg, n_obj, n_pts, budget_s=15.0, max_scenes=8):
+    """The CPU oracle (torch fp32 port of the reference, one scene per call like validation())
+    timed on this box's host cores on a bounded sample of the same workload."""
+    from oracle import vlsat_oracle as O
+    w = O.to_torch(synth.make_weights(cfg))
+    t_used, n_done, first = 0.0, 0, None
+    torch.set_num_threads(os.cpu_count() or 1)
+    for s in range(max_scenes):
+        b = {k: torch.from_numpy(v) for k, v in synth.make_batch(1, n_obj, n_pts, seed0=1000 + s).items()}
+        t0 = time.perf_counter()
+        out = O.forward(w, cfg, b["obj_points"], b["obj_2d_feats"], b["edge_indices"], b["descriptor"], b["batch_ids"])
+        dt = time.perf_counter() - t0
+        if s == 0:
+            first = out
+            if max_scenes > 1:
+                continue                      # scene 0 = warm-up (thread pool, allocator), not timed
+        t_used += dt
+        n_done += 1
+        if t_used > budget_s:
+            break
+    return {"value": n_done / t_used, "unit": "scenes/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n_done} scenes of {n_obj} objects x {n_pts} points (L={cfg.N_LAYERS}), one scene per call, "
+                      f"after 1 warm-up scene; torch {torch.__version__} CPU fp32"}, first
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scenes", type=int, default=64, help="scenes per GPU per step")
+    ap.add_argument("--objects", type=int, default=40)
+    ap.add_argument("--points", type=int, default=256)
+    ap.add_argument("--layers", type=int, default=3)
+    ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    args = ap.parse_args()
+
+    rank, local, world = vdist.init()
+    if world != args.gpus:
+        if args.gpus != 1 or world != 1:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
+                  file=sys.stderr)
+            sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no MI355X visible; the HIP path has no CPU fallback", file=sys.stderr)
+        sys.exit(3)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    from vlsat_amd.model import VLSATModel
+
+    cfg = VLSATConfig(N_LAYERS=args.layers)
+    model = VLSATModel(cfg, str(dev)).load_state(synth.make_weights(cfg)).eval()
+    # this rank's shard of the global scene list (weak scaling: args.scenes per GPU)
+    scenes = vdist.shard(args.scenes * world, rank, world)
+    batch = synth.collate([synth.make_scene(args.objects, args.points, 1000 + s) for s in scenes])
+    d = {k: torch.from_numpy(v).to(dev) for k, v in batch.items()}
+    n_scenes = len(scenes)
+
+    def step():
+        out = model(d["obj_points"], d["obj_2d_feats"], d["edge_indices"], d["descriptor"], d["batch_ids"])
+        m = vdist.allreduce_metrics(vdist.scene_metrics(out, n_scenes))
+        return out, m
+
+    for _ in range(args.warmup):
+        out, metrics = step()
+    torch.cuda.synchronize()
+    prof = not args.no_profile
+    if prof:
+        model.profile_enable(True)
+        model.profile_read()
+    vdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out, metrics = step()
+    torch.cuda.synchronize()
+    vdist.barrier()
+    dt = vdist.max_over_ranks(time.perf_counter() - t0, dev)
+    classes = model.profile_read() if prof else {}
+    model.profile_enable(False)
+
+    if rank != 0:
+        return
+    total_scenes = float(metrics[0].item()) if world > 1 else n_scenes
+    value = total_scenes * args.steps / dt
+    e_scene = args.objects * (args.objects - 1)
+    falg = f_alg(args.objects, args.points, e_scene, args.layers)
+
+    roofline = None
+    if classes:
+        dom = max(classes, key=lambda k: classes[k]["ms"])
+        c = classes[dom]
+        avg_ms = c["ms"] / max(c["launches"], 1)
+        achieved = c["flops"] / (c["ms"] * 1e-3) / 1e12 if c["ms"] > 0 else 0.0
+        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": c["launches"] // args.steps, "avg_launch_ms": round(avg_ms, 4),
+                    "flop_per_launch": c["flops"] / max(c["launches"], 1),
+                    "whole_forward_tflops": round(falg * value / world / 1e12, 2),
+                    "whole_forward_frac": round(falg * value / world / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                    "time_share": {k: round(v["ms"] / max(sum(x["ms"] for x in classes.values()), 1e-9), 4)
+                                   for k, v in classes.items()},
+                    "class_tflops": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)
+                                     for k, v in classes.items() if v["ms"] > 0 and v["flops"] > 0}}
+
+    cpu, err = None, None
+    if world == 1 and not args.no_cpu:
+        cpu, ref0 = cpu_baseline(cfg, args.objects, args.points)
+        n, e = args.objects, e_scene
+        got0 = [out[0][:n], out[1][:n], out[2][:e], out[3][:e]]
+        err = {k: float((g.cpu() - r).abs().max()) for k, g, r in zip(("obj3d", "obj2d", "rel3d", "rel2d"), got0, ref0)}
+
+    line = {
+        "metric": "scenes/sec (3RScan-shaped, N=40 obj x 256 pts)", "value": round(value, 2), "unit": "scenes/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[1]: batch of {args.scenes} synthetic scenes per GPU, "
+                               f"{args.objects} objects x {args.points} pts, fully-connected edges "
+                               f"(E={e_scene}/scene), {args.layers} GNN layers, fp32",
+                   "scenes_per_gpu": args.scenes, "parallelism": f"scene-sharded x{world}"},
+        "flop_per_scene_alg": falg,
+        "roofline": roofline, "cpu_baseline": cpu, "max_abs_err_vs_cpu_oracle": err,
+        "speedup_vs_cpu": round(value / cpu["value"], 1) if cpu else None,
+    }
+    print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

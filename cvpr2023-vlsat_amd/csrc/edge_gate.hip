@@ -1,0 +1,129 @@
+// 'fat' edge gate of MultiHeadedEdgeAttention.forward (reference network_MMG.py:96-104):
+//   q = proj_query(x_i).view(E,64,8); k = proj_edge(e).view(E,64,8)          (head = FAST axis)
+//   prob = softmax_dim1( Conv1d(128->32)( ReLU( Conv1d(128->128)( cat[q,k] ) ) ) )   [E,32,8]
+//   gated = prob.reshape(E,256) * proj_value(x_j)
+//
+// Algebra used here (weights prepared once in vlsat_finalize_weights):
+//   * the q half of layer 1 only depends on the SOURCE node -> Gq[n, h*128+o] (bias included)
+//     is computed per node by the node-side GEMM and gathered here;
+//   * proj_edge rows are permuted so k arrives head-major: kproj[e, h*64 + c] == k[e, c, h];
+//     the [E,512] matrix is then a contiguous [8E, 64] matrix of (edge, head) rows.
+// Per (edge, head) row:  hidden = relu(Gq + W0k . kproj_row);  logits = W3 . hidden + b3;
+// prob = softmax(logits);  gated[e, m*8+h] = prob[m] * value[dst[e], m*8+h].
+//
+// fp32 MFMA, transposed products so that a lane owns ONE (edge, head) row:
+//   hidden^T[o][row] : A = W0k (LDS), B = kproj rows straight from HBM (float4 per lane)
+//   logits^T[m][row] : A = W3 (LDS), B = hidden^T registers of layer 1 (no LDS round trip)
+// so the softmax over the 32 channels is 15 in-lane ops + one lane^32 exchange.
+// One wave = 32 rows = 4 edges per step (192 MFMAs); a block of 4 waves walks 16-edge groups.
+#include "gemm_core.h"
+#include "kernels.h"
+
+namespace vlsat {
+
+constexpr int GT_PITCH = 68;     // W0k rows: 64 + 4 pad
+constexpr int GT_PITCH3 = 132;   // W3 rows: 128 + 4 pad
+
+__global__ __launch_bounds__(256, 2) void edge_gate_kernel(GateArgs p) {
+    __shared__ __attribute__((aligned(16))) float sW0[128 * GT_PITCH];
+    __shared__ __attribute__((aligned(16))) float sW3[32 * GT_PITCH3];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, hi = lane >> 5;
+
+    for (int i = tid; i < 128 * 16; i += 256) {
+        const int r = i >> 4, c4 = (i & 15) * 4;
+        *reinterpret_cast<f32x4*>(sW0 + r * GT_PITCH + c4) = *reinterpret_cast<const f32x4*>(p.w0k + r * 64 + c4);
+    }
+    for (int i = tid; i < 32 * 32; i += 256) {
+        const int r = i >> 5, c4 = (i & 31) * 4;
+        *reinterpret_cast<f32x4*>(sW3 + r * GT_PITCH3 + c4) = *reinterpret_cast<const f32x4*>(p.w3 + r * 128 + c4);
+    }
+    float b3f[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) b3f[r] = p.b3[crow32(r, hi)];
+    __syncthreads();
+
+    const int n_groups = (p.n_edges + 15) / 16;
+    for (int g = blockIdx.x; g < n_groups; g += gridDim.x) {
+        // the weight fragments are loop-invariant; without this clobber LICM hoists all 192 of
+        // them into VGPRs and the kernel spills.  Re-reading them from LDS per step is free.
+        asm volatile("" ::: "memory");
+        const int e_raw = g * 16 + wave * 4 + (li >> 3);
+        const int h = li & 7;
+        const bool valid = e_raw < p.n_edges;
+        const int e = valid ? e_raw : p.n_edges - 1;
+        const float* zrow = p.kproj + (size_t)e * 512 + h * 64 + 4 * hi;
+        f32x4 z[8];
+#pragma unroll
+        for (int kg = 0; kg < 8; ++kg) z[kg] = *reinterpret_cast<const f32x4*>(zrow + kg * 8);
+        const int sn = p.src[e], dn = p.dst[e];
+
+        // Per 32-wide slice `to` of the hidden layer: layer 1 (32 MFMAs) then immediately its
+        // contribution to layer 2 (16 MFMAs), so only one 32x32 accumulator is live at a time.
+        const float* gq = p.node + (size_t)sn * p.ld_node + p.gq_off + h * 128 + 4 * hi;
+        f32x16 lg;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) lg[r] = b3f[r];
+#pragma unroll
+        for (int to = 0; to < 4; ++to) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int kg = 0; kg < 8; ++kg) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(sW0 + (to * 32 + li) * GT_PITCH + kg * 8 + 4 * hi);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], z[kg][s], acc, 0, 0, 0);
+            }
+            // hidden = relu(acc + Gq[src, h*128 + o]),  o = to*32 + 8*r4 + 4*hi + c
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const f32x4 gqv = *reinterpret_cast<const f32x4*>(gq + to * 32 + 8 * r4);
+                // layer-2 A fragment: W3[m = li][o = to*32 + 8*r4 + 4*hi + c]
+                const f32x4 w3v = *reinterpret_cast<const f32x4*>(sW3 + li * GT_PITCH3 + to * 32 + 8 * r4 + 4 * hi);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float hid = fmaxf(acc[r4 * 4 + c] + gqv[c], 0.f);
+                    lg = __builtin_amdgcn_mfma_f32_32x32x2f32(w3v[c], hid, lg, 0, 0, 0);
+                }
+            }
+        }
+        // softmax over the 32 channels m = crow32(r, hi) (+ the other 16 in lane^32)
+        float mx = lg[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, lg[r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            lg[r] = __expf(lg[r] - mx);
+            sum += lg[r];
+        }
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.f / sum;
+        if (valid) {
+            const float* vrow = p.node + (size_t)dn * p.ld_node + p.v_off + h;
+            float* grow = p.gated + (size_t)e * 256 + h;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = crow32(r, hi);
+                const float pr = lg[r] * inv;
+                grow[m * 8] = pr * vrow[m * 8];
+                if (p.prob) p.prob[(size_t)e * 256 + m * 8 + h] = pr;
+            }
+        }
+    }
+}
+
+int launch_edge_gate(const GateArgs& a, hipStream_t s) {
+    if (a.n_edges <= 0) return 0;
+    if ((a.ld_node & 3) || (a.gq_off & 3)) return fail(-1, "edge_gate: ld_node/gq_off must be multiples of 4");
+    const int n_groups = (a.n_edges + 15) / 16;
+    const int grid = n_groups < 2048 ? n_groups : 2048;
+    hipLaunchKernelGGL(edge_gate_kernel, dim3(grid), dim3(256), 0, s, a);
+    VLSAT_LAUNCH_CHECK("edge_gate");
+    return 0;
+}
+
+}  // namespace vlsat

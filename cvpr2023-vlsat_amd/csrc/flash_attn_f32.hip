@@ -1,0 +1,173 @@
+// Edge cross-attention core, flash style, exact fp32 on the matrix cores.
+// Replaces ScaledDotProductAttention.forward's  att = QK^T/sqrt(d); softmax; att.V
+// (reference transformer/attention.py:60-76) as called with q = 2D edges, k = v = 3D edges and
+// no mask/bias from MMG.forward (reference network_MMG.py:231).  The reference materialises
+// att [1,8,E,E] (and a clone); here the E x E scores never leave registers.
+//
+// Per scene (block-diagonal by construction: one tile entry = one scene), head h:
+//   block  = 128 queries (4 waves x 32), loops over the scene's keys in tiles of 32;
+//   S^T    = K_tile . Q^T   (32 keys x 32 queries per wave): A operand = K rows from LDS
+//            (ds_read_b128, 4 consecutive d per lane), B operand = Q held in 32 VGPRs/lane;
+//            "swapped" product so a lane owns ONE query column: its 16 registers are 16 keys,
+//            the other 16 keys sit in lane^32 -> the softmax row reductions are 15 in-lane
+//            max/add + one cross-half shuffle (no LDS);
+//   O^T   += V^T . P^T      : B operand = P straight from the S registers (k index = the key
+//            that register already holds), A operand = V[key][d] from LDS (ds_read_b32,
+//            conflict free: 32 lanes read 32 consecutive d);
+//   online softmax with running (m, l) per query, exp2 with log2(e) folded into the scale.
+// K/V tiles are double-buffered in LDS via register staging; one barrier per key tile
+// (64 MFMAs = 4096 cycles per wave between barriers).
+// Roofline: fp32 MFMA.  Algorithmic work 4*T^2*64 flop per (scene, head); HBM traffic is
+// Q,O once and K,V re-read once per 128-query block out of L2 (K,V of one scene-head =
+// T*64*4*2 B, 0.8 MB at T=1560): the same-scene blocks are made consecutive on one XCD.
+#include "gemm_core.h"
+#include "kernels.h"
+
+namespace vlsat {
+
+constexpr int FA_KV = 32;        // keys per tile
+constexpr int FA_D = 64;         // head dim
+constexpr int FA_PITCH = 68;     // LDS row pitch (floats): 16-B pad -> conflict-free b128 reads
+
+__global__ __launch_bounds__(256, 2) void flash_attn_f32_kernel(
+    const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
+    float* __restrict__ O, int ldq, int ldkv, int ldo, const int4* __restrict__ tiles, int n_tiles,
+    float scale_log2e) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * 2 * FA_KV * FA_PITCH];   // [buf][K|V][32][68]
+    constexpr int BUF = 2 * FA_KV * FA_PITCH;
+
+    const int4 t = tiles[xcd_remap(blockIdx.x, n_tiles)];
+    const int row_base = t.x, n_tok = t.y, q0 = t.z, head = t.w;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, hi = lane >> 5;
+    const size_t col0 = (size_t)head * FA_D;
+
+    // ---- this lane's query row: d = 32*hi + s, s = 0..31 (pre-scaled) ----
+    int qrow = q0 + wave * 32 + li;
+    if (qrow >= n_tok) qrow = n_tok - 1;      // clamped rows are computed but never stored
+    float q[32];
+    {
+        const float* qp = Q + (size_t)(row_base + qrow) * ldq + col0 + 32 * hi;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(qp + 4 * g);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) q[4 * g + c] = x[c] * scale_log2e;
+        }
+    }
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+
+    // staging: K and V tile each [32][64] = 512 float4; thread -> rows (tid>>4) and +16
+    const int srow = tid >> 4, sc4 = (tid & 15) * 4;
+    f32x4 rk[2], rv[2];
+    auto load_tile = [&](int kv0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int r = kv0 + srow + 16 * i;
+            r = r < n_tok ? r : n_tok - 1;
+            const size_t off = (size_t)(row_base + r) * ldkv + col0 + sc4;
+            rk[i] = *reinterpret_cast<const f32x4*>(K + off);
+            rv[i] = *reinterpret_cast<const f32x4*>(V + off);
+        }
+    };
+    auto store_tile = [&](float* buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<f32x4*>(buf + (srow + 16 * i) * FA_PITCH + sc4) = rk[i];
+            *reinterpret_cast<f32x4*>(buf + FA_KV * FA_PITCH + (srow + 16 * i) * FA_PITCH + sc4) = rv[i];
+        }
+    };
+
+    const int n_kv_tiles = (n_tok + FA_KV - 1) / FA_KV;
+    load_tile(0);
+    store_tile(smem);
+    __syncthreads();
+
+    for (int kt = 0; kt < n_kv_tiles; ++kt) {
+        const float* sK = smem + (kt & 1) * BUF;
+        const float* sV = sK + FA_KV * FA_PITCH;
+        const bool more = kt + 1 < n_kv_tiles;
+        if (more) load_tile((kt + 1) * FA_KV);
+
+        // ---- S^T[key][query] = sum_d K[key][d] * Q[query][d] ----
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const f32x4 kf = *reinterpret_cast<const f32x4*>(sK + li * FA_PITCH + 32 * hi + 4 * g);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[c], q[4 * g + c], s, 0, 0, 0);
+        }
+        // keys beyond the scene's token count (last tile only)
+        if (kt == n_kv_tiles - 1) {
+            const int kv0 = kt * FA_KV;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (kv0 + crow32(r, hi) >= n_tok) s[r] = -INFINITY;
+        }
+        // ---- online softmax for this lane's query ----
+        float mx = s[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        float rs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[r] = __builtin_amdgcn_exp2f(s[r] - m_new);
+            rs += s[r];
+        }
+        rs += __shfl_xor(rs, 32);
+        l_run = l_run * alpha + rs;
+        m_run = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+        // ---- O^T[d][query] += sum_key V[key][d] * P[key][query] ----
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float* vp = sV + crow32(r, hi) * FA_PITCH + li;
+            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[0], s[r], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[32], s[r], o1, 0, 0, 0);
+        }
+        if (more) store_tile(smem + ((kt + 1) & 1) * BUF);
+        __syncthreads();
+    }
+
+    // ---- normalise, transpose through LDS (wave-private [32 q][68]), coalesced store ----
+    const float inv_l = 1.f / l_run;
+    float* so = smem + wave * (32 * FA_PITCH);     // 4 x 8704 B = all of smem
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        so[li * FA_PITCH + crow32(r, hi)] = o0[r] * inv_l;
+        so[li * FA_PITCH + 32 + crow32(r, hi)] = o1[r] * inv_l;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = lane + 64 * i;             // 512 float4 = 32 rows x 16
+        const int r = idx >> 4, c4 = (idx & 15) * 4;
+        const int qr = q0 + wave * 32 + r;
+        if (qr < n_tok)
+            *reinterpret_cast<f32x4*>(O + (size_t)(row_base + qr) * ldo + col0 + c4) =
+                *reinterpret_cast<const f32x4*>(so + r * FA_PITCH + c4);
+    }
+}
+
+int launch_flash_attn(const float* Q, int ldq, const float* K, const float* V, int ldkv, float* O, int ldo,
+                      const int4* tiles, int n_tiles, float scale_log2e, hipStream_t s) {
+    if (n_tiles <= 0) return 0;
+    if ((ldq | ldkv | ldo) & 3) return fail(-1, "flash_attn: leading dims must be multiples of 4");
+    hipLaunchKernelGGL(flash_attn_f32_kernel, dim3(n_tiles), dim3(256), 0, s, Q, K, V, O, ldq, ldkv, ldo, tiles,
+                       n_tiles, scale_log2e);
+    VLSAT_LAUNCH_CHECK("flash_attn_f32");
+    return 0;
+}
+
+}  // namespace vlsat

@@ -1,0 +1,87 @@
+// Host-side launchers of the hand-written gfx950 kernels (internal C++ interface between the
+// engine and the .hip files; the public surface is include/vlsat.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vlsat {
+
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2 };
+
+// C[M,N] = act(rowscale[m]*(reluA?(A) . W^T) + bias[n] + resid_scale*resid[m,n] + g0[gi0[m],n] + g1[gi1[m],n])
+struct GemmArgs {
+    const float* A = nullptr; int lda = 0;      // [M,K]
+    const float* W = nullptr; int ldw = 0;      // [N,K]  (nn.Linear layout)
+    float* C = nullptr;       int ldc = 0;      // [M,N]
+    int M = 0, N = 0, K = 0;
+    const float* bias = nullptr;                // [N]
+    const float* rowscale = nullptr;            // [M]
+    const float* resid = nullptr; int ldr = 0; float resid_scale = 1.f;
+    const float* g0 = nullptr; const int32_t* gi0 = nullptr; int ldg0 = 0;   // gathered row add
+    const float* g1 = nullptr; const int32_t* gi1 = nullptr; int ldg1 = 0;
+    int relu_a = 0;                             // apply ReLU to A while staging
+    int act = ACT_NONE;
+};
+int launch_gemm(const GemmArgs& a, hipStream_t s);
+double gemm_flops(const GemmArgs& a);
+
+// ---- PointNet object encoder (fused conv1..conv3 + ReLU + max over points) ----
+int launch_pointnet(const float* pts, int n_obj, int n_points, const float* w1, const float* b1,
+                    const float* w2, const float* b2, const float* w3, const float* b3, int n_out,
+                    float* out, hipStream_t s);
+
+// ---- edge cross-attention (flash style, fp32 MFMA) ----
+// tiles: device array of int4 {row_base, n_tokens, q0, head}; one block per entry.
+int launch_flash_attn(const float* Q, int ldq, const float* K, const float* V, int ldkv, float* O, int ldo,
+                      const int4* tiles, int n_tiles, float scale_log2e, hipStream_t s);
+constexpr int FLASH_BQ = 128;   // queries per block
+
+// ---- node attention with distance bias (per scene, per head) ----
+// scene_ptr: device [n_scenes+1] node offsets; bias_ptr: device [n_scenes] offsets into bias
+// (layout per scene: [H][n][n], query-major).  grid covers max_n queries per scene.
+int launch_node_attn(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,
+                     float* O, int ldo, const float* bias, const int32_t* scene_ptr,
+                     const int64_t* bias_ptr, int n_scenes, int max_n, int n_heads, float scale,
+                     hipStream_t s);
+// distance-bias MLP (MMG.self_attn_fc): centres = desc[:,0:3] (ld = 11)
+struct DistBiasW { const float *w0, *b0, *g2, *be2, *w3, *b3, *g5, *be5, *w6, *b6; };
+int launch_dist_bias(const float* desc, int ld_desc, const int32_t* scene_ptr, const int64_t* bias_ptr,
+                     int n_scenes, int max_n, int n_heads, DistBiasW w, float* bias, hipStream_t s);
+
+// ---- small fused VALU kernels ----
+// edge descriptor (Gen_edge_descriptor) + conv1 of both relation encoders:
+// h1[e, 0:64] = relu(W1_3d ed + b), h1[e, 64:128] = relu(W1_2d ed + b)
+int launch_edge_embed(const float* desc, const int32_t* src, const int32_t* dst, int n_edges,
+                      const float* w1cat /*[128,11]*/, const float* b1cat /*[128]*/, float* h1, hipStream_t s);
+// x3[n, 504:512] = [desc[3:9], log desc[9], log desc[10]]
+int launch_desc_tail(const float* desc, int n_nodes, float* x, int ldx, int col0, hipStream_t s);
+// in-place LayerNorm over rows of `dim` (dim == 512), optional ReLU
+int launch_layernorm(float* x, int ld, int rows, int dim, const float* gamma, const float* beta, int relu,
+                     hipStream_t s);
+// rowscale[m] = scale / ||x[m,:]||_2  (dim == 512)
+int launch_row_invnorm(const float* x, int ld, int rows, int dim, float scale, float* out, hipStream_t s);
+
+// ---- 'fat' edge gate: per (edge, head) MLP 128->128->32, softmax over 32, times value ----
+struct GateArgs {
+    const float* kproj;      // [E, 512] head-major: kproj[e, h*64 + c]
+    const float* node;       // node-side buffer, row pitch ld_node
+    int ld_node;
+    int gq_off;              // column offset of Gq[h*128 + o] (layer-1 node part incl. bias)
+    int v_off;               // column offset of value[m*8 + h]
+    const int32_t* src;      // [E]
+    const int32_t* dst;      // [E]
+    const float* w0k;        // [128, 64]  layer-1 weights acting on the edge half
+    const float* w3;         // [32, 128]
+    const float* b3;         // [32]
+    float* gated;            // [E, 256]  gated[e, m*8 + h]
+    float* prob;             // optional [E, 32, 8] tap (tests) or nullptr
+    int n_edges;
+};
+int launch_edge_gate(const GateArgs& a, hipStream_t s);
+
+// ---- scatter aggregation by source node over a CSR (rowptr[N+1], order[E]) ----
+// out[n, col0 + c] = reduce_{k in rowptr[n]..rowptr[n+1]} gated[order[k], c]; empty -> 0
+int launch_aggregate(const float* gated, int n_ch, const int32_t* rowptr, const int32_t* order,
+                     int n_nodes, int aggr, float* out, int ldo, int col0, hipStream_t s);
+
+}  // namespace vlsat

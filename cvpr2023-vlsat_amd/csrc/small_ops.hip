@@ -1,0 +1,330 @@
+// Small fused VALU kernels of the path (all HBM/latency-bound glue around the MFMA kernels).
+#include "common.h"
+#include "kernels.h"
+
+namespace vlsat {
+
+// ------------------------------------------------------------------------------------------
+// Edge descriptor + first layer of both relation encoders.
+//   ed = [x_i[0:6] - x_j[0:6], log(x_i[6:11] / x_j[6:11])]   with x_i = desc[src], x_j = desc[dst]
+//   (Gen_edge_descriptor.message, flow='target_to_source': reference src/utils/op_utils.py:78-97)
+//   h1[e, c] = relu(W1cat[c, :] . ed + b1cat[c]),  c < 64: rel_encoder_3d.conv1, c >= 64: rel_encoder_2d.conv1
+//   (PointNetfeat conv1 with point_size = 11, P = 1: reference network_PointNet.py:141-144)
+// Block = 64 edges: 64 threads build the descriptors in LDS, then 256 threads x 32 outputs.
+__global__ __launch_bounds__(256) void edge_embed_kernel(const float* __restrict__ desc,
+                                                         const int32_t* __restrict__ src,
+                                                         const int32_t* __restrict__ dst, int n_edges,
+                                                         const float* __restrict__ w1cat,
+                                                         const float* __restrict__ b1cat, float* __restrict__ h1) {
+    __shared__ float sE[64][12];
+    __shared__ float sWt[11][129];     // transposed weights, padded
+    __shared__ float sB[128];
+    const int tid = threadIdx.x;
+    const int e0 = blockIdx.x * 64;
+    for (int i = tid; i < 128 * 11; i += 256) sWt[i % 11][i / 11] = w1cat[i];
+    if (tid < 128) sB[tid] = b1cat[tid];
+    if (tid < 64) {
+        int e = e0 + tid;
+        e = e < n_edges ? e : n_edges - 1;
+        const float* a = desc + (size_t)src[e] * 11;
+        const float* b = desc + (size_t)dst[e] * 11;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) sE[tid][c] = a[c] - b[c];
+#pragma unroll
+        for (int c = 6; c < 11; ++c) sE[tid][c] = logf(a[c] / b[c]);
+    }
+    __syncthreads();
+    const int c = tid & 127;
+    float w[11];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) w[k] = sWt[k][c];
+    const float bb = sB[c];
+    for (int el = tid >> 7; el < 64; el += 2) {
+        const int e = e0 + el;
+        if (e >= n_edges) break;
+        float acc = bb;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) acc = fmaf(w[k], sE[el][k], acc);
+        h1[(size_t)e * 128 + c] = fmaxf(acc, 0.f);
+    }
+}
+
+int launch_edge_embed(const float* desc, const int32_t* src, const int32_t* dst, int n_edges,
+                      const float* w1cat, const float* b1cat, float* h1, hipStream_t s) {
+    if (n_edges <= 0) return 0;
+    hipLaunchKernelGGL(edge_embed_kernel, dim3((n_edges + 63) / 64), dim3(256), 0, s, desc, src, dst, n_edges,
+                       w1cat, b1cat, h1);
+    VLSAT_LAUNCH_CHECK("edge_embed");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Spatial tail of the 3D node feature: x[n, col0:col0+8] = [desc[3:9], log desc[9], log desc[10]]
+// (reference SGFN_MMG/model.py:296-299).
+__global__ void desc_tail_kernel(const float* __restrict__ desc, int n_nodes, float* __restrict__ x, int ldx,
+                                 int col0) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes * 8) return;
+    const int n = i >> 3, c = i & 7;
+    float v = desc[(size_t)n * 11 + 3 + c];
+    if (c >= 6) v = logf(v);
+    x[(size_t)n * ldx + col0 + c] = v;
+}
+int launch_desc_tail(const float* desc, int n_nodes, float* x, int ldx, int col0, hipStream_t s) {
+    if (n_nodes <= 0) return 0;
+    hipLaunchKernelGGL(desc_tail_kernel, dim3((n_nodes * 8 + 255) / 256), dim3(256), 0, s, desc, n_nodes, x, ldx, col0);
+    VLSAT_LAUNCH_CHECK("desc_tail");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// In-place LayerNorm over rows of 512 (eps 1e-5, biased variance = torch.nn.LayerNorm), optional
+// ReLU.  One wave per row, 8 values per lane as two float4 (columns 4*lane and 256 + 4*lane).
+// reference transformer/attention.py:122 (post-LN residual) and network_MMG.py:236-248 (ReLU).
+__global__ __launch_bounds__(256) void layernorm512_kernel(float* __restrict__ x, int ld, int rows,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, int relu) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float* p = x + (size_t)row * ld;
+    f32x4 a = *reinterpret_cast<const f32x4*>(p + 4 * lane);
+    f32x4 b = *reinterpret_cast<const f32x4*>(p + 256 + 4 * lane);
+    float s = a[0] + a[1] + a[2] + a[3] + b[0] + b[1] + b[2] + b[3];
+    const float mean = wave_sum(s) * (1.f / 512.f);
+    float v = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        a[c] -= mean; b[c] -= mean;
+        v += a[c] * a[c] + b[c] * b[c];
+    }
+    const float rstd = rsqrtf(wave_sum(v) * (1.f / 512.f) + 1e-5f);
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + 4 * lane);
+    const f32x4 gb = *reinterpret_cast<const f32x4*>(gamma + 256 + 4 * lane);
+    const f32x4 ba = *reinterpret_cast<const f32x4*>(beta + 4 * lane);
+    const f32x4 bb = *reinterpret_cast<const f32x4*>(beta + 256 + 4 * lane);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        a[c] = a[c] * rstd * ga[c] + ba[c];
+        b[c] = b[c] * rstd * gb[c] + bb[c];
+        if (relu) { a[c] = fmaxf(a[c], 0.f); b[c] = fmaxf(b[c], 0.f); }
+    }
+    *reinterpret_cast<f32x4*>(p + 4 * lane) = a;
+    *reinterpret_cast<f32x4*>(p + 256 + 4 * lane) = b;
+}
+int launch_layernorm(float* x, int ld, int rows, int dim, const float* gamma, const float* beta, int relu,
+                     hipStream_t s) {
+    if (rows <= 0) return 0;
+    if (dim != 512 || (ld & 3)) return fail(-1, "layernorm: dim must be 512 and ld a multiple of 4");
+    hipLaunchKernelGGL(layernorm512_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, ld, rows, gamma, beta, relu);
+    VLSAT_LAUNCH_CHECK("layernorm512");
+    return 0;
+}
+
+// rowscale[m] = scale / ||x[m, 0:512]||_2   (object heads: reference SGFN_MMG/model.py:327-330)
+__global__ __launch_bounds__(256) void row_invnorm512_kernel(const float* __restrict__ x, int ld, int rows,
+                                                             float scale, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* p = x + (size_t)row * ld;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p + 4 * lane);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(p + 256 + 4 * lane);
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) s += a[c] * a[c] + b[c] * b[c];
+    s = wave_sum(s);
+    if (lane == 0) out[row] = scale / sqrtf(s);
+}
+int launch_row_invnorm(const float* x, int ld, int rows, int dim, float scale, float* out, hipStream_t s) {
+    if (rows <= 0) return 0;
+    if (dim != 512 || (ld & 3)) return fail(-1, "row_invnorm: dim must be 512 and ld a multiple of 4");
+    hipLaunchKernelGGL(row_invnorm512_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, ld, rows, scale, out);
+    VLSAT_LAUNCH_CHECK("row_invnorm512");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Aggre_Index (reference network_util.py:64-73; aggr from MODEL.GCN_AGGR, flow target_to_source
+// => reduce over the edges whose SOURCE is n).  CSR over sources, one block per node, one
+// thread per channel: deterministic, no atomics; empty segment -> 0 (torch_scatter semantics).
+__global__ __launch_bounds__(256) void aggregate_kernel(const float* __restrict__ gated, int n_ch,
+                                                        const int32_t* __restrict__ rowptr,
+                                                        const int32_t* __restrict__ order, int aggr,
+                                                        float* __restrict__ out, int ldo, int col0) {
+    const int n = blockIdx.x, c = threadIdx.x;
+    if (c >= n_ch) return;
+    const int b = rowptr[n], e = rowptr[n + 1];
+    float acc = 0.f;
+    if (e > b) {
+        if (aggr == 0) {
+            acc = -INFINITY;
+            for (int k = b; k < e; ++k) acc = fmaxf(acc, gated[(size_t)order[k] * n_ch + c]);
+        } else {
+            for (int k = b; k < e; ++k) acc += gated[(size_t)order[k] * n_ch + c];
+            if (aggr == 2) acc /= (float)(e - b);
+        }
+    }
+    out[(size_t)n * ldo + col0 + c] = acc;
+}
+int launch_aggregate(const float* gated, int n_ch, const int32_t* rowptr, const int32_t* order, int n_nodes,
+                     int aggr, float* out, int ldo, int col0, hipStream_t s) {
+    if (n_nodes <= 0) return 0;
+    if (n_ch > 256) return fail(-1, "aggregate: n_ch must be <= 256");
+    hipLaunchKernelGGL(aggregate_kernel, dim3(n_nodes), dim3(256), 0, s, gated, n_ch, rowptr, order, aggr, out, ldo,
+                       col0);
+    VLSAT_LAUNCH_CHECK("aggregate");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Distance-bias MLP of MMG.forward (reference network_MMG.py:190-203, self_attn_fc :165-173):
+//   w = [c_b - c_a, ||c_b - c_a||] -> Linear(4,32) ReLU LN -> Linear(32,32) ReLU LN -> Linear(32,H)
+// One thread per (scene, query a, key b); weights are read with wave-uniform indices (scalar loads).
+// Output layout per scene: bias[bias_ptr[s] + (h*n + a)*n + b].
+__device__ __forceinline__ void ln32(float (&t)[32], const float* g, const float* b) {
+    float m = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) m += t[i];
+    m *= (1.f / 32.f);
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) { t[i] -= m; v += t[i] * t[i]; }
+    const float r = rsqrtf(v * (1.f / 32.f) + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) t[i] = t[i] * r * g[i] + b[i];
+}
+__global__ __launch_bounds__(256) void dist_bias_kernel(const float* __restrict__ desc, int ld_desc,
+                                                        const int32_t* __restrict__ scene_ptr,
+                                                        const int64_t* __restrict__ bias_ptr, int n_heads,
+                                                        DistBiasW w, float* __restrict__ bias) {
+    const int s = blockIdx.y;
+    const int n0 = scene_ptr[s], n = scene_ptr[s + 1] - n0;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * n) return;
+    const int a = i / n, b = i % n;
+    const float* ca = desc + (size_t)(n0 + a) * ld_desc;
+    const float* cb = desc + (size_t)(n0 + b) * ld_desc;
+    float x[4];
+    x[0] = cb[0] - ca[0]; x[1] = cb[1] - ca[1]; x[2] = cb[2] - ca[2];
+    x[3] = sqrtf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+    float t[32], u[32];
+#pragma unroll
+    for (int o = 0; o < 32; ++o) {
+        float acc = w.b0[o];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc = fmaf(w.w0[o * 4 + k], x[k], acc);
+        t[o] = fmaxf(acc, 0.f);
+    }
+    ln32(t, w.g2, w.be2);
+#pragma unroll
+    for (int o = 0; o < 32; ++o) {
+        float acc = w.b3[o];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) acc = fmaf(w.w3[o * 32 + k], t[k], acc);
+        u[o] = fmaxf(acc, 0.f);
+    }
+    ln32(u, w.g5, w.be5);
+    float* dst = bias + bias_ptr[s] + (size_t)a * n + b;
+    for (int h = 0; h < n_heads; ++h) {
+        float acc = w.b6[h];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) acc = fmaf(w.w6[h * 32 + k], u[k], acc);
+        dst[(size_t)h * n * n] = acc;
+    }
+}
+int launch_dist_bias(const float* desc, int ld_desc, const int32_t* scene_ptr, const int64_t* bias_ptr,
+                     int n_scenes, int max_n, int n_heads, DistBiasW w, float* bias, hipStream_t s) {
+    if (n_scenes <= 0 || max_n <= 0) return 0;
+    const int gx = (max_n * max_n + 255) / 256;
+    hipLaunchKernelGGL(dist_bias_kernel, dim3(gx, n_scenes), dim3(256), 0, s, desc, ld_desc, scene_ptr, bias_ptr,
+                       n_heads, w, bias);
+    VLSAT_LAUNCH_CHECK("dist_bias");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Node attention: softmax(q.k*scale + bias) v per scene (block-diagonal mask of
+// network_MMG.py:188-193 == per-scene loop) and head; d_k = 64.
+// (reference transformer/attention.py:60-76 as called from network_MMG.py:217-218.)
+// N per scene is small (40 at cfg 2, 200 at cfg 5): one query per lane, keys streamed through
+// LDS in chunks of 64 (wave-uniform broadcast reads), online softmax, fp32 VALU.
+__global__ __launch_bounds__(64) void node_attn_kernel(const float* __restrict__ Q, int ldq,
+                                                       const float* __restrict__ K, int ldk,
+                                                       const float* __restrict__ V, int ldv,
+                                                       float* __restrict__ O, int ldo,
+                                                       const float* __restrict__ bias,
+                                                       const int32_t* __restrict__ scene_ptr,
+                                                       const int64_t* __restrict__ bias_ptr, float scale) {
+    __shared__ __attribute__((aligned(16))) float sK[64 * 64];
+    __shared__ __attribute__((aligned(16))) float sV[64 * 64];
+    const int s = blockIdx.z, h = blockIdx.y, lane = threadIdx.x;
+    const int n0 = scene_ptr[s], n = scene_ptr[s + 1] - n0;
+    const int qa = blockIdx.x * 64 + lane;
+    if (blockIdx.x * 64 >= n) return;
+    const bool valid = qa < n;
+    const int qrow = n0 + (valid ? qa : n - 1);
+    float q[64], acc[64];
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(Q + (size_t)qrow * ldq + h * 64 + 4 * g);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { q[4 * g + c] = x[c] * scale; acc[4 * g + c] = 0.f; }
+    }
+    float m_run = -INFINITY, l_run = 0.f;
+    const float* brow = bias + bias_ptr[s] + ((size_t)h * n + (valid ? qa : n - 1)) * n;
+    for (int k0 = 0; k0 < n; k0 += 64) {
+        const int kn = min(64, n - k0);
+        __syncthreads();
+        for (int i = lane; i < kn * 16; i += 64) {
+            const int r = i >> 4, c4 = (i & 15) * 4;
+            *reinterpret_cast<f32x4*>(sK + r * 64 + c4) =
+                *reinterpret_cast<const f32x4*>(K + (size_t)(n0 + k0 + r) * ldk + h * 64 + c4);
+            *reinterpret_cast<f32x4*>(sV + r * 64 + c4) =
+                *reinterpret_cast<const f32x4*>(V + (size_t)(n0 + k0 + r) * ldv + h * 64 + c4);
+        }
+        __syncthreads();
+        for (int j = 0; j < kn; ++j) {
+            float sc = brow[k0 + j];
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const f32x4 kk = *reinterpret_cast<const f32x4*>(sK + j * 64 + 4 * g);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) sc = fmaf(q[4 * g + c], kk[c], sc);
+            }
+            const float m_new = fmaxf(m_run, sc);
+            const float alpha = __expf(m_run - m_new);
+            const float p = __expf(sc - m_new);
+            l_run = l_run * alpha + p;
+            m_run = m_new;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const f32x4 vv = *reinterpret_cast<const f32x4*>(sV + j * 64 + 4 * g);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[4 * g + c] = fmaf(acc[4 * g + c], alpha, p * vv[c]);
+            }
+        }
+    }
+    if (valid) {
+        const float inv = 1.f / l_run;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            f32x4 o;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[c] = acc[4 * g + c] * inv;
+            *reinterpret_cast<f32x4*>(O + (size_t)qrow * ldo + h * 64 + 4 * g) = o;
+        }
+    }
+}
+int launch_node_attn(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
+                     const float* bias, const int32_t* scene_ptr, const int64_t* bias_ptr, int n_scenes, int max_n,
+                     int n_heads, float scale, hipStream_t s) {
+    if (n_scenes <= 0 || max_n <= 0) return 0;
+    if ((ldq | ldk | ldv | ldo) & 3) return fail(-1, "node_attn: leading dims must be multiples of 4");
+    hipLaunchKernelGGL(node_attn_kernel, dim3((max_n + 63) / 64, n_heads, n_scenes), dim3(64), 0, s, Q, ldq, K, ldk,
+                       V, ldv, O, ldo, bias, scene_ptr, bias_ptr, scale);
+    VLSAT_LAUNCH_CHECK("node_attn");
+    return 0;
+}
+
+}  // namespace vlsat

@@ -1,0 +1,232 @@
+"""Host-side mirror of the reference model object for the eval forward path.
+
+``VLSATModel`` keeps the surface ``MMGNet.validation`` touches on ``Mmgnet`` (reference
+``src/model/model.py:181-211``, ``src/model/SGFN_MMG/model.py:288-335,458-460``):
+``forward`` with the same tensor-in/tensor-out signature, ``eval()``, ``to()``, and weight
+loading by reference ``state_dict`` key.  All arithmetic happens in libvlsat_hip.so; this
+file only validates shapes, caches the per-graph plan and passes raw pointers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import weakref
+from collections import OrderedDict
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import lib as L
+from .config import VLSATConfig, param_shapes
+
+_AGGR = {"max": 0, "add": 1, "mean": 2}
+
+
+class _Plan:
+    def __init__(self, handle, perm):
+        self.handle = handle          # vlsat_plan (c_void_p)
+        self.perm = perm              # device int64 permutation applied to the edges, or None
+
+    def destroy(self):
+        if self.handle:
+            L.load().vlsat_plan_destroy(self.handle)
+            self.handle = None
+
+
+class VLSATModel:
+    """Drop-in for ``Mmgnet`` on the eval forward path (one instance is not re-entrant)."""
+
+    MAX_PLANS = 4
+
+    def __init__(self, config: Optional[VLSATConfig] = None, device: str = "cuda:0"):
+        self.config = config or VLSATConfig()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise L.VlsatError("VLSATModel runs on an MI355X only (device must be cuda:N); there is no CPU path")
+        if not torch.cuda.is_available():
+            raise L.VlsatError("no HIP device visible: libvlsat_hip.so cannot run (there is no CPU fallback)")
+        self._lib = L.load()
+        c = self.config
+        dims = L.VlsatDims(c.N_LAYERS, c.NUM_HEADS, c.DIM_ATTEN, _AGGR[c.GCN_AGGR], c.dim_point,
+                           c.num_obj_class, c.num_rel_class, float(c.obj_logit_scale))
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            L.check(self._lib.vlsat_create(C.byref(dims), C.byref(self._h)))
+        self._loaded = False
+        self._zero_bid = {}
+        self._plans: "OrderedDict[tuple, _Plan]" = OrderedDict()
+        self.training = False
+
+    # ---- nn.Module-like surface --------------------------------------------------------------
+    def eval(self):
+        self.training = False
+        return self
+
+    def to(self, device):
+        if torch.device(device) != self.device:
+            raise L.VlsatError("weights live on the device given at construction; build a new VLSATModel to move")
+        return self
+
+    def __call__(self, *a, **k):
+        return self.forward(*a, **k)
+
+    def close(self):
+        for p in self._plans.values():
+            p.destroy()
+        self._plans.clear()
+        if getattr(self, "_h", None):
+            self._lib.vlsat_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- weights -------------------------------------------------------------------------------
+    def load_state(self, weights: Dict[str, "np.ndarray | torch.Tensor"], strict: bool = True):
+        """``weights``: reference ``state_dict`` keys (``'mmg.gcn_3ds.0.edgeatten.nn_edge.0.weight'``)
+        -> fp32 arrays.  Dead/unused entries of a reference checkpoint are ignored."""
+        want = param_shapes(self.config)
+        missing = [k for k in want if k not in weights]
+        if missing and strict:
+            raise L.VlsatError(f"missing {len(missing)} weights, first: {missing[0]}")
+        with torch.cuda.device(self.device):
+            for k, shape in want.items():
+                if k not in weights:
+                    continue
+                v = weights[k]
+                if torch.is_tensor(v):
+                    v = v.detach().cpu().numpy()
+                v = np.ascontiguousarray(v, dtype=np.float32)
+                if tuple(v.shape) != tuple(shape):
+                    raise L.VlsatError(f"weight {k}: shape {v.shape}, expected {shape}")
+                L.check(self._lib.vlsat_load_weight(self._h, k.encode(), v.ctypes.data, v.size))
+            L.check(self._lib.vlsat_finalize_weights(self._h))
+        self._loaded = True
+        return self
+
+    # ---- graph plan ----------------------------------------------------------------------------
+    def _plan(self, edge_indices, batch_ids, n, p) -> _Plan:
+        """Plan for this graph.  A cached plan is reused only for the SAME tensor objects at the
+        same in-place version (an address match alone is not enough: the caching allocator hands
+        the same address to the next scene's tensors)."""
+        key = (id(edge_indices), id(batch_ids), n, p)
+        hit = self._plans.get(key)
+        if hit is not None:
+            ok = (hit.refs[0]() is edge_indices and hit.refs[1]() is batch_ids
+                  and hit.versions == (edge_indices._version, batch_ids._version))
+            if ok:
+                self._plans.move_to_end(key)
+                return hit
+            self._plans.pop(key).destroy()
+        ei = edge_indices.detach().cpu().contiguous()           # one D2H sync per NEW graph
+        bid = batch_ids.detach().view(-1).cpu().contiguous()
+        e = ei.shape[1]
+        perm = None
+        out = C.c_void_p()
+
+        def create(ei_host):
+            return self._lib.vlsat_plan_create(self._h, bid.data_ptr(), ei_host.data_ptr(), n, e, p, C.byref(out))
+
+        rc = create(ei)
+        if rc == -4:   # VLSAT_EGRAPH: edges not grouped by scene -> stable sort by scene, remember the permutation
+            order = torch.argsort(bid[ei[0]], stable=True)
+            ei = ei[:, order].contiguous()
+            rc = create(ei)
+            perm = order.to(self.device)
+        L.check(rc)
+        plan = _Plan(out, perm)
+        plan.refs = (weakref.ref(edge_indices), weakref.ref(batch_ids))
+        plan.versions = (edge_indices._version, batch_ids._version)
+        self._plans[key] = plan
+        while len(self._plans) > self.MAX_PLANS:
+            _, old = self._plans.popitem(last=False)
+            old.destroy()
+        return plan
+
+    def plan_info(self, edge_indices, batch_ids, n, p):
+        plan = self._plan(edge_indices, batch_ids, n, p)
+        s, ws, fc = C.c_int32(), C.c_size_t(), C.c_int32()
+        L.check(self._lib.vlsat_plan_info(plan.handle, C.byref(s), C.byref(ws), C.byref(fc)))
+        return {"n_scenes": s.value, "workspace_bytes": ws.value, "is_fc": bool(fc.value)}
+
+    # ---- forward -------------------------------------------------------------------------------
+    def _chk(self, t, name, shape, dtype):
+        if not torch.is_tensor(t) or t.device != self.device:
+            raise L.VlsatError(f"{name}: expected a tensor on {self.device}")
+        if t.dtype != dtype:
+            raise L.VlsatError(f"{name}: dtype {t.dtype}, expected {dtype}")
+        for got, want in zip(t.shape, shape):
+            if want is not None and got != want:
+                raise L.VlsatError(f"{name}: shape {tuple(t.shape)}, expected {shape}")
+        if len(t.shape) != len(shape):
+            raise L.VlsatError(f"{name}: rank {t.dim()}, expected {len(shape)}")
+        return t if t.is_contiguous() else t.contiguous()
+
+    @torch.no_grad()
+    def forward(self, obj_points, obj_2d_feats, edge_indices, descriptor=None, batch_ids=None, istrain=False):
+        """Same contract as ``Mmgnet.forward`` (reference SGFN_MMG/model.py:288-335):
+        obj_points f32[N,3,P], obj_2d_feats f32[N,512], edge_indices i64[2,E], descriptor f32[N,11],
+        batch_ids i64[N,1] -> (obj_logits_3d [N,160], obj_logits_2d [N,160], rel_cls_3d [E,26], rel_cls_2d [E,26])."""
+        if istrain:
+            raise NotImplementedError("only the eval forward (istrain=False) is implemented")
+        if not self._loaded:
+            raise L.VlsatError("weights not loaded: call load_state() first")
+        if descriptor is None:
+            raise L.VlsatError("descriptor is required (MODEL.USE_SPATIAL must be true, SURVEY §8a)")
+        c = self.config
+        n = obj_points.shape[0]
+        pts = self._chk(obj_points, "obj_points", (n, c.dim_point, None), torch.float32)
+        f2d = self._chk(obj_2d_feats, "obj_2d_feats", (n, c.clip_feat_dim), torch.float32)
+        desc = self._chk(descriptor, "descriptor", (n, c.dim_descriptor), torch.float32)
+        ei = self._chk(edge_indices, "edge_indices", (2, None), torch.int64)
+        if batch_ids is None:
+            batch_ids = self._zero_bid.get(n)
+            if batch_ids is None:
+                batch_ids = self._zero_bid[n] = torch.zeros(n, 1, dtype=torch.int64, device=self.device)
+        if batch_ids.numel() != n or batch_ids.dtype != torch.int64 or batch_ids.device != self.device:
+            raise L.VlsatError(f"batch_ids: expected int64[{n},1] on {self.device}")
+        p, e = pts.shape[2], ei.shape[1]
+        with torch.cuda.device(self.device):
+            plan = self._plan(edge_indices if ei is edge_indices else ei, batch_ids, n, p)
+            obj3 = torch.empty(n, c.num_obj_class, dtype=torch.float32, device=self.device)
+            obj2 = torch.empty_like(obj3)
+            rel3 = torch.empty(e, c.num_rel_class, dtype=torch.float32, device=self.device)
+            rel2 = torch.empty_like(rel3)
+            L.check(self._lib.vlsat_forward(self._h, plan.handle, pts.data_ptr(), f2d.data_ptr(), desc.data_ptr(),
+                                            obj3.data_ptr(), obj2.data_ptr(), rel3.data_ptr(), rel2.data_ptr(),
+                                            L.stream_ptr()))
+            if plan.perm is not None:     # outputs were computed in scene-grouped edge order
+                r3, r2 = torch.empty_like(rel3), torch.empty_like(rel2)
+                r3[plan.perm] = rel3
+                r2[plan.perm] = rel2
+                rel3, rel2 = r3, r2
+        return obj3, obj2, rel3, rel2
+
+    # ---- profiling / debug hooks -----------------------------------------------------------------
+    def profile_enable(self, on: bool):
+        L.check(self._lib.vlsat_profile_enable(self._h, int(on)))
+
+    def profile_read(self) -> dict:
+        out = {}
+        for i in range(self._lib.vlsat_profile_num_classes()):
+            ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
+            L.check(self._lib.vlsat_profile_read(self._h, i, C.byref(ms), C.byref(n), C.byref(fl)))
+            out[self._lib.vlsat_profile_class_name(i).decode()] = {"ms": ms.value, "launches": n.value,
+                                                                  "flops": fl.value}
+        return out
+
+    def debug_stop_after(self, stage: int):
+        L.check(self._lib.vlsat_debug_stop_after(self._h, stage))
+
+    def debug_buffer(self, edge_indices, batch_ids, n, p, name: str) -> torch.Tensor:
+        """Copy of a named workspace buffer of the plan for this graph (tests only)."""
+        plan = self._plan(edge_indices, batch_ids, n, p)
+        ptr, rows, cols, ld = C.c_void_p(), C.c_int64(), C.c_int32(), C.c_int32()
+        L.check(self._lib.vlsat_debug_buffer(plan.handle, name.encode(), C.byref(ptr), C.byref(rows), C.byref(cols),
+                                             C.byref(ld)))
+        out = torch.empty(rows.value, cols.value, dtype=torch.float32, device=self.device)
+        L.check(self._lib.vlsat_debug_read(plan.handle, name.encode(), out.data_ptr(), cols.value))
+        return out

@@ -1,0 +1,153 @@
+/*
+ * vlsat.h -- C ABI of libvlsat_hip.so: the MI355X (gfx950) implementation of VL-SAT's
+ * per-scene eval forward.
+ *
+ * The reference has NO native/FFI layer (pure Python on PyTorch + PyG); its boundary for this
+ * path is the nn.Module call
+ *     Mmgnet.forward(obj_points, obj_2d_feats, edge_indices, descriptor, batch_ids, istrain=False)
+ *         reference src/model/SGFN_MMG/model.py:288-335, called from process_val :458-460,
+ *         which MMGNet.validation calls at src/model/model.py:203-211.
+ * Every entry point below replaces a piece of that call; the reference line it stands for is
+ * cited on each declaration.  The ctypes binding a reference maintainer would add is shown in
+ * INTEGRATION.md and implemented in cvpr2023-vlsat_amd/lib.py.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; device pointers are raw HIP device addresses
+ *     (torch: tensor.data_ptr()); `stream` is a hipStream_t passed as void*
+ *     (torch: torch.cuda.current_stream().cuda_stream); NULL = the default stream.
+ *   - all tensors fp32 row-major contiguous unless noted; indices int64 like the reference.
+ *   - every function returns 0 on success or a negative VLSAT_E* code; it never throws and
+ *     never calls exit(); vlsat_last_error() returns a thread-local message for the last failure.
+ *   - vlsat_forward and the vlsat_k_* kernels are asynchronous on `stream` and do not synchronise.
+ *   - a handle (weights) may be shared by several plans; a plan owns its workspace and is NOT
+ *     re-entrant (one forward at a time per plan), mirroring one nn.Module instance.
+ */
+#ifndef VLSAT_H
+#define VLSAT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VLSAT_OK            0
+#define VLSAT_EINVAL       (-1)   /* bad argument / shape */
+#define VLSAT_EHIP         (-2)   /* HIP runtime error (message has hipGetErrorString) */
+#define VLSAT_ESTATE       (-3)   /* call order (weights missing / not finalised) */
+#define VLSAT_EGRAPH       (-4)   /* graph layout not supported as given (see vlsat_plan_create) */
+#define VLSAT_ENOMEM       (-5)
+
+typedef struct vlsat_ctx*  vlsat_handle;
+typedef struct vlsat_plan_s* vlsat_plan;
+
+/* Hyper-parameters = the MODEL keys Mmgnet.__init__ reads (reference SGFN_MMG/model.py:26-130,
+ * config/mmgnet.json:26-58). */
+typedef struct {
+    int32_t n_layers;        /* MODEL.N_LAYERS */
+    int32_t n_heads;         /* MODEL.NUM_HEADS (8) */
+    int32_t dim_atten;       /* MODEL.DIM_ATTEN (256) */
+    int32_t gcn_aggr;        /* MODEL.GCN_AGGR: 0 max, 1 add, 2 mean */
+    int32_t dim_point;       /* 3 (USE_RGB / USE_NORMAL unsupported) */
+    int32_t n_obj_class;     /* 160 */
+    int32_t n_rel_class;     /* 26 */
+    float   obj_logit_scale; /* log(1/0.07): never checkpointed by the reference */
+} VlsatDims;
+
+const char* vlsat_last_error(void);
+/* library / build identification, e.g. "vlsat-hip gfx950 fp32-mfma r1" */
+const char* vlsat_version(void);
+
+/* Mmgnet.__init__ (module construction), reference SGFN_MMG/model.py:20-159. */
+int vlsat_create(const VlsatDims* dims, vlsat_handle* out);
+void vlsat_destroy(vlsat_handle h);
+
+/* BaseModel.load / load_state_dict, reference model_utils/model_base.py:75-129: `name` is the
+ * reference state_dict key prefixed by the sub-module name ("mmg.gcn_3ds.0.edgeatten.nn_edge.0.weight");
+ * `host` is fp32, `count` elements.  Unknown names -> VLSAT_EINVAL. */
+int vlsat_load_weight(vlsat_handle h, const char* name, const float* host, size_t count);
+/* Folds BatchNorm(eval), splits/concatenates/permutes the projections the kernels use and
+ * uploads everything to the device.  Fails with VLSAT_ESTATE listing the first missing tensor. */
+int vlsat_finalize_weights(vlsat_handle h);
+
+/* Graph analysis for one batch = what MMG.forward derives from batch_ids each call
+ * (reference network_MMG.py:183-205) plus the PyG gather/scatter index bookkeeping
+ * (network_util.py:50-73).  HOST pointers: batch_ids [N] int64 (scene id per node, scenes
+ * contiguous and ascending), edges [2,E] int64 (row 0 = source, row 1 = target, already offset
+ * like collate_fn_mmg does, reference DataLoader.py:167-172).  Requirements: every edge joins two
+ * nodes of one scene; edges of a scene are contiguous and scenes appear in node order
+ * (otherwise VLSAT_EGRAPH: the Python glue then permutes edges and retries).  Within a scene the
+ * edge order is arbitrary.  Allocates the per-plan device workspace for (N, E, P). */
+int vlsat_plan_create(vlsat_handle h, const int64_t* batch_ids_host, const int64_t* edges_host,
+                      int64_t n_nodes, int64_t n_edges, int32_t n_points, vlsat_plan* out);
+void vlsat_plan_destroy(vlsat_plan p);
+/* n_scenes, workspace bytes, and whether the fully-connected fast paths were selected */
+int vlsat_plan_info(vlsat_plan p, int32_t* n_scenes, size_t* workspace_bytes, int32_t* is_fc);
+
+/* Mmgnet.forward(..., istrain=False), reference SGFN_MMG/model.py:288-335.
+ * Device pointers: obj_points [N,3,P], obj_2d_feats [N,512], descriptor [N,11];
+ * outputs obj_logits_3d/2d [N,n_obj_class] (logits x exp(scale)), rel_cls_3d/2d
+ * [E,n_rel_class] (post-sigmoid).  Edge order of the outputs = edge order given to the plan. */
+int vlsat_forward(vlsat_handle h, vlsat_plan p,
+                  const float* obj_points, const float* obj_2d_feats, const float* descriptor,
+                  float* obj_logits_3d, float* obj_logits_2d, float* rel_cls_3d, float* rel_cls_2d,
+                  void* stream);
+
+/* Per-kernel timing of the forward with HIP events on `stream` (bench.py roofline leg).
+ * enable=1: every launch of every kernel class is bracketed by hipEventRecord on the launch
+ * stream; vlsat_profile_read synchronises, accumulates and returns per-class totals since
+ * the last read.  Classes are enumerated by vlsat_profile_class_name(i), i in [0, n). */
+int vlsat_profile_enable(vlsat_handle h, int32_t enable);
+int vlsat_profile_num_classes(void);
+const char* vlsat_profile_class_name(int32_t cls);
+int vlsat_profile_read(vlsat_handle h, int32_t cls, double* total_ms, int64_t* launches, double* flops);
+
+/* -------- single-kernel entry points (unit/parity tests; all device pointers) ---------------- */
+
+/* C[M,N] = act(rowscale[m] * (reluA?(A)[M,K] . W[N,K]^T) + bias[n] + resid_scale*resid[m,n]
+ *              + g0[gi0[m], n] + g1[gi1[m], n]);   act: 0 none, 1 relu, 2 sigmoid.
+ * Replaces every nn.Linear / Conv1d(k=1) call site of the path (SURVEY §2 "addmm" row).
+ * K % 32 == 0; lda/ldw % 4 == 0; any pointer except A, W, C may be NULL. */
+int vlsat_k_gemm(const float* A, int32_t lda, const float* W, int32_t ldw, float* C, int32_t ldc,
+                 int32_t M, int32_t N, int32_t K,
+                 const float* bias, const float* rowscale,
+                 const float* resid, int32_t ldr, float resid_scale,
+                 const float* g0, const int32_t* gi0, int32_t ldg0,
+                 const float* g1, const int32_t* gi1, int32_t ldg1,
+                 int32_t relu_a, int32_t act, void* stream);
+
+/* PointNetfeat.forward (obj_encoder), reference network_PointNet.py:141-164:
+ * pts [N,3,P] -> out [N,768] = max_p relu(W3 relu(W2 relu(W1 x + b1) + b2) + b3).
+ * Weights in the reference layout (W1 [64,3], W2 [128,64], W3 [768,128]). */
+int vlsat_k_pointnet(const float* pts, int32_t n_obj, int32_t n_points,
+                     const float* w1, const float* b1, const float* w2, const float* b2,
+                     const float* w3, const float* b3, int32_t n_out, float* out, void* stream);
+
+/* ScaledDotProductAttention core for the edge cross-attention (reference attention.py:60-76 as
+ * called from network_MMG.py:231): per scene s and head h, O = softmax(Q K^T * scale) V with
+ * Q,K,V,O [T,512] (head h = columns 64h..64h+63), tokens of scene s = rows tok_ptr[s]..tok_ptr[s+1].
+ * tok_ptr is a HOST array of n_scenes+1 int64.  Never materialises the T x T scores. */
+int vlsat_k_flash_attn(const float* Q, const float* K, const float* V, float* O,
+                       int32_t ld, const int64_t* tok_ptr_host, int32_t n_scenes, int32_t n_heads,
+                       float scale, void* stream);
+
+/* LayerNorm over rows of 512 in place, optional ReLU (reference attention.py:122 + MMG :236-248). */
+int vlsat_k_layernorm(float* x, int32_t ld, int32_t rows, int32_t dim, const float* gamma,
+                      const float* beta, int32_t relu, void* stream);
+
+/* -------- debug / test hooks (used by tests/ to localise a parity failure) -------------------- */
+/* Stop vlsat_forward after stage `stage` (-1 = run everything).  Stages: 1 object encoder,
+ * 2 node embedding, 3 edge embedding, 4 adapter, 5 distance bias, then for layer l:
+ * 10+10l self-attention, +1 cross-attention, +2 gcn_3ds, +3 gcn_2ds, +4 edge cross-attention. */
+int vlsat_debug_stop_after(vlsat_handle h, int32_t stage);
+/* Device pointer and shape of a named workspace buffer of a plan ("X3","X2","E3","E2","F","G",
+ * "AGG3","AGG2","H1","KP","NP","Hbig","bias","On","Oe","Qe","KVe"). */
+int vlsat_debug_buffer(vlsat_plan p, const char* name, void** ptr, int64_t* rows, int32_t* cols, int32_t* ld);
+/* Synchronous strided device-to-device copy of that buffer into dst (row pitch dst_ld floats). */
+int vlsat_debug_read(vlsat_plan p, const char* name, float* dst, int64_t dst_ld);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VLSAT_H */

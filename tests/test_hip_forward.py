@@ -1,0 +1,232 @@
+"""Full-forward parity of the HIP path (through VLSATModel -> C ABI) against the CPU oracle and the
+golden vectors made from the real reference.  Tolerance from BASELINE.json north_star: 1e-3 fp32
+on the four outputs (two are logits scaled by 14.29, two are probabilities).  Needs an MI355X."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import vlsat_amd  # noqa: F401
+from vlsat_amd import VLSATConfig, synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 1e-3          # the contract
+TIGHT = 1e-4        # what an fp32 implementation should actually reach; catches subtle indexing bugs
+NAMES = ("obj3d", "obj2d", "rel3d", "rel2d")
+
+
+def _dev(b):
+    return {k: torch.from_numpy(v).to(DEV) for k, v in b.items()}
+
+
+def _cpu(b):
+    return {k: torch.from_numpy(v) for k, v in b.items()}
+
+
+_MODELS = {}
+
+
+def model_for(cfg):
+    from vlsat_amd.model import VLSATModel
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: the HIP path cannot run and there is no fallback")
+    key = (cfg.N_LAYERS, cfg.GCN_AGGR)
+    if key not in _MODELS:
+        _MODELS[key] = VLSATModel(cfg, DEV).load_state(synth.make_weights(cfg)).eval()
+    return _MODELS[key]
+
+
+def run_hip(cfg, b):
+    d = _dev(b)
+    m = model_for(cfg)
+    out = m(d["obj_points"], d["obj_2d_feats"], d["edge_indices"], d["descriptor"], d["batch_ids"])
+    torch.cuda.synchronize()
+    return [o.cpu() for o in out]
+
+
+def run_oracle(cfg, b, taps=None, dtype=torch.float32):
+    from oracle import vlsat_oracle as O
+    w = O.to_torch(synth.make_weights(cfg), dtype)
+    c = _cpu(b)
+    return O.forward(w, cfg, c["obj_points"].to(dtype), c["obj_2d_feats"].to(dtype), c["edge_indices"],
+                     c["descriptor"].to(dtype), c["batch_ids"], taps=taps)
+
+
+def _check(got, ref, tol, what):
+    errs = {}
+    for n, g, r in zip(NAMES, got, ref):
+        r = torch.as_tensor(r)
+        assert g.shape == r.shape, (what, n, g.shape, r.shape)
+        assert torch.isfinite(g).all(), f"{what} {n}: non-finite output"
+        errs[n] = float((g - r.float()).abs().max())
+    print(what, {k: f"{v:.2e}" for k, v in errs.items()})
+    bad = {k: v for k, v in errs.items() if v > tol}
+    assert not bad, f"{what}: max-abs-err over {tol}: {bad}"
+    return errs
+
+
+# ------------------------------------------------------------------------------------------------
+def test_staged_taps_cfg1():
+    """Stop the forward after each stage and compare the workspace with the oracle's taps:
+    localises a failure to one kernel in a single GPU run."""
+    cfg = VLSATConfig(N_LAYERS=2)
+    b = synth.make_batch(1, 8, 256, seed0=1000)
+    taps = {}
+    run_oracle(cfg, b, taps)
+    d = _dev(b)
+    m = model_for(cfg)
+    n, p = 8, 256
+
+    def stage(stage_id, buf):
+        m.debug_stop_after(stage_id)
+        try:
+            m(d["obj_points"], d["obj_2d_feats"], d["edge_indices"], d["descriptor"], d["batch_ids"])
+            return m.debug_buffer(d["edge_indices"], d["batch_ids"], n, p, buf).cpu()
+        finally:
+            m.debug_stop_after(-1)
+
+    def close(got, ref, name, tol=TIGHT):
+        err = float((got - ref).abs().max())
+        print(f"stage {name}: {err:.2e}")
+        assert err < tol, f"stage {name}: max-abs-err {err:.3e}"
+
+    close(stage(1, "F"), taps["obj_encoder"], "pointnet")
+    close(stage(2, "X3"), taps["node_embed"], "node_embed")
+    close(stage(3, "E3"), taps["rel_encoder_3d"], "rel_encoder_3d")
+    close(stage(3, "E2"), taps["rel_encoder_2d"], "rel_encoder_2d")
+    close(stage(4, "X2"), taps["clip_adapter"], "adapter")
+    close(stage(10, "X3"), taps["self_attn0"], "self_attn0")
+    close(stage(11, "X2"), taps["cross_attn0"], "cross_attn0")
+    close(stage(12, "G"), taps["gcn3d0.gated"], "gate3d (head layout)")
+    close(stage(12, "AGG3"), taps["gcn3d0.agg"], "aggregate3d")
+    close(stage(12, "E3"), taps["gcn3d0.edge"], "gcn3d edge")
+    close(stage(12, "X3"), torch.relu(taps["gcn3d0.node"]), "gcn3d node (+inter-layer relu)")
+    close(stage(13, "E2"), taps["gcn2d0.edge"], "gcn2d edge")
+    close(stage(13, "X2"), torch.relu(taps["gcn2d0.node"]), "gcn2d node (+inter-layer relu)")
+    close(stage(14, "E2"), torch.relu(taps["cross_attn_rel0"]), "edge cross-attention (+relu)")
+
+
+def test_cfg1_golden_and_oracle(golden_dir):
+    cfg = VLSATConfig(N_LAYERS=2)
+    b = synth.make_batch(1, 8, 256, seed0=1000)
+    got = run_hip(cfg, b)
+    z = np.load(os.path.join(golden_dir, "cfg1_n8_p256_l2.npz"))
+    _check(got, [z[n] for n in NAMES], TIGHT, "cfg1 vs reference golden")
+    _check(got, run_oracle(cfg, b, dtype=torch.float64), TIGHT, "cfg1 vs fp64 oracle")
+
+
+def test_cfg2_scene_golden(golden_dir):
+    cfg = VLSATConfig(N_LAYERS=3)
+    b = synth.make_batch(1, 40, 256, seed0=1000)
+    got = run_hip(cfg, b)
+    z = np.load(os.path.join(golden_dir, "cfg2_n40_p256_l3.npz"))
+    _check(got, [z[n] for n in NAMES], TOL, "cfg2 scene vs reference golden")
+    _check(got, [z[n] for n in NAMES], 3e-4, "cfg2 scene vs reference golden (tight)")
+
+
+def test_ragged_batch_golden(golden_dir):
+    cfg = VLSATConfig(N_LAYERS=2)
+    b = synth.collate([synth.make_scene(5, 64, 2000), synth.make_scene(7, 64, 2001)])
+    got = run_hip(cfg, b)
+    z = np.load(os.path.join(golden_dir, "ragged_n5_n7_p64_l2.npz"))
+    _check(got, [z[n] for n in NAMES], TIGHT, "ragged 2-scene batch vs per-scene reference")
+
+
+@pytest.mark.parametrize("aggr", ["max", "add", "mean"])
+def test_general_edges_golden(golden_dir, aggr):
+    """Non fully-connected, unsorted edge list with an empty source segment; L=1 (ReLU applies)."""
+    cfg = VLSATConfig(N_LAYERS=1, GCN_AGGR=aggr)
+    z = np.load(os.path.join(golden_dir, "general_edges_n6_p32_l1.npz"))
+    sc = synth.make_scene(6, 32, 3000)
+    sc["edge_indices"] = z["edge_indices"]
+    got = run_hip(cfg, synth.collate([sc]))
+    _check(got, [z[f"{aggr}.{n}"] for n in NAMES], TIGHT, f"general edges / {aggr}")
+
+
+def test_edges_interleaved_across_scenes():
+    """Edges not grouped by scene: the glue permutes them (VLSAT_EGRAPH path) and un-permutes
+    the relation outputs."""
+    cfg = VLSATConfig(N_LAYERS=2)
+    b = synth.collate([synth.make_scene(6, 32, 4000), synth.make_scene(4, 32, 4001), synth.make_scene(9, 32, 4002)])
+    perm = np.random.default_rng(0).permutation(b["edge_indices"].shape[1])
+    b2 = dict(b)
+    b2["edge_indices"] = np.ascontiguousarray(b["edge_indices"][:, perm])
+    ref = run_oracle(cfg, b2)
+    got = run_hip(cfg, b2)
+    _check(got, ref, TIGHT, "interleaved edges")
+    base = run_hip(cfg, b)
+    assert float((got[2] - base[2][perm]).abs().max()) < 1e-5
+
+
+def test_single_object_scene_and_no_edges():
+    cfg = VLSATConfig(N_LAYERS=2)
+    b = synth.collate([synth.make_scene(1, 32, 4100), synth.make_scene(3, 32, 4101)])
+    got = run_hip(cfg, b)
+    _check(got, run_oracle(cfg, b), TIGHT, "scene with one object (no edges)")
+
+
+def test_batch_independence_full_size():
+    """cfg 2 at full batch size (64 scenes x 40 objects x 256 points, L=3): every scene's outputs
+    must equal that scene run alone (block-diagonal attention), and scene 0 must match
+    the reference golden."""
+    cfg = VLSATConfig(N_LAYERS=3)
+    S, N, P = 64, 40, 256
+    b = synth.make_batch(S, N, P, seed0=1000)
+    got = run_hip(cfg, b)
+    E = N * (N - 1)
+    for s in (0, 17, 63):
+        one = run_hip(cfg, synth.make_batch(1, N, P, seed0=1000 + s))
+        for name, g, o, rows in zip(NAMES, got, one, (N, N, E, E)):
+            err = float((g[s * rows:(s + 1) * rows] - o).abs().max())
+            assert err < 2e-5, f"scene {s} {name}: batched vs alone {err:.3e}"
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "cfg2_n40_p256_l3.npz"))
+    _check([got[0][:N], got[1][:N], got[2][:E], got[3][:E]], [z[n] for n in NAMES], TOL, "batch-64 scene 0 vs golden")
+    # cheap whole-batch properties: finite, probabilities in [0,1]
+    for g in got:
+        assert torch.isfinite(g).all()
+    assert float(got[2].min()) >= 0 and float(got[2].max()) <= 1
+
+
+def test_plan_cache_not_fooled_by_address_reuse():
+    """Two different graphs with identical shapes: a plan must never be reused across them."""
+    cfg = VLSATConfig(N_LAYERS=2)
+    m = model_for(cfg)
+    outs = []
+    for seed in (6000, 6001):
+        sc = synth.make_scene(6, 32, seed)
+        g = np.random.default_rng(seed)
+        keep = g.permutation(sc["edge_indices"].shape[1])[:20]
+        sc["edge_indices"] = np.ascontiguousarray(sc["edge_indices"][:, keep])
+        b = synth.collate([sc])
+        got = run_hip(cfg, b)
+        _check(got, run_oracle(cfg, b), TIGHT, f"graph seed {seed}")
+        outs.append(got)
+        del got
+        torch.cuda.empty_cache()
+
+
+def test_errors_are_loud():
+    from vlsat_amd import lib as L
+    from vlsat_amd.model import VLSATModel
+    cfg = VLSATConfig(N_LAYERS=2)
+    m = model_for(cfg)
+    d = _dev(synth.make_batch(1, 4, 32, seed0=1))
+    with pytest.raises(NotImplementedError):
+        m(d["obj_points"], d["obj_2d_feats"], d["edge_indices"], d["descriptor"], d["batch_ids"], istrain=True)
+    with pytest.raises(L.VlsatError):
+        m(d["obj_points"].cpu(), d["obj_2d_feats"], d["edge_indices"], d["descriptor"], d["batch_ids"])
+    with pytest.raises(L.VlsatError):
+        m(d["obj_points"], d["obj_2d_feats"], d["edge_indices"], None, d["batch_ids"])
+    bad = d["edge_indices"].clone()
+    bad[1, 0] = 99
+    with pytest.raises(L.VlsatError):
+        m(d["obj_points"], d["obj_2d_feats"], bad, d["descriptor"], d["batch_ids"])
+    fresh = VLSATModel(cfg, DEV)
+    with pytest.raises(L.VlsatError):
+        fresh(d["obj_points"], d["obj_2d_feats"], d["edge_indices"], d["descriptor"], d["batch_ids"])
+    w = synth.make_weights(cfg)
+    w.pop("mmg.gcn_2ds.1.prop.2.bias")
+    with pytest.raises(L.VlsatError):
+        fresh.load_state(w)
