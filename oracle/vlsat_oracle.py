@@ -146,15 +146,17 @@ def edge_atten(x: Tensor, e: Tensor, ei: Tensor, w: W, prefix: str, n_heads: int
     p = prefix + ".edgeatten."
     e_new = lin(torch.relu(lin(torch.cat([xi, e, xj], 1), w, p + "nn_edge.0")), w, p + "nn_edge.2")
     v = lin(xj, w, p + "proj_value.0")
-    q = lin(xi, w, p + "proj_query.0").view(E, -1, n_heads)
-    k = lin(e, w, p + "proj_edge.0").view(E, -1, n_heads)
+    q = lin(xi, w, p + "proj_query.0")
+    k = lin(e, w, p + "proj_edge.0")
+    q = q.view(E, q.shape[1] // n_heads, n_heads)       # explicit dims: E may be 0 (single-object scene)
+    k = k.view(E, k.shape[1] // n_heads, n_heads)
     z = torch.cat([q, k], 1)                                             # [E, dn+de, H]
     w0, b0 = w[p + "nn.0.weight"][:, :, 0], w[p + "nn.0.bias"]
     w3, b3 = w[p + "nn.3.weight"][:, :, 0], w[p + "nn.3.bias"]
     z = torch.relu(torch.einsum("oc,ech->eoh", w0, z) + b0[None, :, None])
     z = torch.einsum("oc,ech->eoh", w3, z) + b3[None, :, None]
     prob = z.softmax(1)
-    gated = prob.reshape(E, -1) * v
+    gated = prob.reshape(E, v.shape[1]) * v
     return gated, e_new, prob
 
 
