@@ -118,6 +118,8 @@ def mha(q_in: Tensor, kv_in: Tensor, w: W, prefix: str, n_heads: int,
     Queries are processed in chunks so the E x E score matrix of the edge cross-attention
     (network_MMG.py:231) is never materialised whole (cfg 5)."""
     nq, nk = q_in.shape[0], kv_in.shape[0]
+    if nq == 0:                      # scene without edges: nothing to attend (reference returns empty too)
+        return q_in
     p = prefix + ".attention."
     dk = q_in.shape[1] // n_heads
     q = lin(q_in, w, p + "fc_q").view(nq, n_heads, dk).permute(1, 0, 2)

@@ -1,0 +1,149 @@
+"""CPU-only tests of the host side: synthetic generators, weight inventory, the C-ABI library
+(loads, exports every declared symbol, argument validation that needs no GPU) and the
+world_size-2 scene sharding over gloo."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import vlsat_amd  # noqa: F401
+from vlsat_amd import VLSATConfig, param_shapes, synth
+from vlsat_amd import dist as vdist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def L():
+    from vlsat_amd import build as B, lib
+    B.build()                      # hipcc cross-compiles gfx950 without a GPU
+    return lib
+
+
+def test_param_inventory_counts():
+    assert sum(int(np.prod(s)) for s in param_shapes(VLSATConfig(N_LAYERS=3)).values()) == 33_904_084
+    two = param_shapes(VLSATConfig(N_LAYERS=2))
+    assert two["mmg.gcn_3ds.1.edgeatten.nn_edge.0.weight"] == (1024, 1536)
+    assert two["mmg.gcn_2ds.0.edgeatten.nn.3.weight"] == (32, 128, 1)
+    assert "mmg.self_attn.2.attention.fc_q.weight" not in two
+
+
+def test_synth_is_deterministic_and_well_formed():
+    a, b = synth.make_weights(VLSATConfig()), synth.make_weights(VLSATConfig())
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    s1, s2 = synth.make_scene(7, 33, 5), synth.make_scene(7, 33, 5)
+    assert all(np.array_equal(s1[k], s2[k]) for k in s1)
+    assert s1["obj_points"].shape == (7, 3, 33) and s1["edge_indices"].shape == (2, 42)
+    assert np.abs(s1["obj_points"].mean(-1)).max() < 1e-5           # zero-meaned per object
+    assert (s1["descriptor"][:, 6:] > 0).all()                       # logs are finite
+    assert (s1["edge_indices"][0] != s1["edge_indices"][1]).all()
+    assert (np.diff(s1["edge_indices"][0]) >= 0).all()               # source-major
+    assert np.allclose(np.linalg.norm(s1["obj_2d_feats"], axis=-1), 1, atol=1e-5)
+    bt = synth.collate([synth.make_scene(3, 8, 1), synth.make_scene(4, 8, 2)])
+    assert bt["batch_ids"].ravel().tolist() == [0, 0, 0, 1, 1, 1, 1]
+    assert bt["edge_indices"][:, 6:].min() == 3 and bt["edge_indices"].shape[1] == 6 + 12
+
+
+def test_library_exports_every_declared_symbol(L):
+    lib = L.load()
+    names = L.declared_symbols()
+    assert len(names) >= 20 and "vlsat_forward" in names and "vlsat_k_gemm" in names
+    for n in names:
+        assert hasattr(lib, n), f"libvlsat_hip.so does not export {n}"
+    assert set(L._SIGNATURES) == set(names), "lib.py binding table and include/vlsat.h disagree"
+    assert b"gfx950" in lib.vlsat_version()
+
+
+def test_c_abi_argument_validation_without_gpu(L):
+    lib = L.load()
+    h = C.c_void_p()
+    good = L.VlsatDims(2, 8, 256, 0, 3, 160, 26, 2.6593)
+    for bad in (L.VlsatDims(0, 8, 256, 0, 3, 160, 26, 2.65), L.VlsatDims(2, 4, 256, 0, 3, 160, 26, 2.65),
+                L.VlsatDims(2, 8, 256, 3, 3, 160, 26, 2.65), L.VlsatDims(2, 8, 256, 0, 6, 160, 26, 2.65)):
+        assert lib.vlsat_create(C.byref(bad), C.byref(h)) == -1
+        assert len(lib.vlsat_last_error()) > 0
+    assert lib.vlsat_create(C.byref(good), C.byref(h)) == 0
+    x = np.zeros(4, np.float32)
+    assert lib.vlsat_load_weight(h, b"not.a.weight", x.ctypes.data, 4) == -1
+    assert b"unknown weight" in lib.vlsat_last_error()
+    assert lib.vlsat_load_weight(h, b"mmg.self_attn_fc.0.bias", x.ctypes.data, 4) == 0
+    out = C.c_void_p()
+    bid = np.zeros(3, np.int64)
+    assert lib.vlsat_plan_create(h, bid.ctypes.data, None, 3, 0, 16, C.byref(out)) == -3    # weights not finalised
+    with pytest.raises(L.VlsatError) as ei:
+        L.check(lib.vlsat_forward(h, None, None, None, None, None, None, None, None, None))
+    assert ei.value.code == -1
+    lib.vlsat_destroy(h)
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "cvpr2023-vlsat_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "vlsat_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, f
+
+
+def test_model_refuses_to_run_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from vlsat_amd import lib as L
+    from vlsat_amd.model import VLSATModel
+    with pytest.raises(L.VlsatError):
+        VLSATModel(VLSATConfig(), "cuda:0")
+    with pytest.raises(L.VlsatError):
+        VLSATModel(VLSATConfig(), "cpu")
+
+
+def test_shard_is_a_balanced_partition():
+    for n, w in ((512, 8), (64, 3), (5, 8), (0, 2)):
+        parts = [vdist.shard(n, r, w) for r in range(w)]
+        assert sorted(i for p in parts for i in p) == list(range(n))
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+_WORKER = r"""
+import os, sys, torch
+sys.path.insert(0, os.environ["VLSAT_ROOT"])
+import vlsat_amd
+from vlsat_amd import VLSATConfig, synth, dist as vdist
+from oracle import vlsat_oracle as O       # tests may use the oracle as the per-rank 'forward'
+rank, local, world = vdist.init("gloo")
+cfg = VLSATConfig(N_LAYERS=1)
+w = O.to_torch(synth.make_weights(cfg))
+mine = vdist.shard(5, rank, world)
+b = {k: torch.from_numpy(v) for k, v in synth.collate([synth.make_scene(4, 16, 900 + s) for s in mine]).items()}
+out = O.forward(w, cfg, b["obj_points"], b["obj_2d_feats"], b["edge_indices"], b["descriptor"], b["batch_ids"])
+m = vdist.allreduce_metrics(vdist.scene_metrics(out, len(mine)))
+t = vdist.max_over_ranks(float(rank + 1), torch.device("cpu"))
+vdist.barrier()
+if rank == 0:
+    print("METRICS", " ".join(repr(float(x)) for x in m.tolist()), "MAXT", t)
+"""
+
+
+def test_two_rank_gloo_scene_sharding_matches_single_process(tmp_path):
+    """world_size 2 over gloo: the all-reduced metrics vector equals the single-process one."""
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, VLSAT_ROOT=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", "29631", str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("METRICS")][0].split()
+    got = np.array([float(x) for x in line[1:line.index("MAXT")]])
+    assert float(line[-1]) == 2.0
+    from oracle import vlsat_oracle as O
+    cfg = VLSATConfig(N_LAYERS=1)
+    w = O.to_torch(synth.make_weights(cfg))
+    b = {k: torch.from_numpy(v) for k, v in synth.collate([synth.make_scene(4, 16, 900 + s) for s in range(5)]).items()}
+    out = O.forward(w, cfg, b["obj_points"], b["obj_2d_feats"], b["edge_indices"], b["descriptor"], b["batch_ids"])
+    ref = vdist.scene_metrics(out, 5).numpy()
+    assert got[0] == 5 and got[1] == 20 and got[2] == 60
+    assert np.allclose(got, ref, rtol=1e-9, atol=1e-6), (got, ref)
