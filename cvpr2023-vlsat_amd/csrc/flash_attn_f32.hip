@@ -43,6 +43,10 @@ __global__ __launch_bounds__(256, 2) void flash_attn_f32_kernel(
     const size_t col0 = (size_t)head * FA_D;
 
     // ---- this lane's query row: d = 32*hi + s, s = 0..31 (pre-scaled) ----
+    // A wave whose 32 query rows are all past the scene's token count still helps staging K/V
+    // but issues no MFMA (the last 128-row block of a scene is usually mostly empty:
+    // 1560 = 12*128 + 24), leaving the matrix pipe to the other resident blocks.
+    const bool wave_active = q0 + wave * 32 < n_tok;
     int qrow = q0 + wave * 32 + li;
     if (qrow >= n_tok) qrow = n_tok - 1;      // clamped rows are computed but never stored
     float q[32];
@@ -93,6 +97,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_f32_kernel(
         const bool more = kt + 1 < n_kv_tiles;
         if (more) load_tile((kt + 1) * FA_KV);
 
+        if (wave_active) {
         // ---- S^T[key][query] = sum_d K[key][d] * Q[query][d] ----
         f32x16 s;
 #pragma unroll
@@ -136,6 +141,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_f32_kernel(
             o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[0], s[r], o0, 0, 0, 0);
             o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[32], s[r], o1, 0, 0, 0);
         }
+        }   // wave_active
         if (more) store_tile(smem + ((kt + 1) & 1) * BUF);
         __syncthreads();
     }

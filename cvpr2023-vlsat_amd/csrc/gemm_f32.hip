@@ -8,34 +8,52 @@
 // made of 32x32 MFMA tiles; K streamed in BK=32 slices through double-buffered LDS with
 // register staging (global loads of slice t+1 are issued before the MFMAs of slice t and
 // written to the other buffer afterwards; one barrier per slice).
-// Roofline: fp32 MFMA (157 TF chip peak).  Per 128x128x32 slice a block moves 32 KB from
-// L2 for 1.05 MFLOP, ~19 GB/s/CU at peak rate, far inside L2 bandwidth, so the kernel is
-// MFMA-issue bound; LDS traffic is 4 ds_read_b128 per 16 MFMAs.
-// Grid is 1-D with an XCD-aware remap: all N-tiles of an M-panel run back-to-back on ONE XCD,
-// so the A panel is fetched from HBM once and re-used out of that XCD's L2.
+//
+// PERSISTENT + pipelined across tiles: the grid is (at most) 2 blocks per CU and every block
+// walks a list of output tiles.  The slice pipeline does not drain at a tile boundary: the
+// first slice of the NEXT tile is prefetched under the last slice of the current one, the
+// additive epilogue operands (residual / gathered rows) are loaded straight into the
+// accumulators at the start of a tile, and the stores of a finished tile retire under the next
+// tile's MFMAs.  With
+// K = 512 (16 slices per tile) the per-tile load/store bubble was ~20 % of the tile time
+// in the one-tile-per-block version (blocks co-resident on a CU run in lock-step, so their
+// bubbles coincide instead of hiding each other).
+//
+// Tile order is XCD-aware: in round r the 64 blocks resident on XCD x (block id % 8 == x) own
+// 64 CONSECUTIVE tiles (N fastest), i.e. whole M-panels, so an A panel is fetched from HBM
+// once and re-read from that XCD's L2 by its N-tile neighbours.
+//
+// Tail: a launch covers only full rounds of the grid; the launcher hands the remaining
+// M-panels to a second launch with a smaller tile so the last, mostly idle round of big tiles
+// (up to 1 of 6 rounds at cfg 2) becomes a quarter-length round.
+//
+// Roofline: fp32 MFMA (157.3 TF).  Per 128x128x32 slice a block moves 32 KB from L2 for
+// 1.05 MFLOP (~19 GB/s/CU at peak rate): MFMA-issue bound, LDS is 4 ds_read_b128 per 16 MFMAs.
 #include "gemm_core.h"
 #include "kernels.h"
 
 namespace vlsat {
 
 template <int BM, int BN>
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int n_tiles, int nbn) {
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int STAGE = (BM + BN) * LDT;
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int nbn = (p.N + BN - 1) / BN;
-    const int nbm = (p.M + BM - 1) / BM;
-    const int v = xcd_remap(blockIdx.x, nbm * nbn);
-    const int m0 = (v / nbn) * BM, n0 = (v % nbn) * BN;
+    const int g8 = gridDim.x >> 3, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int KT = p.K / BK;
+    const bool has_add = p.resid || p.g0 || p.g1;
+
+    int round = 0;
+    int v = xcd * g8 + slot;                 // tile of round r: (r*8 + xcd)*g8 + slot
+    if (v >= n_tiles) return;
+    int m0 = (v / nbn) * BM, n0 = (v % nbn) * BN;
 
     f32x16 acc[TM][TN];
     zero_acc<TM, TN>(acc);
-
     f32x4 ra[BM / 32], rb[BN / 32];
-    const int KT = p.K / BK;
 
     stage_load<BM>(p.A, p.lda, m0, p.M - 1, 0, ra, tid);
     stage_load<BN>(p.W, p.ldw, n0, p.N - 1, 0, rb, tid);
@@ -44,58 +62,149 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
     stage_store<BN>(smem + BM * LDT, rb, tid);
     __syncthreads();
 
-    for (int kt = 0; kt < KT; ++kt) {
-        float* cur = smem + (kt & 1) * STAGE;
-        float* nxt = smem + ((kt + 1) & 1) * STAGE;
-        const bool more = kt + 1 < KT;
-        if (more) {
-            stage_load<BM>(p.A, p.lda, m0, p.M - 1, (kt + 1) * BK, ra, tid);
-            stage_load<BN>(p.W, p.ldw, n0, p.N - 1, (kt + 1) * BK, rb, tid);
-        }
-        mma_slice<TM, TN>(cur + (wm * TM * 32) * LDT, cur + BM * LDT + (wn * TN * 32) * LDT, acc, lane);
-        if (more) {
-            if (p.relu_a) stage_relu<BM>(ra);
-            stage_store<BM>(nxt, ra, tid);
-            stage_store<BN>(nxt + BM * LDT, rb, tid);
-        }
-        __syncthreads();
-    }
-
-    // ---- epilogue: lane holds column n, 16 rows per 32x32 tile ----
-    const int li = lane & 31, hi = lane >> 5;
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-        const int n = n0 + (wn * TN + tn) * 32 + li;
-        if (n >= p.N) continue;
-        const float bn = p.bias ? p.bias[n] : 0.f;
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + (wm * TM + tm) * 32 + crow32(r, hi);
-                if (m >= p.M) continue;
-                float x = acc[tm][tn][r];
-                if (p.rowscale) x *= p.rowscale[m];
-                x += bn;
-                if (p.resid) x += p.resid_scale * p.resid[(size_t)m * p.ldr + n];
-                if (p.g0) x += p.g0[(size_t)p.gi0[m] * p.ldg0 + n];
-                if (p.g1) x += p.g1[(size_t)p.gi1[m] * p.ldg1 + n];
-                if (p.act == ACT_RELU) x = fmaxf(x, 0.f);
-                else if (p.act == ACT_SIGMOID) x = 1.f / (1.f + __expf(-x));
-                p.C[(size_t)m * p.ldc + n] = x;
+    int buf = 0;
+    while (true) {
+        const int nv = ((round + 1) * 8 + xcd) * g8 + slot;
+        const bool next_tile = nv < n_tiles;
+        const int nm0 = (nv / nbn) * BM, nn0 = (nv % nbn) * BN;
+        for (int kt = 0; kt < KT; ++kt) {
+            float* cur = smem + buf * STAGE;
+            float* nxt = smem + (buf ^ 1) * STAGE;
+            const bool last = kt == KT - 1;
+            const bool more = !last || next_tile;
+            if (more) {
+                const int lm0 = last ? nm0 : m0, ln0 = last ? nn0 : n0, lk = last ? 0 : (kt + 1) * BK;
+                stage_load<BM>(p.A, p.lda, lm0, p.M - 1, lk, ra, tid);
+                stage_load<BN>(p.W, p.ldw, ln0, p.N - 1, lk, rb, tid);
             }
+            if (kt == 0 && has_add) {
+                // additive epilogue operands (residual / gathered rows) are loaded straight into
+                // the accumulators at the start of a tile (C-in of the first MFMA): no extra
+                // registers, and the wait overlaps the co-resident block's MFMAs.
+                // 32-bit offsets from wave-uniform bases keep the address math in SGPR+VGPR form.
+                // (the asm makes the lane id and pitches opaque per tile: otherwise LICM hoists all
+                //  the per-lane offsets/predicates out of the persistent loop and the kernel spills)
+                int ldr = p.ldr, ldg0 = p.ldg0, ldg1 = p.ldg1, lv = lane;
+                asm volatile("" : "+s"(ldr), "+s"(ldg0), "+s"(ldg1), "+v"(lv));
+                const int li = lv & 31, hi = lv >> 5;
+                const float* rbase = p.resid ? p.resid + (size_t)m0 * ldr + n0 : nullptr;
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    int nl = (wn * TN + tn) * 32 + li;                    // column inside the tile
+                    if (n0 + nl >= p.N) nl = p.N - 1 - n0;
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            int ml = (wm * TM + tm) * 32 + crow32(r, hi);   // row inside the tile
+                            if (m0 + ml >= p.M) ml = p.M - 1 - m0;
+                            float x = 0.f;
+                            if (p.resid) x = p.resid_scale * rbase[(unsigned)(ml * ldr + nl)];
+                            if (p.g0) x += p.g0[(unsigned)(p.gi0[m0 + ml] * ldg0 + n0 + nl)];
+                            if (p.g1) x += p.g1[(unsigned)(p.gi1[m0 + ml] * ldg1 + n0 + nl)];
+                            acc[tm][tn][r] = x;
+                        }
+                }
+            }
+            mma_slice<TM, TN>(cur + (wm * TM * 32) * LDT, cur + BM * LDT + (wn * TN * 32) * LDT, acc, lane);
+            if (more) {
+                if (p.relu_a) stage_relu<BM>(ra);
+                stage_store<BM>(nxt, ra, tid);
+                stage_store<BN>(nxt + BM * LDT, rb, tid);
+            }
+            __syncthreads();
+            if (last) {
+                // ---- epilogue: lane holds column n, 16 rows per 32x32 tile ----
+                int ldc = p.ldc, lv = lane;
+                asm volatile("" : "+s"(ldc), "+v"(lv));              // see above: no LICM of the store offsets
+                const int li = lv & 31, hi = lv >> 5;
+                float* cbase = p.C + (size_t)m0 * ldc + n0;
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    const int nl = (wn * TN + tn) * 32 + li;
+                    const bool n_ok = n0 + nl < p.N;
+                    const float bn = (p.bias && n_ok) ? p.bias[n0 + nl] : 0.f;
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int ml = (wm * TM + tm) * 32 + crow32(r, hi);
+                            const bool m_ok = m0 + ml < p.M;
+                            float x = acc[tm][tn][r];
+                            acc[tm][tn][r] = 0.f;
+                            if (p.rowscale) x *= p.rowscale[m_ok ? m0 + ml : p.M - 1];
+                            x += bn;
+                            if (p.act == ACT_RELU) x = fmaxf(x, 0.f);
+                            else if (p.act == ACT_SIGMOID) x = 1.f / (1.f + __expf(-x));
+                            if (n_ok && m_ok) cbase[(unsigned)(ml * ldc + nl)] = x;
+                        }
+                    }
+                }
+            }
+            buf ^= 1;
         }
+        if (!next_tile) break;
+        ++round;
+        m0 = nm0;
+        n0 = nn0;
     }
 }
 
 double gemm_flops(const GemmArgs& a) { return 2.0 * a.M * (double)a.N * a.K; }
 
+static int g_slots = 0;      // resident 256-thread blocks the persistent grid may use (2 per CU)
+static int slots() {
+    if (!g_slots) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            hipDeviceProp_t pr;
+            if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount;
+        }
+        g_slots = ((2 * cus) / 8) * 8;
+        if (g_slots < 8) g_slots = 8;
+    }
+    return g_slots;
+}
+
 template <int BM, int BN>
-static int launch_t(const GemmArgs& a, hipStream_t s) {
-    const int nb = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN>), dim3(nb), dim3(256), 0, s, a);
+static int launch_t(const GemmArgs& a, int n_tiles, int grid, hipStream_t s) {
+    const int nbn = (a.N + BN - 1) / BN;
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN>), dim3(grid), dim3(256), 0, s, a, n_tiles, nbn);
     VLSAT_LAUNCH_CHECK("gemm_f32");
     return 0;
+}
+
+// rows [row0, M) of the problem as a sub-problem
+static GemmArgs tail_of(const GemmArgs& a, int row0) {
+    GemmArgs t = a;
+    t.A += (size_t)row0 * a.lda;
+    t.C += (size_t)row0 * a.ldc;
+    t.M = a.M - row0;
+    if (a.rowscale) t.rowscale += row0;
+    if (a.resid) t.resid += (size_t)row0 * a.ldr;
+    if (a.gi0) t.gi0 += row0;
+    if (a.gi1) t.gi1 += row0;
+    return t;
+}
+
+template <int BM, int BN>
+static int run_tiled(const GemmArgs& a, hipStream_t s) {
+    const int G = slots();
+    const int nbm = (a.M + BM - 1) / BM, nbn = (a.N + BN - 1) / BN;
+    const long T = (long)nbm * nbn;
+    if (T <= G) {                                   // one round: grid = tiles (rounded up to 8)
+        const int grid = (int)((T + 7) / 8) * 8;
+        return launch_t<BM, BN>(a, (int)T, grid, s);
+    }
+    // full rounds with this tile; the remaining M-panels go to a smaller tile (see header)
+    const long rounds = T / G;
+    long main_panels = (rounds * G) / nbn;
+    if (main_panels <= 0 || main_panels >= nbm || (BM == 64 && BN == 64)) return launch_t<BM, BN>(a, (int)T, G, s);
+    GemmArgs m = a;
+    m.M = (int)(main_panels * BM);
+    int r = launch_t<BM, BN>(m, (int)(main_panels * nbn), G, s);
+    if (r) return r;
+    return launch_gemm(tail_of(a, (int)(main_panels * BM)), s);   // strictly fewer rows: terminates
 }
 
 int launch_gemm(const GemmArgs& a, hipStream_t s) {
@@ -105,13 +214,14 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
     if ((a.lda & 3) || (a.ldw & 3)) return fail(-1, "gemm: lda/ldw must be multiples of 4 floats");
     if ((reinterpret_cast<uintptr_t>(a.A) & 15) || (reinterpret_cast<uintptr_t>(a.W) & 15))
         return fail(-1, "gemm: A/W must be 16-byte aligned");
+    const int G = slots();
     auto blocks = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
-    // Largest tile that still gives every CU (256) two blocks; small problems take the
-    // smallest tile so the launch covers as many CUs as the problem allows.
-    if (a.N > 64 && blocks(128, 128) >= 512) return launch_t<128, 128>(a, s);
-    if (a.N <= 64 && blocks(128, 64) >= 512) return launch_t<128, 64>(a, s);
-    if (a.N > 64 && blocks(64, 128) >= 512) return launch_t<64, 128>(a, s);
-    return launch_t<64, 64>(a, s);
+    // Largest tile that still gives every resident slot a tile; small problems (and the tails
+    // of big ones) take smaller tiles so the launch covers as many CUs as the problem allows.
+    if (a.N > 64 && blocks(128, 128) >= G) return run_tiled<128, 128>(a, s);
+    if (a.N <= 64 && blocks(128, 64) >= G) return run_tiled<128, 64>(a, s);
+    if (a.N > 64 && blocks(64, 128) >= G) return run_tiled<64, 128>(a, s);
+    return run_tiled<64, 64>(a, s);
 }
 
 }  // namespace vlsat

@@ -108,6 +108,25 @@ def test_gemm_all_epilogues(lib):
             assert err < 3e-5, f"act={act} relu_a={relu_a}: {err:.3e}"
 
 
+def test_gemm_persistent_rounds_with_epilogues(lib):
+    """Several rounds of the persistent grid plus the small-tile tail launch, with gathered
+    rows, residual and ReLU-on-A (the nn_edge / out-proj launch shapes in miniature)."""
+    g = torch.Generator().manual_seed(21)
+    M, N, K, NG = 3 * 512 * 128 // 4 + 777, 512, 64, 301      # 1536 tiles of 128x128 -> 3 rounds + tail rows
+    A = torch.randn(M, K, generator=g).to(DEV)
+    W = (torch.randn(N, K, generator=g) * 0.1).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    resid = torch.randn(M, N, generator=g).to(DEV)
+    gbuf = torch.randn(NG, 2 * N, generator=g).to(DEV)
+    gi0 = torch.randint(0, NG, (M,), generator=g, dtype=torch.int32).to(DEV)
+    gi1 = torch.randint(0, NG, (M,), generator=g, dtype=torch.int32).to(DEV)
+    kw = dict(bias=bias, resid=resid, resid_scale=1.0, g0=gbuf[:, :N], gi0=gi0, g1=gbuf[:, N:], gi1=gi1, relu_a=1, act=1)
+    got = _gemm(lib, A, W, **kw)
+    ref = _ref_gemm(A, W, **kw)
+    err = float((got - ref).abs().max())
+    assert err < 3e-5, f"{err:.3e}"
+
+
 def test_gemm_strided_a_and_inplace_residual(lib):
     """The forward feeds A with a 768 pitch and adds the residual in place (C == resid)."""
     g = torch.Generator().manual_seed(5)
