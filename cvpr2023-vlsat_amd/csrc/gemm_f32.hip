@@ -212,6 +212,8 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0) return 0;
     if (a.K <= 0 || a.K % BK) return fail(-1, "gemm: K must be a positive multiple of 32");
     if ((a.lda & 3) || (a.ldw & 3)) return fail(-1, "gemm: lda/ldw must be multiples of 4 floats");
+    if (a.rowscale && (a.resid || a.g0 || a.g1))
+        return fail(-1, "gemm: rowscale cannot be combined with resid/g0/g1 (additive operands are accumulator inits)");
     if ((reinterpret_cast<uintptr_t>(a.A) & 15) || (reinterpret_cast<uintptr_t>(a.W) & 15))
         return fail(-1, "gemm: A/W must be 16-byte aligned");
     const int G = slots();

@@ -108,7 +108,8 @@ int vlsat_profile_read(vlsat_handle h, int32_t cls, double* total_ms, int64_t* l
 /* C[M,N] = act(rowscale[m] * (reluA?(A)[M,K] . W[N,K]^T) + bias[n] + resid_scale*resid[m,n]
  *              + g0[gi0[m], n] + g1[gi1[m], n]);   act: 0 none, 1 relu, 2 sigmoid.
  * Replaces every nn.Linear / Conv1d(k=1) call site of the path (SURVEY §2 "addmm" row).
- * K % 32 == 0; lda/ldw % 4 == 0; any pointer except A, W, C may be NULL. */
+ * K % 32 == 0; lda/ldw % 4 == 0; any pointer except A, W, C may be NULL; rowscale may not be
+ * combined with resid/g0/g1 (VLSAT_EINVAL). */
 int vlsat_k_gemm(const float* A, int32_t lda, const float* W, int32_t ldw, float* C, int32_t ldc,
                  int32_t M, int32_t N, int32_t K,
                  const float* bias, const float* rowscale,

@@ -100,12 +100,15 @@ def test_gemm_all_epilogues(lib):
     g0v, g1v = gbuf[:, :N], gbuf[:, N:2 * N]
     for act in (0, 1, 2):
         for relu_a in (0, 1):
-            kw = dict(bias=bias, rowscale=rs, resid=resid, resid_scale=0.5, g0=g0v, gi0=gi0, g1=g1v, gi1=gi1,
-                      relu_a=relu_a, act=act)
-            got = _gemm(lib, A, W, ldc=N + 3, **kw)
-            ref = _ref_gemm(A, W, **kw)
-            err = float((got - ref).abs().max())
-            assert err < 3e-5, f"act={act} relu_a={relu_a}: {err:.3e}"
+            for kw in (dict(bias=bias, resid=resid, resid_scale=0.5, g0=g0v, gi0=gi0, g1=g1v, gi1=gi1),
+                       dict(bias=bias, rowscale=rs), dict(resid=resid), dict(g1=g1v, gi1=gi1)):
+                kw = dict(kw, relu_a=relu_a, act=act)
+                got = _gemm(lib, A, W, ldc=N + 3, **kw)
+                ref = _ref_gemm(A, W, **kw)
+                err = float((got - ref).abs().max())
+                assert err < 3e-5, f"act={act} relu_a={relu_a} {sorted(kw)}: {err:.3e}"
+    with pytest.raises(lib.VlsatError):
+        _gemm(lib, A, W, rowscale=rs, resid=resid)
 
 
 def test_gemm_persistent_rounds_with_epilogues(lib):

@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the fp32 MFMA GEMM through the C ABI on the shapes the cfg-2 forward launches.
+    python tools/gemm_bench.py [--iters 20] [--only NAME]
+Prints one line per shape: time, TFLOP/s, fraction of the 157.3 TF fp32 MFMA peak."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import vlsat_amd  # noqa: E402
+from vlsat_amd import lib as L  # noqa: E402
+
+E, N = 99840, 2560
+SHAPES = [
+    # name, M, N, K, resid, gather
+    ("kproj/q/fc1 E x512 x512", E, 512, 512, False, False),
+    ("out-proj +resid E x512 x512", E, 512, 512, True, False),
+    ("kv E x1024 x512", E, 1024, 512, False, False),
+    ("nn_edge.0 +gather E x1024 x512", E, 1024, 512, False, True),
+    ("nn_edge.2 E x512 x1024", E, 512, 1024, False, False),
+    ("rel conv3 E x512 x128", E, 512, 128, False, False),
+    ("rel conv2 E x128 x64", E, 128, 64, False, False),
+    ("fc2 E x256 x512", E, 256, 512, False, False),
+    ("fc3 E x26 x256", E, 26, 256, False, False),
+    ("node proj N x3328 x512", N, 3328, 512, False, False),
+    ("node qkv N x1536 x512", N, 1536, 512, False, False),
+    ("node 512", N, 512, 512, True, False),
+    ("prop.0 N x768 x768", N, 768, 768, False, False),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    lib = L.load()
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(0)
+    for name, M, Nn, K, resid, gather in SHAPES:
+        if a.only and a.only not in name:
+            continue
+        A = torch.randn(M, K, generator=g).to(dev)
+        W = (torch.randn(Nn, K, generator=g) * 0.05).to(dev)
+        Cb = torch.empty(M, Nn, device=dev)
+        bias = torch.randn(Nn, generator=g).to(dev)
+        R = torch.randn(M, Nn, device=dev) if resid else None
+        G0 = torch.randn(N, 2 * Nn, device=dev) if gather else None
+        gi = torch.randint(0, N, (M,), dtype=torch.int32, device=dev) if gather else None
+
+        def run():
+            L.check(lib.vlsat_k_gemm(A.data_ptr(), K, W.data_ptr(), K, Cb.data_ptr(), Nn, M, Nn, K, bias.data_ptr(), 0,
+                                     L.ptr(R), Nn if resid else 0, 1.0,
+                                     L.ptr(G0), L.ptr(gi), 2 * Nn if gather else 0,
+                                     (G0.data_ptr() + 4 * Nn) if gather else 0, L.ptr(gi), 2 * Nn if gather else 0,
+                                     0, 1, L.stream_ptr()))
+        for _ in range(3):
+            run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.iters):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / a.iters
+        tf = 2.0 * M * Nn * K / (ms * 1e-3) / 1e12
+        print(f"{name:34s} {ms * 1e3:9.1f} us  {tf:7.1f} TF  {100 * tf / 157.3:5.1f} %", flush=True)
+
+
+if __name__ == "__main__":
+    main()
