@@ -34,7 +34,9 @@
 
 namespace vlsat {
 
-template <int BM, int BN>
+// ADD (compile time, so the 64 accumulator-init loads per lane are branch-free and batched):
+//   bit 0 = residual, bit 1 = gathered rows g0, bit 2 = gathered rows g1.
+template <int BM, int BN, int ADD>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int n_tiles, int nbn) {
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int STAGE = (BM + BN) * LDT;
@@ -44,7 +46,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int n_tile
     const int wm = wave >> 1, wn = wave & 1;
     const int g8 = gridDim.x >> 3, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int KT = p.K / BK;
-    const bool has_add = p.resid || p.g0 || p.g1;
 
     int round = 0;
     int v = xcd * g8 + slot;                 // tile of round r: (r*8 + xcd)*g8 + slot
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int n_tile
                 stage_load<BM>(p.A, p.lda, lm0, p.M - 1, lk, ra, tid);
                 stage_load<BN>(p.W, p.ldw, ln0, p.N - 1, lk, rb, tid);
             }
-            if (kt == 0 && has_add) {
+            if (ADD != 0 && kt == 0) {
                 // additive epilogue operands (residual / gathered rows) are loaded straight into
                 // the accumulators at the start of a tile (C-in of the first MFMA): no extra
                 // registers, and the wait overlaps the co-resident block's MFMAs.
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int n_tile
                 int ldr = p.ldr, ldg0 = p.ldg0, ldg1 = p.ldg1, lv = lane;
                 asm volatile("" : "+s"(ldr), "+s"(ldg0), "+s"(ldg1), "+v"(lv));
                 const int li = lv & 31, hi = lv >> 5;
-                const float* rbase = p.resid ? p.resid + (size_t)m0 * ldr + n0 : nullptr;
+                const float* rbase = (ADD & 1) ? p.resid + (size_t)m0 * ldr + n0 : nullptr;
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) {
                     int nl = (wn * TN + tn) * 32 + li;                    // column inside the tile
@@ -99,9 +100,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int n_tile
                             int ml = (wm * TM + tm) * 32 + crow32(r, hi);   // row inside the tile
                             if (m0 + ml >= p.M) ml = p.M - 1 - m0;
                             float x = 0.f;
-                            if (p.resid) x = p.resid_scale * rbase[(unsigned)(ml * ldr + nl)];
-                            if (p.g0) x += p.g0[(unsigned)(p.gi0[m0 + ml] * ldg0 + n0 + nl)];
-                            if (p.g1) x += p.g1[(unsigned)(p.gi1[m0 + ml] * ldg1 + n0 + nl)];
+                            if (ADD & 1) x = p.resid_scale * rbase[(unsigned)(ml * ldr + nl)];
+                            if (ADD & 2) x += p.g0[(unsigned)(p.gi0[m0 + ml] * ldg0 + n0 + nl)];
+                            if (ADD & 4) x += p.g1[(unsigned)(p.gi1[m0 + ml] * ldg1 + n0 + nl)];
                             acc[tm][tn][r] = x;
                         }
                 }
@@ -169,7 +170,14 @@ static int slots() {
 template <int BM, int BN>
 static int launch_t(const GemmArgs& a, int n_tiles, int grid, hipStream_t s) {
     const int nbn = (a.N + BN - 1) / BN;
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN>), dim3(grid), dim3(256), 0, s, a, n_tiles, nbn);
+    const int add = (a.resid ? 1 : 0) | (a.g0 ? 2 : 0) | (a.g1 ? 4 : 0);
+#define VLSAT_GEMM_CASE(ADD) \
+    case ADD: hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, ADD>), dim3(grid), dim3(256), 0, s, a, n_tiles, nbn); break;
+    switch (add) {
+        VLSAT_GEMM_CASE(0) VLSAT_GEMM_CASE(1) VLSAT_GEMM_CASE(2) VLSAT_GEMM_CASE(3)
+        VLSAT_GEMM_CASE(4) VLSAT_GEMM_CASE(5) VLSAT_GEMM_CASE(6) VLSAT_GEMM_CASE(7)
+    }
+#undef VLSAT_GEMM_CASE
     VLSAT_LAUNCH_CHECK("gemm_f32");
     return 0;
 }
