@@ -59,22 +59,37 @@ template <int TM, int TN, int PITCH_A = LDT, int PITCH_B = LDT>
 __device__ __forceinline__ void mma_slice(const float* __restrict__ sA, const float* __restrict__ sB,
                                           f32x16 (&acc)[TM][TN], int lane) {
     const int li = lane & 31, hi = lane >> 5;
-#pragma unroll
-    for (int kg = 0; kg < BK / 8; ++kg) {
-        f32x4 a[TM], b[TN];
+    // Two fragment sets in flight: the ds_reads of k-group kg+2 are issued right after the MFMAs
+    // of group kg have ISSUED (they read their operands at issue) and are consumed one whole
+    // group (TM*TN*4 MFMAs) later, so LDS latency never reaches the matrix pipe.  The
+    // sched_barriers pin that order (left alone, hipcc re-uses one register set and places the
+    // reads one MFMA ahead of their use).
+    f32x4 a[2][TM], b[2][TN];
+    auto load = [&](int set, int kg) {
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
-            a[tm] = *reinterpret_cast<const f32x4*>(sA + (tm * 32 + li) * PITCH_A + kg * 8 + hi * 4);
+            a[set][tm] = *reinterpret_cast<const f32x4*>(sA + (tm * 32 + li) * PITCH_A + kg * 8 + hi * 4);
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn)
-            b[tn] = *reinterpret_cast<const f32x4*>(sB + (tn * 32 + li) * PITCH_B + kg * 8 + hi * 4);
+            b[set][tn] = *reinterpret_cast<const f32x4*>(sB + (tn * 32 + li) * PITCH_B + kg * 8 + hi * 4);
+    };
+    load(0, 0);
+    load(1, 1);
+#pragma unroll
+    for (int kg = 0; kg < BK / 8; ++kg) {
+        const int set = kg & 1;
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][s], b[tn][s], acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[set][tm][s], b[set][tn][s], acc[tm][tn], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kg + 2 < BK / 8) {
+            load(set, kg + 2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 }
 

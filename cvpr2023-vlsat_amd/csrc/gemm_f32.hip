@@ -29,6 +29,7 @@
 //
 // Roofline: fp32 MFMA (157.3 TF).  Per 128x128x32 slice a block moves 32 KB from L2 for
 // 1.05 MFLOP (~19 GB/s/CU at peak rate): MFMA-issue bound, LDS is 4 ds_read_b128 per 16 MFMAs.
+#include <cstdlib>
 #include "gemm_core.h"
 #include "kernels.h"
 
@@ -120,27 +121,69 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int n_tile
                 asm volatile("" : "+s"(ldc), "+v"(lv));              // see above: no LICM of the store offsets
                 const int li = lv & 31, hi = lv >> 5;
                 float* cbase = p.C + (size_t)m0 * ldc + n0;
+                // Everything below is straight-line code under WAVE-UNIFORM branches: per-element
+                // branches on the runtime flags cost ~30 % of the tile time in the first version.
+                if (p.rowscale) {
 #pragma unroll
-                for (int tn = 0; tn < TN; ++tn) {
-                    const int nl = (wn * TN + tn) * 32 + li;
-                    const bool n_ok = n0 + nl < p.N;
-                    const float bn = (p.bias && n_ok) ? p.bias[n0 + nl] : 0.f;
-#pragma unroll
-                    for (int tm = 0; tm < TM; ++tm) {
+                    for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
-                            const int ml = (wm * TM + tm) * 32 + crow32(r, hi);
-                            const bool m_ok = m0 + ml < p.M;
-                            float x = acc[tm][tn][r];
-                            acc[tm][tn][r] = 0.f;
-                            if (p.rowscale) x *= p.rowscale[m_ok ? m0 + ml : p.M - 1];
-                            x += bn;
-                            if (p.act == ACT_RELU) x = fmaxf(x, 0.f);
-                            else if (p.act == ACT_SIGMOID) x = 1.f / (1.f + __expf(-x));
-                            if (n_ok && m_ok) cbase[(unsigned)(ml * ldc + nl)] = x;
+                            int m = m0 + (wm * TM + tm) * 32 + crow32(r, hi);
+                            m = m < p.M ? m : p.M - 1;
+                            const float rs = p.rowscale[m];
+#pragma unroll
+                            for (int tn = 0; tn < TN; ++tn) acc[tm][tn][r] *= rs;
                         }
+                }
+                if (p.bias) {
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) {
+                        int n = n0 + (wn * TN + tn) * 32 + li;
+                        n = n < p.N ? n : p.N - 1;
+                        const float bn = p.bias[n];
+#pragma unroll
+                        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[tm][tn][r] += bn;
                     }
                 }
+                if (p.act == ACT_RELU) {
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = fmaxf(acc[tm][tn][r], 0.f);
+                } else if (p.act == ACT_SIGMOID) {
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 1.f / (1.f + __expf(-acc[tm][tn][r]));
+                }
+                if (m0 + BM <= p.M && n0 + BN <= p.N) {          // interior tile: unguarded stores
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int ml = (wm * TM + tm) * 32 + crow32(r, hi), nl = (wn * TN + tn) * 32 + li;
+                                cbase[(unsigned)(ml * ldc + nl)] = acc[tm][tn][r];
+                            }
+                } else {
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int ml = (wm * TM + tm) * 32 + crow32(r, hi), nl = (wn * TN + tn) * 32 + li;
+                                if (m0 + ml < p.M && n0 + nl < p.N) cbase[(unsigned)(ml * ldc + nl)] = acc[tm][tn][r];
+                            }
+                }
+                zero_acc<TM, TN>(acc);
             }
             buf ^= 1;
         }
@@ -162,6 +205,7 @@ static int slots() {
             if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount;
         }
         g_slots = ((2 * cus) / 8) * 8;
+        if (const char* e = getenv("VLSAT_GEMM_SLOTS")) g_slots = (atoi(e) / 8) * 8;   // tuning knob
         if (g_slots < 8) g_slots = 8;
     }
     return g_slots;
