@@ -144,8 +144,22 @@ def main():
         c = classes[dom]
         avg_ms = c["ms"] / max(c["launches"], 1)
         achieved = c["flops"] / (c["ms"] * 1e-3) / 1e12 if c["ms"] > 0 else 0.0
+        traffic, traffic_src = None, None
+        default_wl = (args.scenes, args.objects, args.points, args.layers) == (64, 40, 256, 3)
+        pmc = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_bench_pmc.json")) \
+            if os.path.isdir(os.path.join(ROOT, "profiles")) else []
+        if default_wl and pmc:
+            # HBM bytes per launch of the dominant kernel class from the committed rocprofv3 PMC passes of this
+            # same command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; tools/pmc_summary.py)
+            try:
+                cls = json.load(open(os.path.join(ROOT, "profiles", pmc[-1])))["classes"]
+                traffic = round(cls[dom]["hbm_bytes_per_launch"])
+                traffic_src = "profiles/" + pmc[-1]
+            except Exception:
+                traffic = None
         roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "traffic_unit": "HBM bytes per launch (PMC)", "traffic_source": traffic_src,
                     "launches_per_step": c["launches"] // args.steps, "avg_launch_ms": round(avg_ms, 4),
                     "flop_per_launch": c["flops"] / max(c["launches"], 1),
                     "whole_forward_tflops": round(falg * value / world / 1e12, 2),
@@ -166,7 +180,7 @@ def main():
         "metric": "scenes/sec (3RScan-shaped, N=40 obj x 256 pts)", "value": round(value, 2), "unit": "scenes/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[1]: batch of {args.scenes} synthetic scenes per GPU, "
+        "config": {"workload": f"{'BASELINE configs[1]' if (args.scenes, args.objects, args.points, args.layers) == (64, 40, 256, 3) else 'custom'}: batch of {args.scenes} synthetic scenes per GPU, "
                                f"{args.objects} objects x {args.points} pts, fully-connected edges "
                                f"(E={e_scene}/scene), {args.layers} GNN layers, fp32",
                    "scenes_per_gpu": args.scenes, "parallelism": f"scene-sharded x{world}"},

@@ -189,6 +189,34 @@ def test_batch_independence_full_size():
     assert float(got[2].min()) >= 0 and float(got[2].max()) <= 1
 
 
+def test_mid_size_scene_multi_tile():
+    """70 objects x 100 points (ragged last point chunk), E = 4830: several flash-attention
+    query tiles with a partial last one, several GEMM rounds; against the fp32 oracle."""
+    cfg = VLSATConfig(N_LAYERS=2)
+    b = synth.collate([synth.make_scene(70, 100, 7000), synth.make_scene(3, 100, 7001)])
+    _check(run_hip(cfg, b), run_oracle(cfg, b), TIGHT, "70-object scene + 3-object scene")
+
+
+def test_cfg5_large_scene_stress(golden_dir):
+    """BASELINE configs[4]: 200 objects x 1024 points, dense graph E = 39 800, L = 3, one scene.
+    Compared with the committed oracle subsample (tests/golden/make_golden_cfg5.py) plus
+    size-independent properties."""
+    cfg = VLSATConfig(N_LAYERS=3)
+    z = np.load(os.path.join(golden_dir, "cfg5_n200_p1024_l3_sub.npz"))
+    b = synth.make_batch(1, 200, 1024, seed0=5000)
+    got = run_hip(cfg, b)
+    idx = torch.from_numpy(z["edge_idx"])
+    _check([got[0], got[1], got[2][idx], got[3][idx]], [z["obj3d"], z["obj2d"], z["rel3d"], z["rel2d"]], TOL,
+           "cfg5 vs oracle subsample")
+    for g in got:
+        assert torch.isfinite(g).all()
+    assert float(got[2].min()) >= 0 and float(got[2].max()) <= 1 and float(got[3].min()) >= 0 and float(got[3].max()) <= 1
+    m = model_for(cfg)
+    d = _dev(b)
+    info = m.plan_info(d["edge_indices"], d["batch_ids"], 200, 1024)
+    assert info["n_scenes"] == 1 and info["is_fc"] and info["workspace_bytes"] < 2 * 1024 ** 3   # O(E), not O(E^2)
+
+
 def test_plan_cache_not_fooled_by_address_reuse():
     """Two different graphs with identical shapes: a plan must never be reused across them."""
     cfg = VLSATConfig(N_LAYERS=2)
