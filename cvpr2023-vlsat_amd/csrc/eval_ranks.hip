@@ -1,0 +1,158 @@
+// Eval ranking step that process_val runs on the forward's outputs:
+//   evaluate_topk_object     reference src/utils/eva_utils_acc.py:27-39
+//   evaluate_topk_predicate  :42-79
+//   evaluate_triplet_topk    :137-213 (use_clip=True)
+// The reference sorts per element on the CPU (for every edge it sorts the full 160x160x26 =
+// 665 600-entry outer product: 74 ms/edge, ~116 s per cfg-2 scene).  A rank only needs COUNTS:
+// walking a descending sort until `pred[gt] >= pred[idx] or index > topk` stops after
+// min(#strictly-greater, topk) steps, and the position of the gt triple in the top-k list is
+// #{conf > gt_conf} + 1.  The outer product is never materialised: a block per edge counts
+// the triples above each threshold, pruning (i,j) pairs with the exact monotone bound
+// (s_i*o_j)*max_k r_k.  All comparisons use the same fp32 products ((s*o)*r, no FMA) as the
+// reference's two einsums, so counts are bit-exact functions of the fp32 inputs.
+// Integer / HBM-latency work: no MFMA.
+#include "common.h"
+#include "kernels.h"
+
+namespace vlsat {
+
+// probs[n, :] = softmax(x[n, :])  (F.softmax in evaluate_triplet_topk :144); one wave per row
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, int ld, int rows, int cols,
+                                                           float* __restrict__ out) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* p = x + (size_t)row * ld;
+    float m = -INFINITY;
+    for (int c = lane; c < cols; c += 64) m = fmaxf(m, p[c]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int c = lane; c < cols; c += 64) s += expf(p[c] - m);
+    s = wave_sum(s);
+    for (int c = lane; c < cols; c += 64) out[(size_t)row * cols + c] = expf(p[c] - m) / s;
+}
+
+__global__ __launch_bounds__(256) void obj_rank_kernel(const float* __restrict__ pred, int ld, const int64_t* __restrict__ gt,
+                                                       int n, int cols, int topk, int32_t* __restrict__ rank) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float* p = pred + (size_t)row * ld;
+    const float g = p[gt[row]];
+    int c = 0;
+    for (int k = lane; k < cols; k += 64) c += p[k] > g;
+    c = (int)wave_sum((float)c);
+    if (lane == 0) rank[row] = min(c, topk) + 1;
+}
+
+// sort ascending, subtract position (eva_utils_acc.py:73-77), n <= 32
+__device__ inline void finish_edge(int* r, int n, int32_t* out, int stride_pad) {
+    for (int i = 1; i < n; ++i) {
+        int v = r[i], j = i - 1;
+        while (j >= 0 && r[j] > v) { r[j + 1] = r[j]; --j; }
+        r[j + 1] = v;
+    }
+    for (int i = 0; i < stride_pad; ++i) out[i] = i < n ? r[i] - i : 0;
+}
+
+__global__ __launch_bounds__(256) void rel_rank_kernel(const float* __restrict__ rel, const int64_t* __restrict__ gt_rel,
+                                                       int n_edges, int R, int topk, float thr,
+                                                       int32_t* __restrict__ out, int32_t* __restrict__ cnt) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_edges) return;
+    const float* p = rel + (size_t)e * R;
+    const int64_t* g = gt_rel + (size_t)e * R;
+    int r[32], n = 0;
+    for (int k = 0; k < R; ++k)
+        if (g[k] == 1) {
+            int c = 0;
+            for (int q = 0; q < R; ++q) c += p[q] > p[k];
+            r[n++] = min(c, topk) + 1;
+        }
+    if (n == 0) {
+        int ge = 0;
+        for (int q = 0; q < R; ++q) ge += p[q] >= thr;
+        r[n++] = ge == R ? topk + 1 : ge + 1;
+    }
+    finish_edge(r, n, out + (size_t)e * R, R);
+    cnt[e] = n;
+}
+
+// One block per edge.  probs [N,C] (softmaxed object scores), rel [E,R], edges [E,2] = (from, to).
+__global__ __launch_bounds__(256) void tri_rank_kernel(const float* __restrict__ probs, const float* __restrict__ rel,
+                                                       const int64_t* __restrict__ gt_cls, const int64_t* __restrict__ gt_rel,
+                                                       const int64_t* __restrict__ edges, int C, int R, int topk, float thr,
+                                                       int32_t* __restrict__ out) {
+    __shared__ float s_sub[1024], s_obj[1024], s_rel[32], s_thr[32];
+    __shared__ int s_cnt[32], s_n, s_ge;
+    const int e = blockIdx.x, tid = threadIdx.x;
+    const int a = (int)edges[2 * e], b = (int)edges[2 * e + 1];
+    for (int c = tid; c < C; c += 256) {
+        s_sub[c] = probs[(size_t)a * C + c];
+        s_obj[c] = probs[(size_t)b * C + c];
+    }
+    if (tid < R) s_rel[tid] = rel[(size_t)e * R + tid];
+    if (tid < 32) s_cnt[tid] = 0;
+    __syncthreads();
+    if (tid == 0) {
+        const float gs = s_sub[gt_cls[a]] * s_obj[gt_cls[b]];
+        int n = 0;
+        for (int k = 0; k < R; ++k)
+            if (gt_rel[(size_t)e * R + k] == 1) s_thr[n++] = gs * s_rel[k];
+        s_ge = 0;
+        if (n == 0) { s_thr[n++] = thr; s_ge = 1; }         // no gt relation: count conf >= thr
+        s_n = n;
+    }
+    __syncthreads();
+    const int n = s_n, ge = s_ge;
+    float rmax = 0.f, tmin = INFINITY;
+    for (int k = 0; k < R; ++k) rmax = fmaxf(rmax, s_rel[k]);
+    for (int g = 0; g < n; ++g) tmin = fminf(tmin, s_thr[g]);
+    int local[4] = {0, 0, 0, 0};                              // up to 3 labels per edge is typical; more -> shared atomics
+    for (int p = tid; p < C * C; p += 256) {
+        const float ns = __fmul_rn(s_sub[p / C], s_obj[p % C]);
+        const float ub = __fmul_rn(ns, rmax);                 // exact monotone upper bound of (ns * r_k)
+        if (ge ? ub < tmin : ub <= tmin) continue;
+        for (int k = 0; k < R; ++k) {
+            const float c = __fmul_rn(ns, s_rel[k]);
+#pragma unroll
+            for (int g = 0; g < 4; ++g)                       // static register indices
+                if (g < n) local[g] += ge ? c >= s_thr[g] : c > s_thr[g];
+            for (int g = 4; g < n; ++g)
+                if (c > s_thr[g]) atomicAdd(&s_cnt[g], 1);
+        }
+    }
+    for (int g = 0; g < 4 && g < n; ++g)
+        if (local[g]) atomicAdd(&s_cnt[g], local[g]);
+    __syncthreads();
+    if (tid == 0) {
+        int r[32];
+        for (int g = 0; g < n; ++g) r[g] = min(s_cnt[g], topk) + 1;
+        finish_edge(r, n, out + (size_t)e * R, R);
+    }
+}
+
+int launch_softmax_rows(const float* x, int ld, int rows, int cols, float* out, hipStream_t s) {
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, ld, rows, cols, out);
+    VLSAT_LAUNCH_CHECK("softmax_rows");
+    return 0;
+}
+
+int launch_eval_ranks(const float* obj_logits, const float* obj_probs, const float* rel, const int64_t* gt_cls,
+                      const int64_t* gt_rel, const int64_t* edges, int N, int E, int C, int R, int topk_obj,
+                      int topk_rel, int topk_tri, float thr, int32_t* obj_rank, int32_t* rel_rank, int32_t* tri_rank,
+                      int32_t* cnt, hipStream_t s) {
+    if (C > 1024 || R > 32) return fail(-1, "eval_ranks: at most 1024 object and 32 relation classes");
+    if (N > 0) {
+        hipLaunchKernelGGL(obj_rank_kernel, dim3((N + 3) / 4), dim3(256), 0, s, obj_logits, C, gt_cls, N, C, topk_obj, obj_rank);
+        VLSAT_LAUNCH_CHECK("obj_rank");
+    }
+    if (E > 0) {
+        hipLaunchKernelGGL(rel_rank_kernel, dim3((E + 255) / 256), dim3(256), 0, s, rel, gt_rel, E, R, topk_rel, thr, rel_rank, cnt);
+        VLSAT_LAUNCH_CHECK("rel_rank");
+        hipLaunchKernelGGL(tri_rank_kernel, dim3(E), dim3(256), 0, s, obj_probs, rel, gt_cls, gt_rel, edges, C, R, topk_tri, thr, tri_rank);
+        VLSAT_LAUNCH_CHECK("tri_rank");
+    }
+    return 0;
+}
+
+}  // namespace vlsat

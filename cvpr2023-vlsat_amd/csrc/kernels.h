@@ -84,4 +84,11 @@ int launch_edge_gate(const GateArgs& a, hipStream_t s);
 int launch_aggregate(const float* gated, int n_ch, const int32_t* rowptr, const int32_t* order,
                      int n_nodes, int aggr, float* out, int ldo, int col0, hipStream_t s);
 
+// ---- eval ranking step: softmax + top-k ranks by counting ----
+int launch_softmax_rows(const float* x, int ld, int rows, int cols, float* out, hipStream_t s);
+int launch_eval_ranks(const float* obj_logits, const float* obj_probs, const float* rel, const int64_t* gt_cls,
+                      const int64_t* gt_rel, const int64_t* edges, int N, int E, int C, int R, int topk_obj,
+                      int topk_rel, int topk_tri, float thr, int32_t* obj_rank, int32_t* rel_rank, int32_t* tri_rank,
+                      int32_t* cnt, hipStream_t s);
+
 }  // namespace vlsat

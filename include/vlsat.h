@@ -137,6 +137,25 @@ int vlsat_k_flash_attn(const float* Q, const float* K, const float* V, float* O,
 int vlsat_k_layernorm(float* x, int32_t ld, int32_t rows, int32_t dim, const float* gamma,
                       const float* beta, int32_t relu, void* stream);
 
+/* -------- eval ranking step (the caller of the path: process_val, reference SGFN_MMG/model.py:463-472) --- */
+
+/* out[r, :] = softmax(x[r, 0:cols]) -- F.softmax(objs_pred) of evaluate_triplet_topk
+ * (reference src/utils/eva_utils_acc.py:144).  out is dense [rows, cols]. */
+int vlsat_k_softmax_rows(const float* x, int32_t ld, int32_t rows, int32_t cols, float* out, void* stream);
+
+/* evaluate_topk_object (eva_utils_acc.py:27-39), evaluate_topk_predicate (:42-79) and
+ * evaluate_triplet_topk (:137-213, multi_rel_outputs=True, use_clip=True) as counting kernels; all
+ * device pointers.  gt_rel is the multi-hot [E,R] int64 target, edges is [E,2] (from, to) int64 like
+ * the `edge_indices` the reference passes.  Outputs: obj_rank [N]; rel_rank / tri_rank [E,R] hold, for
+ * edge e, its cnt[e] = max(#gt relations, 1) ranks already sorted and position-adjusted as the reference
+ * appends them (first cnt[e] slots, rest 0).  Flattening the used slots in edge order gives exactly
+ * the reference's result arrays. */
+int vlsat_eval_ranks(const float* obj_logits, const float* obj_probs, const float* rel_probs,
+                     const int64_t* gt_class, const int64_t* gt_rel, const int64_t* edges,
+                     int32_t n_nodes, int32_t n_edges, int32_t n_obj_class, int32_t n_rel_class,
+                     int32_t topk_obj, int32_t topk_rel, int32_t topk_triplet, float threshold,
+                     int32_t* obj_rank, int32_t* rel_rank, int32_t* tri_rank, int32_t* cnt, void* stream);
+
 /* -------- debug / test hooks (used by tests/ to localise a parity failure) -------------------- */
 /* Stop vlsat_forward after stage `stage` (-1 = run everything).  Stages: 1 object encoder,
  * 2 node embedding, 3 edge embedding, 4 adapter, 5 distance bias, then for layer l:

@@ -1,0 +1,102 @@
+"""GPU eval-ranking kernels (csrc/eval_ranks.hip via the C ABI) against the reference goldens and
+the metrics oracle.  Integer outputs: bit-exact given the same fp32 probabilities."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import vlsat_amd  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: the HIP path cannot run and there is no fallback")
+
+
+@pytest.mark.parametrize("case", ["a", "b", "c"])
+def test_ranks_equal_reference_goldens(golden_dir, case):
+    _need_gpu()
+    from vlsat_amd import metrics as M
+    z = np.load(os.path.join(golden_dir, "metrics_small.npz"))
+    g = lambda k: torch.from_numpy(z[f"{case}.{k}"])
+    obj3 = None
+    for suffix in ("", "_2d"):
+        logits = g("obj_logits" + suffix)
+        probs = F.softmax(logits, dim=-1)            # the reference's CPU softmax -> bit-exact triple scores
+        r = M.eval_ranks(logits.to(DEV), g("rel" + suffix).to(DEV), g("gt_cls").to(DEV), g("gt_rel").to(DEV),
+                         g("edges").to(DEV), obj_probs=probs.to(DEV))
+        torch.cuda.synchronize()
+        assert np.array_equal(r["top_k_obj"].cpu().numpy(), z[f"{case}.top_k_obj{suffix}"])
+        assert np.array_equal(r["top_k_rel"].cpu().numpy(), z[f"{case}.top_k_rel{suffix}"])
+        assert np.array_equal(r["top_k_triplet"].cpu().numpy(), z[f"{case}.top_k_triplet{suffix}"])
+        if suffix == "":
+            obj3 = r["top_k_obj"]
+            cm = M.cls_matrix(g("gt_cls").to(DEV), g("gt_rel").to(DEV), g("edges").to(DEV), obj3)
+            assert np.array_equal(cm.cpu().numpy(), z[f"{case}.cls_matrix"])
+            s = M.summarize(r["top_k_obj"].cpu(), r["top_k_rel"].cpu(), r["top_k_triplet"].cpu(), cm.cpu())
+            assert np.allclose([s["mean_recall@50"], s["mean_recall@100"]], z[f"{case}.mean_recall"])
+        # with the GPU softmax the scores differ in the last bits at most: ranks agree (ties are measure-zero)
+        r2 = M.eval_ranks(logits.to(DEV), g("rel" + suffix).to(DEV), g("gt_cls").to(DEV), g("gt_rel").to(DEV),
+                          g("edges").to(DEV))
+        assert float((r2["obj_probs"].cpu() - probs).abs().max()) < 1e-6
+        agree = (r2["top_k_triplet"].cpu().numpy() == z[f"{case}.top_k_triplet{suffix}"]).mean()
+        assert agree >= 0.98, agree
+
+
+def test_ranks_equal_oracle_random_graph():
+    _need_gpu()
+    from vlsat_amd import metrics as M
+    from oracle import metrics_oracle as MO
+    g = torch.Generator().manual_seed(42)
+    n, e, C, R = 60, 300, 160, 26
+    logits = torch.randn(n, C, generator=g) * 4
+    gt = torch.randint(0, C, (n,), generator=g)
+    logits[torch.arange(0, n, 3), gt[::3]] += 10
+    edges = torch.stack([torch.randint(0, n, (e,), generator=g), torch.randint(0, n, (e,), generator=g)], 1)
+    rel = torch.sigmoid(torch.randn(e, R, generator=g) * 3)
+    gt_rel = (torch.rand(e, R, generator=g) < 0.07).long()
+    gt_rel[5] = 1                                     # an edge with all 26 labels (> 4 thresholds path)
+    probs = F.softmax(logits, dim=-1)
+    r = M.eval_ranks(logits.to(DEV), rel.to(DEV), gt.to(DEV), gt_rel.to(DEV), edges.to(DEV), obj_probs=probs.to(DEV))
+    torch.cuda.synchronize()
+    obj = MO.topk_object(logits, gt, 11)
+    assert np.array_equal(r["top_k_obj"].cpu().numpy(), obj)
+    assert np.array_equal(r["top_k_rel"].cpu().numpy(), MO.topk_predicate(rel, gt_rel, 6))
+    tri, cm = MO.triplet_topk(logits, rel, gt, gt_rel, edges, 101, obj, obj_probs=probs)
+    assert np.array_equal(r["top_k_triplet"].cpu().numpy(), tri)
+    assert np.array_equal(M.cls_matrix(gt.to(DEV), gt_rel.to(DEV), edges.to(DEV), r["top_k_obj"]).cpu().numpy(), cm)
+
+
+def test_process_val_tuple_matches_oracle_pipeline():
+    """End to end: forward + ranking through the process_val mirror, against oracle forward +
+    metrics oracle on the same scene."""
+    _need_gpu()
+    from vlsat_amd import VLSATConfig, synth, metrics as M
+    from vlsat_amd.model import VLSATModel
+    from oracle import vlsat_oracle as O, metrics_oracle as MO
+    cfg = VLSATConfig(N_LAYERS=2)
+    w = synth.make_weights(cfg)
+    b = synth.make_batch(1, 8, 64, seed0=8000)
+    g = torch.Generator().manual_seed(1)
+    n, e = 8, b["edge_indices"].shape[1]
+    gt_cls = torch.randint(0, 160, (n,), generator=g)
+    gt_rel = (torch.rand(e, 26, generator=g) < 0.06).long()
+    edges = torch.from_numpy(b["edge_indices"]).t().contiguous()             # [E,2] as the loader yields
+    model = VLSATModel(cfg, DEV).load_state(w).eval()
+    d = {k: torch.from_numpy(v).to(DEV) for k, v in b.items()}
+    out = M.process_val(model, d["obj_points"], d["obj_2d_feats"], gt_cls.to(DEV), d["descriptor"], gt_rel.to(DEV),
+                        edges.to(DEV), d["batch_ids"])
+    c = {k: torch.from_numpy(v) for k, v in b.items()}
+    ref = O.forward(O.to_torch(w), cfg, c["obj_points"], c["obj_2d_feats"], c["edge_indices"], c["descriptor"], c["batch_ids"])
+    obj3 = MO.topk_object(ref[0], gt_cls, 11)
+    assert np.array_equal(out[0], obj3) and np.array_equal(out[1], MO.topk_object(ref[1], gt_cls, 11))
+    assert np.array_equal(out[2], MO.topk_predicate(ref[2], gt_rel, 6))
+    assert np.array_equal(out[3], MO.topk_predicate(ref[3], gt_rel, 6))
+    tri, cm = MO.triplet_topk(ref[0], ref[2], gt_cls, gt_rel, edges, 101, obj3)
+    assert (out[4] == tri).mean() >= 0.97 and np.array_equal(out[6], cm)     # logits differ by ~4e-6: near-ties may flip
+    assert out[7].shape == (int(gt_rel.sum()), 160) and out[9].shape == (int(gt_rel.sum()), 26)
