@@ -106,23 +106,38 @@ __global__ __launch_bounds__(256) void tri_rank_kernel(const float* __restrict__
     float rmax = 0.f, tmin = INFINITY;
     for (int k = 0; k < R; ++k) rmax = fmaxf(rmax, s_rel[k]);
     for (int g = 0; g < n; ++g) tmin = fminf(tmin, s_thr[g]);
-    int local[4] = {0, 0, 0, 0};                              // up to 3 labels per edge is typical; more -> shared atomics
-    for (int p = tid; p < C * C; p += 256) {
-        const float ns = __fmul_rn(s_sub[p / C], s_obj[p % C]);
-        const float ub = __fmul_rn(ns, rmax);                 // exact monotone upper bound of (ns * r_k)
-        if (ge ? ub < tmin : ub <= tmin) continue;
-        for (int k = 0; k < R; ++k) {
-            const float c = __fmul_rn(ns, s_rel[k]);
+    // Counts are only needed up to topk (ranks are capped): pairs are walked in chunks of 16 per
+    // thread and the block stops as soon as every threshold has >= topk hits.  With a flat score
+    // distribution (untrained weights) almost every triple beats the gt score and the cap is hit in
+    // the first chunk; with a peaked one the (s_i*o_j)*max r bound prunes almost every pair.
+    const int total = C * C;
+    for (int base = 0; base < total; base += 256 * 16) {
+        int local[4] = {0, 0, 0, 0};
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+            const int p = base + it * 256 + tid;
+            if (p >= total) break;
+            const float ns = __fmul_rn(s_sub[p / C], s_obj[p % C]);
+            const float ub = __fmul_rn(ns, rmax);             // exact monotone upper bound of (ns * r_k)
+            if (ge ? ub < tmin : ub <= tmin) continue;
+            for (int k = 0; k < R; ++k) {
+                const float c = __fmul_rn(ns, s_rel[k]);
 #pragma unroll
-            for (int g = 0; g < 4; ++g)                       // static register indices
-                if (g < n) local[g] += ge ? c >= s_thr[g] : c > s_thr[g];
-            for (int g = 4; g < n; ++g)
-                if (c > s_thr[g]) atomicAdd(&s_cnt[g], 1);
+                for (int g = 0; g < 4; ++g)                   // static register indices
+                    if (g < n) local[g] += ge ? c >= s_thr[g] : c > s_thr[g];
+                for (int g = 4; g < n; ++g)
+                    if (c > s_thr[g]) atomicAdd(&s_cnt[g], 1);
+            }
         }
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            if (g < n && local[g]) atomicAdd(&s_cnt[g], local[g]);
+        __syncthreads();
+        int lo = s_cnt[0];
+        for (int g = 1; g < n; ++g) lo = min(lo, s_cnt[g]);
+        __syncthreads();
+        if (lo >= topk) break;                                // block-uniform
     }
-    for (int g = 0; g < 4 && g < n; ++g)
-        if (local[g]) atomicAdd(&s_cnt[g], local[g]);
-    __syncthreads();
     if (tid == 0) {
         int r[32];
         for (int g = 0; g < n; ++g) r[g] = min(s_cnt[g], topk) + 1;
