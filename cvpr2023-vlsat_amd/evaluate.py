@@ -1,0 +1,107 @@
+"""Scene-sharded evaluation loop: the MI355X counterpart of ``MMGNet.validation`` (reference
+``src/model/model.py:181-362``) for the part that sits on top of the hot path.
+
+Each rank walks its contiguous shard of the scene list, runs forward + ranking on its GPU
+(``metrics.process_val``), and accumulates a fixed-length vector of hit COUNTS.  Counts are
+additive over scenes, so ONE all-reduce(SUM) at the end (RCCL over xGMI; gloo in the CPU test)
+gives exactly the numbers a single process would get from the concatenated rank lists
+(``validation()`` concatenates and thresholds them, :214-242, :267-282); the per-predicate
+counts reproduce ``get_mean_recall`` (eva_utils_acc.py:224-237) and ``compute_mean_predicate``
+(model.py:364-388)."""
+from __future__ import annotations
+
+from typing import Dict, Iterable
+
+import numpy as np
+import torch
+
+from . import dist as vdist
+
+N_REL = 26
+# layout of the metrics vector (fp64): see fields()
+_OBJ_K, _REL_K, _TRI_K = (1, 5, 10), (1, 3, 5), (50, 100)
+
+
+def fields(n_rel: int = N_REL):
+    f = ["scenes"]
+    # get_mean_recall loops `range(int(cls_matrix.max()))` with the max taken over the WHOLE matrix
+    # (object classes and ranks included): class c counts iff some entry >= c+1.  Kept additive:
+    f += [f"cm_ge{k}" for k in range(1, n_rel + 1)]
+    for br in ("3d", "2d"):
+        f += [f"obj_n_{br}"] + [f"obj_hit@{k}_{br}" for k in _OBJ_K]
+        f += [f"rel_n_{br}"] + [f"rel_hit@{k}_{br}" for k in _REL_K]
+        f += [f"tri_n_{br}"] + [f"tri_hit@{k}_{br}" for k in _TRI_K]
+        for c in range(n_rel):
+            f += [f"cls{c}_n_{br}"] + [f"cls{c}_tri@{k}_{br}" for k in _TRI_K] + [f"cls{c}_rel@{k}_{br}" for k in _REL_K]
+    return f
+
+
+def accumulate(vec: np.ndarray, ranks: Dict[str, np.ndarray], cls_matrix: np.ndarray, n_scenes: int, n_rel: int = N_REL):
+    """Add one batch's rank arrays (process_val outputs) into the counts vector (in place)."""
+    idx = {k: i for i, k in enumerate(fields(n_rel))}
+    vec[idx["scenes"]] += n_scenes
+    pred = cls_matrix[:, -1] if len(cls_matrix) else np.zeros(0, dtype=np.int64)
+    for k in range(1, n_rel + 1):
+        vec[idx[f"cm_ge{k}"]] += int((cls_matrix >= k).sum()) if len(cls_matrix) else 0
+    for br, o, r, t in (("3d", ranks["top_k_obj"], ranks["top_k_rel"], ranks["top_k_triplet"]),
+                        ("2d", ranks["top_k_obj_2d"], ranks["top_k_rel_2d"], ranks["top_k_triplet_2d"])):
+        vec[idx[f"obj_n_{br}"]] += len(o)
+        vec[idx[f"rel_n_{br}"]] += len(r)
+        vec[idx[f"tri_n_{br}"]] += len(t)
+        for k in _OBJ_K:
+            vec[idx[f"obj_hit@{k}_{br}"]] += int((o <= k).sum())
+        for k in _REL_K:
+            vec[idx[f"rel_hit@{k}_{br}"]] += int((r <= k).sum())
+        for k in _TRI_K:
+            vec[idx[f"tri_hit@{k}_{br}"]] += int((t <= k).sum())
+        for c in range(n_rel):                       # rows of cls_matrix align with the rank lists entry by entry
+            sel = pred == c
+            if not sel.any():
+                continue
+            vec[idx[f"cls{c}_n_{br}"]] += int(sel.sum())
+            for k in _TRI_K:
+                vec[idx[f"cls{c}_tri@{k}_{br}"]] += int((t[sel] <= k).sum())
+            for k in _REL_K:
+                vec[idx[f"cls{c}_rel@{k}_{br}"]] += int((r[sel] <= k).sum())
+    return vec
+
+
+def summarize(vec: np.ndarray, n_rel: int = N_REL) -> Dict[str, float]:
+    """Percentages validation() prints, from the (all-reduced) counts."""
+    idx = {k: i for i, k in enumerate(fields(n_rel))}
+    out = {"scenes": float(vec[idx["scenes"]])}
+    for br in ("3d", "2d"):
+        for name, ks in (("obj", _OBJ_K), ("rel", _REL_K), ("tri", _TRI_K)):
+            n = max(vec[idx[f"{name}_n_{br}"]], 1)
+            for k in ks:
+                out[f"{name}_acc@{k}_{br}"] = float(vec[idx[f"{name}_hit@{k}_{br}"]] * 100 / n)
+        present = [c for c in range(n_rel) if vec[idx[f"cls{c}_n_{br}"]] > 0]
+        for k in _TRI_K:                             # classes c < cls_matrix.max() (reference quirk, kept)
+            rec = [vec[idx[f"cls{c}_tri@{k}_{br}"]] * 100 / vec[idx[f"cls{c}_n_{br}"]] for c in present
+                   if vec[idx[f"cm_ge{c + 1}"]] > 0]
+            out[f"mean_recall@{k}_{br}"] = float(np.mean(np.array(rec, dtype=np.float32))) if rec else 0.0
+        for k in _REL_K:                             # compute_mean_predicate: all 26 classes with samples
+            acc = [vec[idx[f"cls{c}_rel@{k}_{br}"]] / vec[idx[f"cls{c}_n_{br}"]] for c in present]
+            out[f"mean_rel_acc@{k}_{br}"] = float(np.mean(acc) * 100) if acc else 0.0
+    return out
+
+
+@torch.no_grad()
+def validation(model, batches: Iterable[dict], device=None) -> Dict[str, float]:
+    """``batches`` yields this rank's dicts with the reference loader's item names
+    (obj_points [N,3,P], obj_2d_feats, gt_class, gt_rel_cls, edge_indices [E,2], descriptor, batch_ids).
+    One collective at the very end."""
+    from . import metrics as M
+    vec = np.zeros(len(fields()), dtype=np.float64)
+    for b in batches:
+        out = M.process_val(model, b["obj_points"], b["obj_2d_feats"], b["gt_class"], b["descriptor"], b["gt_rel_cls"],
+                            b["edge_indices"], b["batch_ids"], use_triplet=True)
+        ranks = dict(top_k_obj=out[0], top_k_obj_2d=out[1], top_k_rel=out[2], top_k_rel_2d=out[3],
+                     top_k_triplet=out[4], top_k_triplet_2d=out[5])
+        n_scenes = int(b["batch_ids"].max().item()) + 1 if b["batch_ids"].numel() else 0
+        accumulate(vec, ranks, out[6], n_scenes)
+    t = torch.from_numpy(vec)
+    if device is not None:
+        t = t.to(device)
+    t = vdist.allreduce_metrics(t)
+    return summarize(t.cpu().numpy())

@@ -100,3 +100,41 @@ def test_process_val_tuple_matches_oracle_pipeline():
     tri, cm = MO.triplet_topk(ref[0], ref[2], gt_cls, gt_rel, edges, 101, obj3)
     assert (out[4] == tri).mean() >= 0.97 and np.array_equal(out[6], cm)     # logits differ by ~4e-6: near-ties may flip
     assert out[7].shape == (int(gt_rel.sum()), 160) and out[9].shape == (int(gt_rel.sum()), 26)
+
+
+def test_sharded_validation_loop_single_rank():
+    """evaluate.validation (forward + ranking + counts + the final all-reduce, here world=1) against the
+    same pipeline built from the two oracles."""
+    _need_gpu()
+    from vlsat_amd import VLSATConfig, synth, evaluate as EV
+    from vlsat_amd.model import VLSATModel
+    from oracle import vlsat_oracle as O, metrics_oracle as MO
+    cfg = VLSATConfig(N_LAYERS=1)
+    w = synth.make_weights(cfg)
+    model = VLSATModel(cfg, DEV).load_state(w).eval()
+    g = torch.Generator().manual_seed(3)
+    batches, vec = [], np.zeros(len(EV.fields()))
+    for s in range(3):
+        b = synth.collate([synth.make_scene(5 + s, 32, 9000 + 2 * s), synth.make_scene(4, 32, 9001 + 2 * s)])
+        n, e = b["obj_points"].shape[0], b["edge_indices"].shape[1]
+        gt_cls = torch.randint(0, 160, (n,), generator=g)
+        gt_rel = (torch.rand(e, 26, generator=g) < 0.08).long()
+        edges = torch.from_numpy(b["edge_indices"]).t().contiguous()
+        item = {k: torch.from_numpy(v).to(DEV) for k, v in b.items() if k != "edge_indices"}
+        item.update(gt_class=gt_cls.to(DEV), gt_rel_cls=gt_rel.to(DEV), edge_indices=edges.to(DEV))
+        batches.append(item)
+        c = {k: torch.from_numpy(v) for k, v in b.items()}
+        ref = O.forward(O.to_torch(w), cfg, c["obj_points"], c["obj_2d_feats"], c["edge_indices"], c["descriptor"], c["batch_ids"])
+        o3, o2 = MO.topk_object(ref[0], gt_cls, 11), MO.topk_object(ref[1], gt_cls, 11)
+        t3, cm = MO.triplet_topk(ref[0], ref[2], gt_cls, gt_rel, edges, 101, o3)
+        t2, _ = MO.triplet_topk(ref[1], ref[3], gt_cls, gt_rel, edges, 101, o3)
+        EV.accumulate(vec, dict(top_k_obj=o3, top_k_obj_2d=o2, top_k_rel=MO.topk_predicate(ref[2], gt_rel, 6),
+                                top_k_rel_2d=MO.topk_predicate(ref[3], gt_rel, 6), top_k_triplet=t3, top_k_triplet_2d=t2),
+                      cm, 2)
+    got = EV.validation(model, batches, device=DEV)
+    want = EV.summarize(vec)
+    assert got["scenes"] == 6
+    for k in want:
+        assert abs(got[k] - want[k]) <= 2.0, (k, got[k], want[k])      # percentages; near-tie flips move single counts
+    exact = [k for k in want if k.startswith(("obj_acc", "rel_acc"))]
+    assert all(got[k] == want[k] for k in exact)
