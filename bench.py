@@ -85,6 +85,8 @@ def main():
     ap.add_argument("--layers", type=int, default=3)
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--gemm-precision", default="fp32", choices=["fp32", "bf16x3", "bf16"],
+                    help="fp32 = BASELINE configs[1] (default, the headline); bf16x3 = configs[2] (split-bf16 MFMA GEMMs)")
     args = ap.parse_args()
 
     rank, local, world = vdist.init()
@@ -102,6 +104,7 @@ def main():
 
     cfg = VLSATConfig(N_LAYERS=args.layers)
     model = VLSATModel(cfg, str(dev)).load_state(synth.make_weights(cfg)).eval()
+    model.set_gemm_precision(args.gemm_precision)
     # this rank's shard of the global scene list (weak scaling: args.scenes per GPU)
     scenes = vdist.shard(args.scenes * world, rank, world)
     batch = synth.collate([synth.make_scene(args.objects, args.points, 1000 + s) for s in scenes])
@@ -145,7 +148,7 @@ def main():
         avg_ms = c["ms"] / max(c["launches"], 1)
         achieved = c["flops"] / (c["ms"] * 1e-3) / 1e12 if c["ms"] > 0 else 0.0
         traffic, traffic_src = None, None
-        default_wl = (args.scenes, args.objects, args.points, args.layers) == (64, 40, 256, 3)
+        default_wl = (args.scenes, args.objects, args.points, args.layers, args.gemm_precision) == (64, 40, 256, 3, "fp32")
         pmc = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_bench_pmc.json")) \
             if os.path.isdir(os.path.join(ROOT, "profiles")) else []
         if default_wl and pmc:
@@ -179,8 +182,11 @@ def main():
     line = {
         "metric": "scenes/sec (3RScan-shaped, N=40 obj x 256 pts)", "value": round(value, 2), "unit": "scenes/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{'BASELINE configs[1]' if (args.scenes, args.objects, args.points, args.layers) == (64, 40, 256, 3) else 'custom'}: batch of {args.scenes} synthetic scenes per GPU, "
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": {"fp32": "f32", "bf16x3": "bf16x3 GEMM operands (split-bf16 MFMA, f32 accumulate); attention/LN f32",
+                  "bf16": "bf16 GEMM operands (f32 accumulate); attention/LN f32"}[args.gemm_precision],
+        "data": "synthetic",
+        "config": {"workload": f"{('BASELINE configs[1]' if args.gemm_precision == 'fp32' else 'BASELINE configs[2]') if (args.scenes, args.objects, args.points, args.layers) == (64, 40, 256, 3) else 'custom'}: batch of {args.scenes} synthetic scenes per GPU, "
                                f"{args.objects} objects x {args.points} pts, fully-connected edges "
                                f"(E={e_scene}/scene), {args.layers} GNN layers, fp32",
                    "scenes_per_gpu": args.scenes, "parallelism": f"scene-sharded x{world}"},

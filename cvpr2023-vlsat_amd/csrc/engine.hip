@@ -77,6 +77,9 @@ struct vlsat_ctx {
     int64_t acc_n[PC_COUNT] = {0};
     double acc_fl[PC_COUNT] = {0};
     int debug_stop = -1;
+    // GEMM operand precision: 0 exact fp32 MFMA, 1 bf16, 3 split-bf16 (vlsat_set_gemm_precision)
+    int prec = 0;
+    std::map<const float*, std::pair<uint16_t*, uint16_t*>> split;
     // workspace arenas of destroyed plans, re-used by the next plan that fits (an eval loop
     // builds one plan per scene; hipMalloc/hipFree per scene would dominate small scenes)
     std::vector<std::pair<char*, size_t>> arena_pool;
@@ -254,7 +257,24 @@ struct Scope {
     }
 };
 
-int gemm(vlsat_ctx* h, hipStream_t s, const GemmArgs& a) {
+int gemm(vlsat_ctx* h, hipStream_t s, const GemmArgs& a0) {
+    GemmArgs a = a0;
+    if (h->prec) {
+        // split-bf16 GEMM path: weights are split into bf16 hi/lo parts once, on first use
+        // (i.e. during warm-up), keyed by the fp32 weight pointer
+        auto it = h->split.find(a.W);
+        if (it == h->split.end()) {
+            const size_t n = (size_t)a.N * a.K;
+            uint16_t *hi = nullptr, *lo = nullptr;
+            VLSAT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&hi), n * 2 + 16));
+            VLSAT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&lo), n * 2 + 16));
+            if (int r = launch_split_bf16(a.W, n, hi, lo, s)) return r;
+            it = h->split.emplace(a.W, std::make_pair(hi, lo)).first;
+        }
+        a.prec = h->prec;
+        a.Whi = it->second.first;
+        a.Wlo = it->second.second;
+    }
     Scope sc(h, s, PC_GEMM, gemm_flops(a));
     return launch_gemm(a, s);
 }
@@ -373,6 +393,7 @@ void vlsat_destroy(vlsat_handle h) {
     if (!h) return;
     for (float* p : h->dev_allocs) hipFree(p);
     for (auto& a : h->arena_pool) hipFree(a.first);
+    for (auto& kv : h->split) { hipFree(kv.second.first); hipFree(kv.second.second); }
     for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
     delete h;
 }
@@ -758,6 +779,13 @@ int vlsat_forward(vlsat_handle h, vlsat_plan p, const float* pts, const float* f
 }
 
 // -------------------------------------------------------------------------------------------
+int vlsat_set_gemm_precision(vlsat_handle h, int32_t mode) {
+    if (!h) return fail(VLSAT_EINVAL, "null handle");
+    if (mode != 0 && mode != 1 && mode != 3) return fail(VLSAT_EINVAL, "gemm precision must be 0 (fp32), 1 (bf16) or 3 (bf16x3)");
+    h->prec = mode;
+    return 0;
+}
+
 int vlsat_profile_enable(vlsat_handle h, int32_t enable) {
     if (!h) return fail(VLSAT_EINVAL, "null handle");
     h->prof = enable != 0;

@@ -103,4 +103,117 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[TM][TN]) {
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Operand pipelines of the persistent GEMM (gemm_f32.hip): how a [BM|BN][32] k-slice travels
+// HBM -> registers -> LDS -> MFMA fragments.  PipeF32 is the exact-fp32 path above.
+struct GemmArgs;
+
+template <int BM, int BN>
+struct PipeF32 {
+    static constexpr int TM = BM / 64, TN = BN / 64;
+    static constexpr int STAGE_BYTES = (BM + BN) * LDT * 4;
+    struct Regs { f32x4 a[BM / 32], b[BN / 32]; };
+    template <class Args>
+    static __device__ __forceinline__ void load(const Args& p, int m0, int n0, int k0, Regs& r, int tid) {
+        stage_load<BM>(p.A, p.lda, m0, p.M - 1, k0, r.a, tid);
+        stage_load<BN>(p.W, p.ldw, n0, p.N - 1, k0, r.b, tid);
+    }
+    static __device__ __forceinline__ void store(char* stage, Regs& r, int tid, int relu_a) {
+        float* s = reinterpret_cast<float*>(stage);
+        if (relu_a) stage_relu<BM>(r.a);
+        stage_store<BM>(s, r.a, tid);
+        stage_store<BN>(s + BM * LDT, r.b, tid);
+    }
+    static __device__ __forceinline__ void mma(const char* stage, int wm, int wn, f32x16 (&acc)[TM][TN], int lane) {
+        const float* s = reinterpret_cast<const float*>(stage);
+        mma_slice<TM, TN>(s + (wm * TM * 32) * LDT, s + BM * LDT + (wn * TN * 32) * LDT, acc, lane);
+    }
+};
+
+// Split-bf16 path (BASELINE configs[2], "bf16 MFMA for the GEMMs"): v_mfma_f32_32x32x16_bf16 with
+// fp32 accumulate.  TERMS = 1: operands rounded to bf16 (one MFMA per k-step; 2^-9 relative
+// input error -> ~2e-2 on the x14.29 object logits, misses the 1e-2 tolerance).
+// TERMS = 3: a = a_hi + a_lo, w = w_hi + w_lo with both parts bf16;
+//   a.w ~= a_hi.w_hi + a_lo.w_hi + a_hi.w_lo   (dropped a_lo.w_lo ~ 2^-16 relative),
+// three MFMAs at 16x the fp32-MFMA rate = 5.3x the fp32 matrix throughput at ~1e-5 error.
+// A stays fp32 in HBM and is split while staging; weights are pre-split once (Whi/Wlo, [N,K] bf16).
+// LDS: bf16 planes [rows][32] with an 80-byte row pitch (conflict-free ds_read_b128 of 8 k).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+template <int BM, int BN, int TERMS>
+struct PipeBF16 {
+    static constexpr int TM = BM / 64, TN = BN / 64;
+    static constexpr int PH = 40;                                  // row pitch in bf16 elements (80 B)
+    static constexpr int PL = TERMS == 1 ? 1 : 2;                  // planes: hi (, lo)
+    static constexpr int A_PLANE = BM * PH * 2, W_PLANE = BN * PH * 2;       // bytes
+    static constexpr int STAGE_BYTES = (A_PLANE + W_PLANE) * PL;
+    struct Regs { f32x4 a[BM / 32]; uint4 w[PL][BN / 64]; };
+    template <class Args>
+    static __device__ __forceinline__ void load(const Args& p, int m0, int n0, int k0, Regs& r, int tid) {
+        stage_load<BM>(p.A, p.lda, m0, p.M - 1, k0, r.a, tid);
+#pragma unroll
+        for (int pl = 0; pl < PL; ++pl) {
+            const uint16_t* w = pl ? p.Wlo : p.Whi;
+#pragma unroll
+            for (int i = 0; i < BN / 64; ++i) {
+                const int idx = tid + 256 * i;
+                int row = n0 + (idx >> 2);
+                row = row < p.N ? row : p.N - 1;
+                r.w[pl][i] = *reinterpret_cast<const uint4*>(w + (size_t)row * p.ldw + k0 + (idx & 3) * 8);
+            }
+        }
+    }
+    static __device__ __forceinline__ void store(char* stage, Regs& r, int tid, int relu_a) {
+        if (relu_a) stage_relu<BM>(r.a);
+#pragma unroll
+        for (int i = 0; i < BM / 32; ++i) {
+            const int idx = tid + 256 * i;
+            const int off = ((idx >> 3) * PH + (idx & 7) * 4) * 2;
+            const bf16x4 h = __builtin_convertvector(r.a[i], bf16x4);
+            *reinterpret_cast<bf16x4*>(stage + off) = h;
+            if (PL == 2) {
+                const f32x4 rest = r.a[i] - __builtin_convertvector(h, f32x4);
+                *reinterpret_cast<bf16x4*>(stage + A_PLANE + off) = __builtin_convertvector(rest, bf16x4);
+            }
+        }
+#pragma unroll
+        for (int pl = 0; pl < PL; ++pl)
+#pragma unroll
+            for (int i = 0; i < BN / 64; ++i) {
+                const int idx = tid + 256 * i;
+                *reinterpret_cast<uint4*>(stage + A_PLANE * PL + W_PLANE * pl + ((idx >> 2) * PH + (idx & 3) * 8) * 2) = r.w[pl][i];
+            }
+    }
+    static __device__ __forceinline__ void mma(const char* stage, int wm, int wn, f32x16 (&acc)[TM][TN], int lane) {
+        const int li = lane & 31, hi = lane >> 5;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a[PL][TM], w[PL][TN];
+#pragma unroll
+            for (int pl = 0; pl < PL; ++pl) {
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+                    a[pl][tm] = *reinterpret_cast<const bf16x8*>(stage + A_PLANE * pl + (((wm * TM + tm) * 32 + li) * PH + ks * 16 + hi * 8) * 2);
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    w[pl][tn] = *reinterpret_cast<const bf16x8*>(stage + A_PLANE * PL + W_PLANE * pl + (((wn * TN + tn) * 32 + li) * PH + ks * 16 + hi * 8) * 2);
+            }
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    if (PL == 2) {                          // small terms first
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][tm], w[0][tn], acc[tm][tn], 0, 0, 0);
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][tm], w[PL - 1][tn], acc[tm][tn], 0, 0, 0);
+                    }
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][tm], w[0][tn], acc[tm][tn], 0, 0, 0);
+                }
+        }
+    }
+};
+
+template <int BM, int BN, int PREC> struct PipeSel { using type = PipeBF16<BM, BN, PREC>; };
+template <int BM, int BN> struct PipeSel<BM, BN, 0> { using type = PipeF32<BM, BN>; };
+
 }  // namespace vlsat

@@ -37,11 +37,13 @@ namespace vlsat {
 
 // ADD (compile time, so the 64 accumulator-init loads per lane are branch-free and batched):
 //   bit 0 = residual, bit 1 = gathered rows g0, bit 2 = gathered rows g1.
-template <int BM, int BN, int ADD>
+// PREC: 0 = exact fp32 (PipeF32), 1 / 3 = bf16 / split-bf16 operands (PipeBF16, gemm_core.h).
+template <int BM, int BN, int ADD, int PREC>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int n_tiles, int nbn) {
     constexpr int TM = BM / 64, TN = BN / 64;
-    constexpr int STAGE = (BM + BN) * LDT;
-    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+    using Pipe = typename PipeSel<BM, BN, PREC>::type;
+    constexpr int STAGE = Pipe::STAGE_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -55,13 +57,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int n_tile
 
     f32x16 acc[TM][TN];
     zero_acc<TM, TN>(acc);
-    f32x4 ra[BM / 32], rb[BN / 32];
+    typename Pipe::Regs regs;
 
-    stage_load<BM>(p.A, p.lda, m0, p.M - 1, 0, ra, tid);
-    stage_load<BN>(p.W, p.ldw, n0, p.N - 1, 0, rb, tid);
-    if (p.relu_a) stage_relu<BM>(ra);
-    stage_store<BM>(smem, ra, tid);
-    stage_store<BN>(smem + BM * LDT, rb, tid);
+    Pipe::load(p, m0, n0, 0, regs, tid);
+    Pipe::store(smem, regs, tid, p.relu_a);
     __syncthreads();
 
     int buf = 0;
@@ -70,14 +69,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int n_tile
         const bool next_tile = nv < n_tiles;
         const int nm0 = (nv / nbn) * BM, nn0 = (nv % nbn) * BN;
         for (int kt = 0; kt < KT; ++kt) {
-            float* cur = smem + buf * STAGE;
-            float* nxt = smem + (buf ^ 1) * STAGE;
+            char* cur = smem + buf * STAGE;
+            char* nxt = smem + (buf ^ 1) * STAGE;
             const bool last = kt == KT - 1;
             const bool more = !last || next_tile;
             if (more) {
                 const int lm0 = last ? nm0 : m0, ln0 = last ? nn0 : n0, lk = last ? 0 : (kt + 1) * BK;
-                stage_load<BM>(p.A, p.lda, lm0, p.M - 1, lk, ra, tid);
-                stage_load<BN>(p.W, p.ldw, ln0, p.N - 1, lk, rb, tid);
+                Pipe::load(p, lm0, ln0, lk, regs, tid);
             }
             if (ADD != 0 && kt == 0) {
                 // additive epilogue operands (residual / gathered rows) are loaded straight into
@@ -108,12 +106,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int n_tile
                         }
                 }
             }
-            mma_slice<TM, TN>(cur + (wm * TM * 32) * LDT, cur + BM * LDT + (wn * TN * 32) * LDT, acc, lane);
-            if (more) {
-                if (p.relu_a) stage_relu<BM>(ra);
-                stage_store<BM>(nxt, ra, tid);
-                stage_store<BN>(nxt + BM * LDT, rb, tid);
-            }
+            Pipe::mma(cur, wm, wn, acc, lane);
+            if (more) Pipe::store(nxt, regs, tid, p.relu_a);
             __syncthreads();
             if (last) {
                 // ---- epilogue: lane holds column n, 16 rows per 32x32 tile ----
@@ -215,11 +209,14 @@ template <int BM, int BN>
 static int launch_t(const GemmArgs& a, int n_tiles, int grid, hipStream_t s) {
     const int nbn = (a.N + BN - 1) / BN;
     const int add = (a.resid ? 1 : 0) | (a.g0 ? 2 : 0) | (a.g1 ? 4 : 0);
-#define VLSAT_GEMM_CASE(ADD) \
-    case ADD: hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, ADD>), dim3(grid), dim3(256), 0, s, a, n_tiles, nbn); break;
-    switch (add) {
-        VLSAT_GEMM_CASE(0) VLSAT_GEMM_CASE(1) VLSAT_GEMM_CASE(2) VLSAT_GEMM_CASE(3)
-        VLSAT_GEMM_CASE(4) VLSAT_GEMM_CASE(5) VLSAT_GEMM_CASE(6) VLSAT_GEMM_CASE(7)
+#define VLSAT_GEMM_CASE(ADD, PREC) \
+    case (PREC) * 8 + (ADD): hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, ADD, PREC>), dim3(grid), dim3(256), 0, s, a, n_tiles, nbn); break;
+    switch (a.prec * 8 + add) {
+        VLSAT_GEMM_CASE(0, 0) VLSAT_GEMM_CASE(1, 0) VLSAT_GEMM_CASE(2, 0) VLSAT_GEMM_CASE(3, 0)
+        VLSAT_GEMM_CASE(4, 0) VLSAT_GEMM_CASE(5, 0) VLSAT_GEMM_CASE(6, 0) VLSAT_GEMM_CASE(7, 0)
+        VLSAT_GEMM_CASE(0, 1) VLSAT_GEMM_CASE(1, 1) VLSAT_GEMM_CASE(6, 1)
+        VLSAT_GEMM_CASE(0, 3) VLSAT_GEMM_CASE(1, 3) VLSAT_GEMM_CASE(6, 3)
+        default: return fail(-1, "gemm: this precision / additive-operand combination is not built");
     }
 #undef VLSAT_GEMM_CASE
     VLSAT_LAUNCH_CHECK("gemm_f32");
@@ -264,6 +261,8 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0) return 0;
     if (a.K <= 0 || a.K % BK) return fail(-1, "gemm: K must be a positive multiple of 32");
     if ((a.lda & 3) || (a.ldw & 3)) return fail(-1, "gemm: lda/ldw must be multiples of 4 floats");
+    if (a.prec != 0 && a.prec != 1 && a.prec != 3) return fail(-1, "gemm: prec must be 0 (fp32), 1 (bf16) or 3 (bf16x3)");
+    if (a.prec && (!a.Whi || (a.prec == 3 && !a.Wlo) || (a.ldw & 7))) return fail(-1, "gemm: bf16 path needs pre-split weights and ldw % 8 == 0");
     if (a.rowscale && (a.resid || a.g0 || a.g1))
         return fail(-1, "gemm: rowscale cannot be combined with resid/g0/g1 (additive operands are accumulator inits)");
     if ((reinterpret_cast<uintptr_t>(a.A) & 15) || (reinterpret_cast<uintptr_t>(a.W) & 15))

@@ -21,6 +21,10 @@ struct GemmArgs {
     const float* g1 = nullptr; const int32_t* gi1 = nullptr; int ldg1 = 0;
     int relu_a = 0;                             // apply ReLU to A while staging
     int act = ACT_NONE;
+    // split-bf16 path: prec 0 = exact fp32 MFMA, 1 = bf16, 3 = bf16x3; weights pre-split [N,K] bf16 (ldw shared)
+    int prec = 0;
+    const uint16_t* Whi = nullptr;
+    const uint16_t* Wlo = nullptr;
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
 double gemm_flops(const GemmArgs& a);
@@ -83,6 +87,9 @@ int launch_edge_gate(const GateArgs& a, hipStream_t s);
 // out[n, col0 + c] = reduce_{k in rowptr[n]..rowptr[n+1]} gated[order[k], c]; empty -> 0
 int launch_aggregate(const float* gated, int n_ch, const int32_t* rowptr, const int32_t* order,
                      int n_nodes, int aggr, float* out, int ldo, int col0, hipStream_t s);
+
+// w[i] -> bf16 hi[i] + bf16 lo[i] (split-bf16 GEMM weights, one-time)
+int launch_split_bf16(const float* w, size_t n, uint16_t* hi, uint16_t* lo, hipStream_t s);
 
 // ---- eval ranking step: softmax + top-k ranks by counting ----
 int launch_softmax_rows(const float* x, int ld, int rows, int cols, float* out, hipStream_t s);

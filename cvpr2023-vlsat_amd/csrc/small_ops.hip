@@ -328,3 +328,25 @@ int launch_node_attn(const float* Q, int ldq, const float* K, int ldk, const flo
 }
 
 }  // namespace vlsat
+
+// ------------------------------------------------------------------------------------------
+// One-time weight preparation of the split-bf16 GEMM path: w = hi + lo with both parts bf16
+// (round-to-nearest-even), stored as raw 16-bit patterns.
+namespace vlsat {
+__global__ void split_bf16_kernel(const float* __restrict__ w, size_t n, uint16_t* __restrict__ hi,
+                                  uint16_t* __restrict__ lo) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = w[i];
+    const __bf16 h = (__bf16)x;
+    const __bf16 l = (__bf16)(x - (float)h);
+    hi[i] = __builtin_bit_cast(uint16_t, h);
+    lo[i] = __builtin_bit_cast(uint16_t, l);
+}
+int launch_split_bf16(const float* w, size_t n, uint16_t* hi, uint16_t* lo, hipStream_t s) {
+    if (!n) return 0;
+    hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, n, hi, lo);
+    VLSAT_LAUNCH_CHECK("split_bf16");
+    return 0;
+}
+}  // namespace vlsat

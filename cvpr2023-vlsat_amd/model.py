@@ -56,6 +56,19 @@ class VLSATModel:
         self._zero_bid = {}
         self._plans: "OrderedDict[tuple, _Plan]" = OrderedDict()
         self.training = False
+        self.gemm_precision = "fp32"
+
+    PRECISIONS = {"fp32": 0, "bf16": 1, "bf16x3": 3}
+
+    def set_gemm_precision(self, mode: str):
+        """'fp32' (default, exact-fp32 MFMA: BASELINE configs[1]) | 'bf16x3' (split-bf16 MFMA GEMMs, fp32
+        accumulate, ~1e-5 error: BASELINE configs[2]) | 'bf16' (single bf16 rounding; ~2e-2 on the object
+        logits, outside the 1e-2 tolerance -- kept for comparison).  Attention/softmax/LN stay fp32."""
+        if mode not in self.PRECISIONS:
+            raise L.VlsatError(f"gemm precision must be one of {sorted(self.PRECISIONS)}")
+        L.check(self._lib.vlsat_set_gemm_precision(self._h, self.PRECISIONS[mode]))
+        self.gemm_precision = mode
+        return self
 
     # ---- nn.Module-like surface --------------------------------------------------------------
     def eval(self):

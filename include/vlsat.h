@@ -94,6 +94,13 @@ int vlsat_forward(vlsat_handle h, vlsat_plan p,
                   float* obj_logits_3d, float* obj_logits_2d, float* rel_cls_3d, float* rel_cls_2d,
                   void* stream);
 
+/* Operand precision of the GEMM kernel inside vlsat_forward (BASELINE configs[2], "bf16 MFMA for the
+ * QKV/FFN GEMMs"): 0 = exact fp32 MFMA (default; BASELINE configs[1]), 1 = bf16 operands, 3 = split-bf16
+ * (a_hi.w_hi + a_lo.w_hi + a_hi.w_lo, fp32 accumulate).  Activations, attention, softmax, LayerNorm and
+ * the point encoder stay fp32 in every mode.  May be changed between forwards; weights are split to
+ * bf16 on the device at first use. */
+int vlsat_set_gemm_precision(vlsat_handle h, int32_t mode);
+
 /* Per-kernel timing of the forward with HIP events on `stream` (bench.py roofline leg).
  * enable=1: every launch of every kernel class is bracketed by hipEventRecord on the launch
  * stream; vlsat_profile_read synchronises, accumulates and returns per-class totals since

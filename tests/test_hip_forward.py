@@ -258,3 +258,37 @@ def test_errors_are_loud():
     w.pop("mmg.gcn_2ds.1.prop.2.bias")
     with pytest.raises(L.VlsatError):
         fresh.load_state(w)
+
+
+def test_cfg3_split_bf16_gemms(golden_dir):
+    """BASELINE configs[2]: bf16 MFMA for the GEMMs, tolerance 1e-2.  The split-bf16 mode (3 MFMAs per
+    product, fp32 accumulate) must meet it with a wide margin; the single-rounding bf16 mode is only
+    required to be sane (it sits at ~2e-2 on the x14.29 object logits)."""
+    from vlsat_amd.model import VLSATModel
+    cfg = VLSATConfig(N_LAYERS=3)
+    z = np.load(os.path.join(golden_dir, "cfg2_n40_p256_l3.npz"))
+    b = synth.make_batch(1, 40, 256, seed0=1000)
+    d = _dev(b)
+    m = VLSATModel(cfg, DEV).load_state(synth.make_weights(cfg)).eval()
+    try:
+        m.set_gemm_precision("bf16x3")
+        got = [o.cpu() for o in m(d["obj_points"], d["obj_2d_feats"], d["edge_indices"], d["descriptor"], d["batch_ids"])]
+        errs = _check(got, [z[n] for n in NAMES], 1e-2, "cfg3 bf16x3 vs reference golden")
+        assert max(errs.values()) < 1e-3, errs                  # in practice fp32-tolerance too
+        m.set_gemm_precision("bf16")
+        got1 = [o.cpu() for o in m(d["obj_points"], d["obj_2d_feats"], d["edge_indices"], d["descriptor"], d["batch_ids"])]
+        _check(got1, [z[n] for n in NAMES], 1e-1, "single-rounding bf16 vs reference golden (informational)")
+        m.set_gemm_precision("fp32")
+        got0 = [o.cpu() for o in m(d["obj_points"], d["obj_2d_feats"], d["edge_indices"], d["descriptor"], d["batch_ids"])]
+        _check(got0, [z[n] for n in NAMES], 3e-4, "back to fp32")
+    finally:
+        m.close()
+    # ragged batch + general edges through the bf16x3 GEMM tails
+    cfg2 = VLSATConfig(N_LAYERS=2)
+    bb = synth.collate([synth.make_scene(5, 64, 2000), synth.make_scene(7, 64, 2001)])
+    m2 = VLSATModel(cfg2, DEV).load_state(synth.make_weights(cfg2)).eval().set_gemm_precision("bf16x3")
+    dd = _dev(bb)
+    got2 = [o.cpu() for o in m2(dd["obj_points"], dd["obj_2d_feats"], dd["edge_indices"], dd["descriptor"], dd["batch_ids"])]
+    zz = np.load(os.path.join(golden_dir, "ragged_n5_n7_p64_l2.npz"))
+    _check(got2, [zz[n] for n in NAMES], 1e-3, "ragged batch bf16x3")
+    m2.close()
