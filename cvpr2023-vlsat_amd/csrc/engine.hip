@@ -69,7 +69,7 @@ struct vlsat_ctx {
     float *obj3_w, *obj3_b, *obj2_w, *obj2_b;
     // profiling
     bool prof = false;
-    struct Rec { int cls; hipEvent_t a, b; double flops; };
+    struct Rec { int cls; hipEvent_t a, b; double flops; long kernels; };
     std::vector<Rec> recs;
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
@@ -242,7 +242,9 @@ struct Scope {
     int cls;
     double flops;
     hipEvent_t a{};
+    long k0 = 0;
     Scope(vlsat_ctx* h_, hipStream_t s_, int cls_, double fl) : h(h_), s(s_), cls(cls_), flops(fl) {
+        k0 = gemm_kernel_launches();
         if (h->prof) {
             a = next_event(h);
             hipEventRecord(a, s);
@@ -252,7 +254,7 @@ struct Scope {
         if (h->prof) {
             hipEvent_t b = next_event(h);
             hipEventRecord(b, s);
-            h->recs.push_back({cls, a, b, flops});
+            h->recs.push_back({cls, a, b, flops, cls == PC_GEMM ? gemm_kernel_launches() - k0 : 1});
         }
     }
 };
@@ -801,7 +803,7 @@ static int profile_drain(vlsat_handle h) {
         float ms = 0.f;
         VLSAT_HIP_CHECK(hipEventElapsedTime(&ms, r.a, r.b));
         h->acc_ms[r.cls] += ms;
-        h->acc_n[r.cls] += 1;
+        h->acc_n[r.cls] += r.kernels;
         h->acc_fl[r.cls] += r.flops;
     }
     h->recs.clear();

@@ -190,6 +190,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int n_tile
 
 double gemm_flops(const GemmArgs& a) { return 2.0 * a.M * (double)a.N * a.K; }
 
+static long g_kernel_launches = 0;          // a logical GEMM is a main launch plus (usually) a small-tile tail launch
+long gemm_kernel_launches() { return g_kernel_launches; }
+
 static int g_slots = 0;      // resident 256-thread blocks the persistent grid may use (2 per CU)
 static int slots() {
     if (!g_slots) {
@@ -219,6 +222,7 @@ static int launch_t(const GemmArgs& a, int n_tiles, int grid, hipStream_t s) {
         default: return fail(-1, "gemm: this precision / additive-operand combination is not built");
     }
 #undef VLSAT_GEMM_CASE
+    ++g_kernel_launches;
     VLSAT_LAUNCH_CHECK("gemm_f32");
     return 0;
 }

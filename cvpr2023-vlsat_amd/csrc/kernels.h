@@ -28,6 +28,7 @@ struct GemmArgs {
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
 double gemm_flops(const GemmArgs& a);
+long gemm_kernel_launches();   // kernels launched so far by launch_gemm (main + tail launches)
 
 // ---- PointNet object encoder (fused conv1..conv3 + ReLU + max over points) ----
 int launch_pointnet(const float* pts, int n_obj, int n_points, const float* w1, const float* b1,
