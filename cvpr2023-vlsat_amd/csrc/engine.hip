@@ -77,6 +77,8 @@ struct vlsat_ctx {
     int64_t acc_n[PC_COUNT] = {0};
     double acc_fl[PC_COUNT] = {0};
     int debug_stop = -1;
+    hipEvent_t last_end{};
+    bool last_end_ok = false;
     // GEMM operand precision: 0 exact fp32 MFMA, 1 bf16, 3 split-bf16 (vlsat_set_gemm_precision)
     int prec = 0;
     std::map<const float*, std::pair<uint16_t*, uint16_t*>> split;
@@ -246,8 +248,13 @@ struct Scope {
     Scope(vlsat_ctx* h_, hipStream_t s_, int cls_, double fl) : h(h_), s(s_), cls(cls_), flops(fl) {
         k0 = gemm_kernel_launches();
         if (h->prof) {
-            a = next_event(h);
-            hipEventRecord(a, s);
+            // consecutive launches of one forward share a boundary event (end of the previous
+            // scope = start of this one): one event per launch instead of two
+            if (h->last_end_ok) a = h->last_end;
+            else {
+                a = next_event(h);
+                hipEventRecord(a, s);
+            }
         }
     }
     ~Scope() {
@@ -255,6 +262,8 @@ struct Scope {
             hipEvent_t b = next_event(h);
             hipEventRecord(b, s);
             h->recs.push_back({cls, a, b, flops, cls == PC_GEMM ? gemm_kernel_launches() - k0 : 1});
+            h->last_end = b;
+            h->last_end_ok = true;
         }
     }
 };
@@ -702,6 +711,7 @@ int vlsat_forward(vlsat_handle h, vlsat_plan p, const float* pts, const float* f
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int N = (int)p->N, E = (int)p->E, D = h->D, L = h->d.n_layers, LDX = 768;
     const int stop = h->debug_stop;
+    h->last_end_ok = false;                // other work may have been enqueued on the stream since the last forward
 #define STAGE(id) do { if (stop == (id)) return 0; } while (0)
 
     {   // a-2 object encoder
@@ -856,6 +866,19 @@ int vlsat_k_flash_attn(const float* Q, const float* K, const float* V, float* O,
     hipStreamSynchronize(st);     // test entry point only: the tile table is freed right away
     hipFree(d);
     return r;
+}
+
+int vlsat_prepare_objects(const float* scene_points, const int32_t* choice, int32_t n_obj, int32_t n_points,
+                          float* obj_points, float* descriptor, void* stream) {
+    if (!scene_points || !choice || !obj_points || !descriptor) return fail(VLSAT_EINVAL, "prepare_objects: null argument");
+    return launch_prepare_objects(scene_points, choice, n_obj, n_points, obj_points, descriptor, static_cast<hipStream_t>(stream));
+}
+
+int vlsat_fc_edges(const int32_t* node_ptr, const int64_t* edge_ptr, int32_t n_scenes, int64_t n_nodes, int64_t n_edges,
+                   int64_t* edges, int64_t* batch_ids, void* stream) {
+    if (!node_ptr || !edge_ptr || !batch_ids || (n_edges > 0 && !edges) || n_scenes <= 0)
+        return fail(VLSAT_EINVAL, "fc_edges: bad argument");
+    return launch_fc_edges(node_ptr, edge_ptr, n_scenes, n_nodes, n_edges, edges, batch_ids, static_cast<hipStream_t>(stream));
 }
 
 int vlsat_k_softmax_rows(const float* x, int32_t ld, int32_t rows, int32_t cols, float* out, void* stream) {

@@ -99,4 +99,10 @@ int launch_eval_ranks(const float* obj_logits, const float* obj_probs, const flo
                       int topk_rel, int topk_tri, float thr, int32_t* obj_rank, int32_t* rel_rank, int32_t* tri_rank,
                       int32_t* cnt, hipStream_t s);
 
+// ---- per-object input preparation ----
+int launch_prepare_objects(const float* scene, const int32_t* choice, int N, int P, float* obj_points, float* desc,
+                           hipStream_t s);
+int launch_fc_edges(const int32_t* node_ptr, const int64_t* edge_ptr, int n_scenes, int64_t n_nodes, int64_t n_edges,
+                    int64_t* edges, int64_t* batch_ids, hipStream_t s);
+
 }  // namespace vlsat

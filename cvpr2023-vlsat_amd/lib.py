@@ -52,6 +52,8 @@ _SIGNATURES = {
     "vlsat_k_pointnet": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
     "vlsat_k_flash_attn": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _f32, _vp]),
     "vlsat_k_layernorm": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
+    "vlsat_prepare_objects": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp]),
+    "vlsat_fc_edges": (C.c_int, [_vp, _vp, _i32, _i64, _i64, _vp, _vp, _vp]),
     "vlsat_k_softmax_rows": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "vlsat_eval_ranks": (C.c_int, [_vp] * 6 + [_i32] * 7 + [_f32] + [_vp] * 4 + [_vp]),
     "vlsat_debug_stop_after": (C.c_int, [_vp, _i32]),

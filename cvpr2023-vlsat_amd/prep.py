@@ -1,0 +1,41 @@
+"""Input preparation on the GPU: host-side mirror of the per-object part of
+``SSGDatasetGraph.data_preparation`` (reference ``src/dataset/dataset_3dssg.py:279-294``), of the
+fully-connected edge list (``:264-266``) and of ``collate_fn_mmg`` (``src/dataset/DataLoader.py:153-176``).
+The random sampling (``np.random.choice``, ``:289``) stays with the caller: ``choice`` is an input."""
+from __future__ import annotations
+
+from typing import Sequence
+
+import torch
+
+from . import lib as L
+
+
+def prepare_objects(scene_points: torch.Tensor, choice: torch.Tensor):
+    """scene_points f32[Npts,3], choice i32[N,P] (device) -> obj_points f32[N,3,P], descriptor f32[N,11]."""
+    lib = L.load()
+    scene_points = scene_points.contiguous()
+    choice = choice.to(torch.int32).contiguous()
+    if scene_points.dim() != 2 or scene_points.shape[1] != 3 or scene_points.dtype != torch.float32:
+        raise L.VlsatError("scene_points must be float32 [Npts,3]")
+    n, p = choice.shape
+    pts = torch.empty(n, 3, p, dtype=torch.float32, device=scene_points.device)
+    desc = torch.empty(n, 11, dtype=torch.float32, device=scene_points.device)
+    L.check(lib.vlsat_prepare_objects(scene_points.data_ptr(), choice.data_ptr(), n, p, pts.data_ptr(), desc.data_ptr(),
+                                      L.stream_ptr()))
+    return pts, desc
+
+
+def fc_edges(n_per_scene: Sequence[int], device) -> tuple:
+    """-> edge_indices i64[2,E] (what Mmgnet.forward takes), batch_ids i64[N,1]."""
+    lib = L.load()
+    n = torch.tensor([0] + list(n_per_scene), dtype=torch.int64)
+    node_ptr = torch.cumsum(n, 0)
+    edge_ptr = torch.cumsum(n * (n - 1), 0)
+    N, E, S = int(node_ptr[-1]), int(edge_ptr[-1]), len(n_per_scene)
+    d_node, d_edge = node_ptr.to(torch.int32).to(device), edge_ptr.to(device)
+    edges = torch.empty(2, E, dtype=torch.int64, device=device)
+    bids = torch.empty(N, 1, dtype=torch.int64, device=device)
+    L.check(lib.vlsat_fc_edges(d_node.data_ptr(), d_edge.data_ptr(), S, N, E, edges.data_ptr(), bids.data_ptr(),
+                               L.stream_ptr()))
+    return edges, bids

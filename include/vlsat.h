@@ -144,6 +144,22 @@ int vlsat_k_flash_attn(const float* Q, const float* K, const float* V, float* O,
 int vlsat_k_layernorm(float* x, int32_t ld, int32_t rows, int32_t dim, const float* gamma,
                       const float* beta, int32_t relu, void* stream);
 
+/* -------- input preparation (the step BEFORE the path: the data loader, reference dataset_3dssg.py:279-294) --- */
+
+/* Per object n: gather P sampled points scene_points[choice[n, :]] ([Npts,3] fp32, choice int32 [N,P]),
+ * descriptor[n] = gen_descriptor of them (reference src/utils/op_utils.py:47-64: centroid, unbiased std,
+ * max-min, volume, max dim), obj_points[n] = the points minus their mean, laid out [N,3,P]
+ * (zero_mean dataset_3dssg.py:189-191 + the permute of src/model/model.py:79).  All device pointers. */
+int vlsat_prepare_objects(const float* scene_points, const int32_t* choice, int32_t n_obj, int32_t n_points,
+                          float* obj_points, float* descriptor, void* stream);
+
+/* Fully-connected directed edges without self loops, source-major, for a batch of scenes with node
+ * offsets applied, and the batch ids (dataset_3dssg.py:264-266 + collate_fn_mmg DataLoader.py:160-172).
+ * node_ptr int32 [S+1] and edge_ptr int64 [S+1] (edge_ptr[s+1]-edge_ptr[s] = n_s(n_s-1)) are device arrays;
+ * edges is [2,E] int64 (the layout Mmgnet.forward takes), batch_ids [N] int64. */
+int vlsat_fc_edges(const int32_t* node_ptr, const int64_t* edge_ptr, int32_t n_scenes, int64_t n_nodes, int64_t n_edges,
+                   int64_t* edges, int64_t* batch_ids, void* stream);
+
 /* -------- eval ranking step (the caller of the path: process_val, reference SGFN_MMG/model.py:463-472) --- */
 
 /* out[r, :] = softmax(x[r, 0:cols]) -- F.softmax(objs_pred) of evaluate_triplet_topk

@@ -1,0 +1,47 @@
+"""CPU ORACLE for the per-object input preparation  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Restates what the reference data loader does per object after sampling:
+  descriptor = gen_descriptor(sampled raw points)            reference src/utils/op_utils.py:47-64
+  points     = zero_mean(sampled points as float32)          reference src/dataset/dataset_3dssg.py:189-191,289-293
+  layout     = permute [N,P,3] -> [N,3,P]                    reference src/model/model.py:79
+  FC edges   = product(range(n), range(n)) minus diagonal    reference src/dataset/dataset_3dssg.py:264-266
+  batching   = node offsets + batch_ids                       reference src/dataset/DataLoader.py:160-172
+Parity status: PINNED for gen_descriptor by tests/test_prep_oracle.py against
+tests/golden/prep_small.npz (reference function called directly); zero_mean / edge list / collate
+are literal restatements (the reference's dataset module needs trimesh and cannot be imported here).
+The random sampling itself (np.random.choice, :289) is an input here (`choice`)."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+
+def gen_descriptor(pts: torch.Tensor) -> torch.Tensor:
+    """[P,3] -> [11]: centroid, unbiased std, dims, volume, max dim (op_utils.py:47-64)."""
+    dims = pts.max(dim=0)[0] - pts.min(dim=0)[0]
+    return torch.cat([pts.mean(0), pts.std(0), dims, (dims[0] * dims[1] * dims[2]).unsqueeze(0), dims.max().unsqueeze(0)], 0)
+
+
+def prepare_objects(scene_points: np.ndarray, choice: np.ndarray, dtype=torch.float32):
+    """scene_points [Npts,3], choice [N,P] (sampled point ids) -> obj_points [N,3,P] f32, descriptor [N,11] f32."""
+    n, p = choice.shape
+    obj = torch.zeros(n, p, 3)
+    desc = torch.zeros(n, 11)
+    for i in range(n):
+        pts = torch.from_numpy(scene_points[choice[i]])
+        desc[i] = gen_descriptor(pts.to(dtype))
+        f = pts.to(torch.float32).clone()
+        f -= f.mean(0).unsqueeze(0)
+        obj[i] = f
+    return obj.permute(0, 2, 1).contiguous(), desc
+
+
+def fc_edges_batch(n_per_scene):
+    """-> edge_indices [E,2] int64 (from, to), batch_ids [N,1] int64, as collate_fn_mmg yields them."""
+    edges, bids, off = [], [], 0
+    for s, n in enumerate(n_per_scene):
+        e = [(i + off, j + off) for i in range(n) for j in range(n) if i != j]
+        edges.append(torch.tensor(e, dtype=torch.long).view(-1, 2))
+        bids.append(torch.full((n, 1), s, dtype=torch.long))
+        off += n
+    return torch.cat(edges, 0), torch.cat(bids, 0)
