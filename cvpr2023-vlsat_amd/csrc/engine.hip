@@ -705,9 +705,14 @@ int vlsat_debug_read(vlsat_plan p, const char* name, float* dst, int64_t dst_ld)
 // -------------------------------------------------------------------------------------------
 int vlsat_forward(vlsat_handle h, vlsat_plan p, const float* pts, const float* f2d, const float* desc,
                   float* obj3d, float* obj2d, float* rel3d, float* rel2d, void* stream) {
-    if (!h || !p || !pts || !f2d || !desc || !obj3d || !obj2d) return fail(VLSAT_EINVAL, "vlsat_forward: null argument");
+    if (!h || !p || !pts || !desc || !obj3d) return fail(VLSAT_EINVAL, "vlsat_forward: null argument");
     if (p->h != h) return fail(VLSAT_EINVAL, "plan belongs to a different handle");
-    if (p->E > 0 && (!rel3d || !rel2d)) return fail(VLSAT_EINVAL, "vlsat_forward: null relation output");
+    // 3D-only mode: both 2D outputs NULL -> the 2D branch (adapter, cross-attention, gcn_2ds, edge
+    // cross-attention, 2D heads) is skipped.  Exact: the 3D branch never reads 2D tensors.
+    const bool do2d = obj2d != nullptr || rel2d != nullptr;
+    if (do2d && (!obj2d || !f2d || (p->E > 0 && !rel2d)))
+        return fail(VLSAT_EINVAL, "vlsat_forward: 2D branch needs obj_2d_feats and both 2D outputs (or neither for 3D-only)");
+    if (p->E > 0 && !rel3d) return fail(VLSAT_EINVAL, "vlsat_forward: null relation output");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int N = (int)p->N, E = (int)p->E, D = h->D, L = h->d.n_layers, LDX = 768;
     const int stop = h->debug_stop;
@@ -733,12 +738,14 @@ int vlsat_forward(vlsat_handle h, vlsat_plan p, const float* pts, const float* f
     }
     RUN(gemm(h, s, G(p->H1, 128, h->re3_w2, 64, p->H2, 128, E, 128, h->re3_b2, ACT_RELU)));
     RUN(gemm(h, s, G(p->H2, 128, h->re3_w3, 128, p->E3, D, E, D, h->re3_b3, ACT_RELU)));
-    RUN(gemm(h, s, G(p->H1 + 64, 128, h->re2_w2, 64, p->H2, 128, E, 128, h->re2_b2, ACT_RELU)));
-    RUN(gemm(h, s, G(p->H2, 128, h->re2_w3, 128, p->E2, D, E, D, h->re2_b3, ACT_RELU)));
+    if (do2d) {
+        RUN(gemm(h, s, G(p->H1 + 64, 128, h->re2_w2, 64, p->H2, 128, E, 128, h->re2_b2, ACT_RELU)));
+        RUN(gemm(h, s, G(p->H2, 128, h->re2_w3, 128, p->E2, D, E, D, h->re2_b3, ACT_RELU)));
+    }
     STAGE(3);
     // a-6 adapter -> X2[:, 0:512]
-    RUN(gemm(h, s, G(f2d, D, h->ad_w1, D, p->T256, 256, N, 256, h->ad_b1, ACT_RELU)));
-    {
+    if (do2d) {
+        RUN(gemm(h, s, G(f2d, D, h->ad_w1, D, p->T256, 256, N, 256, h->ad_b1, ACT_RELU)));
         GemmArgs a = G(p->T256, 256, h->ad_w2h, 256, p->X2, LDX, N, D, h->ad_b2h);
         a.resid = f2d; a.ldr = D; a.resid_scale = 0.5f;
         RUN(gemm(h, s, a));
@@ -755,13 +762,13 @@ int vlsat_forward(vlsat_handle h, vlsat_plan p, const float* pts, const float* f
         const int base = 10 + 10 * l;
         RUN(attn_block(h, p, s, h->self_attn[l], p->X3, p->X3, true));                  // :217
         STAGE(base + 0);
-        RUN(attn_block(h, p, s, h->cross_attn[l], p->X2, p->X3, false));                // :218
+        if (do2d) RUN(attn_block(h, p, s, h->cross_attn[l], p->X2, p->X3, false));      // :218
         STAGE(base + 1);
         RUN(gcn_block(h, p, s, h->gcn3[l], p->X3, p->E3, e3_pending_relu, inter));      // :224
         STAGE(base + 2);
-        RUN(gcn_block(h, p, s, h->gcn2[l], p->X2, p->E2, 0, inter));                    // :225
+        if (do2d) RUN(gcn_block(h, p, s, h->gcn2[l], p->X2, p->E2, 0, inter));          // :225
         STAGE(base + 3);
-        {   // :231 edge cross-attention: q = 2D edges, k = v = 3D edges (pre-activation)
+        if (do2d) {   // :231 edge cross-attention: q = 2D edges, k = v = 3D edges (pre-activation)
             const AttnW& w = h->cross_rel[l];
             RUN(gemm(h, s, G(p->E2, D, w.wq, D, p->Qe, D, E, D, w.bq)));
             RUN(gemm(h, s, G(p->E3, D, w.wkv, D, p->KVe, 2 * D, E, 2 * D, w.bkv)));
@@ -782,10 +789,10 @@ int vlsat_forward(vlsat_handle h, vlsat_plan p, const float* pts, const float* f
     // a-15 relation heads, a-16 object heads
     if (E > 0) {
         RUN(rel_head(h, p, s, h->rel3, p->E3, e3_pending_relu, rel3d));
-        RUN(rel_head(h, p, s, h->rel2, p->E2, 0, rel2d));
+        if (do2d) RUN(rel_head(h, p, s, h->rel2, p->E2, 0, rel2d));
     }
     RUN(obj_head(h, p, s, p->X3, h->obj3_w, h->obj3_b, obj3d));
-    RUN(obj_head(h, p, s, p->X2, h->obj2_w, h->obj2_b, obj2d));
+    if (do2d) RUN(obj_head(h, p, s, p->X2, h->obj2_w, h->obj2_b, obj2d));
 #undef STAGE
     return 0;
 }

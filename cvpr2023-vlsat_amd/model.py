@@ -218,6 +218,35 @@ class VLSATModel:
                 rel3, rel2 = r3, r2
         return obj3, obj2, rel3, rel2
 
+    @torch.no_grad()
+    def forward_3d(self, obj_points, edge_indices, descriptor, batch_ids=None):
+        """3D-only deployment (no image features): returns (obj_logits_3d, rel_cls_3d), bit-identical to
+        the first and third outputs of ``forward`` -- the 3D branch never reads the 2D branch
+        (cf. reference src/model/SGFN_MMG/model_single.py:247-281) -- at about half the work."""
+        if not self._loaded:
+            raise L.VlsatError("weights not loaded: call load_state() first")
+        c = self.config
+        n = obj_points.shape[0]
+        pts = self._chk(obj_points, "obj_points", (n, c.dim_point, None), torch.float32)
+        desc = self._chk(descriptor, "descriptor", (n, c.dim_descriptor), torch.float32)
+        ei = self._chk(edge_indices, "edge_indices", (2, None), torch.int64)
+        if batch_ids is None:
+            batch_ids = self._zero_bid.get(n)
+            if batch_ids is None:
+                batch_ids = self._zero_bid[n] = torch.zeros(n, 1, dtype=torch.int64, device=self.device)
+        p, e = pts.shape[2], ei.shape[1]
+        with torch.cuda.device(self.device):
+            plan = self._plan(edge_indices if ei is edge_indices else ei, batch_ids, n, p)
+            obj3 = torch.empty(n, c.num_obj_class, dtype=torch.float32, device=self.device)
+            rel3 = torch.empty(e, c.num_rel_class, dtype=torch.float32, device=self.device)
+            L.check(self._lib.vlsat_forward(self._h, plan.handle, pts.data_ptr(), None, desc.data_ptr(),
+                                            obj3.data_ptr(), None, rel3.data_ptr(), None, L.stream_ptr()))
+            if plan.perm is not None:
+                r3 = torch.empty_like(rel3)
+                r3[plan.perm] = rel3
+                rel3 = r3
+        return obj3, rel3
+
     # ---- profiling / debug hooks -----------------------------------------------------------------
     def profile_enable(self, on: bool):
         L.check(self._lib.vlsat_profile_enable(self._h, int(on)))

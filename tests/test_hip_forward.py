@@ -235,6 +235,30 @@ def test_plan_cache_not_fooled_by_address_reuse():
         torch.cuda.empty_cache()
 
 
+def test_3d_only_path_is_bit_identical_and_faster():
+    """forward_3d skips the 2D branch; its outputs must equal forward()'s 3D outputs bit for bit."""
+    import time
+    cfg = VLSATConfig(N_LAYERS=3)
+    m = model_for(cfg)
+    d = _dev(synth.make_batch(8, 40, 256, seed0=1000))
+    full = m(d["obj_points"], d["obj_2d_feats"], d["edge_indices"], d["descriptor"], d["batch_ids"])
+    o3, r3 = m.forward_3d(d["obj_points"], d["edge_indices"], d["descriptor"], d["batch_ids"])
+    torch.cuda.synchronize()
+    assert torch.equal(o3, full[0]) and torch.equal(r3, full[2])
+
+    def timed(fn):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+    t_full = timed(lambda: m(d["obj_points"], d["obj_2d_feats"], d["edge_indices"], d["descriptor"], d["batch_ids"]))
+    t_3d = timed(lambda: m.forward_3d(d["obj_points"], d["edge_indices"], d["descriptor"], d["batch_ids"]))
+    print(f"3D-only {t_3d / 5 * 1e3:.2f} ms vs full {t_full / 5 * 1e3:.2f} ms")
+    assert t_3d < 0.7 * t_full
+
+
 def test_errors_are_loud():
     from vlsat_amd import lib as L
     from vlsat_amd.model import VLSATModel
