@@ -57,6 +57,8 @@ class VLSATModel:
         self._plans: "OrderedDict[tuple, _Plan]" = OrderedDict()
         self.training = False
         self.gemm_precision = "fp32"
+        # attributes MMGNet.validation reads on the model object (reference src/model/model.py:255,361)
+        self.iteration, self.eva_res, self.epoch = 0, 0, -1
 
     PRECISIONS = {"fp32": 0, "bf16": 1, "bf16x3": 3}
 
@@ -119,6 +121,23 @@ class VLSATModel:
             L.check(self._lib.vlsat_finalize_weights(self._h))
         self._loaded = True
         return self
+
+    def load(self, ckpt_dir: str, best: bool = False) -> bool:
+        """``BaseModel.load(best)`` on the reference's checkpoint directory (one ``.pth`` per sub-module,
+        reference model_utils/model_base.py:75-129); sets ``iteration`` / ``eva_res`` like the reference."""
+        from .checkpoint import load_reference_checkpoint
+        weights, meta = load_reference_checkpoint(ckpt_dir, self.config, best=best)
+        self.load_state(weights)
+        self.iteration, self.eva_res = meta["iteration"], meta["eva_res"]
+        return True
+
+    def process_val(self, obj_points, obj_2d_feats, gt_cls, descriptor, gt_rel_cls, edge_indices, batch_ids=None,
+                    with_log=False, use_triplet=False):
+        """Same arguments and 10-tuple as ``Mmgnet.process_val`` (reference SGFN_MMG/model.py:458-480);
+        forward and ranking both run on the GPU (``metrics.process_val``)."""
+        from . import metrics
+        return metrics.process_val(self, obj_points, obj_2d_feats, gt_cls, descriptor, gt_rel_cls, edge_indices,
+                                   batch_ids, use_triplet=use_triplet)
 
     # ---- graph plan ----------------------------------------------------------------------------
     def _plan(self, edge_indices, batch_ids, n, p) -> _Plan:

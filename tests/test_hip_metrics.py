@@ -138,3 +138,30 @@ def test_sharded_validation_loop_single_rank():
         assert abs(got[k] - want[k]) <= 2.0, (k, got[k], want[k])      # percentages; near-tie flips move single counts
     exact = [k for k in want if k.startswith(("obj_acc", "rel_acc"))]
     assert all(got[k] == want[k] for k in exact)
+
+
+def test_model_object_surface_like_the_reference(tmp_path, golden_dir):
+    """What MMGNet touches on the model object: load(best) from the per-module checkpoint directory,
+    eval(), process_val(...), iteration / eva_res (reference src/model/model.py:55-66,196-211,255,361)."""
+    _need_gpu()
+    from vlsat_amd import VLSATConfig, synth
+    from vlsat_amd.checkpoint import save_reference_checkpoint
+    from vlsat_amd.model import VLSATModel
+    cfg = VLSATConfig(N_LAYERS=2)
+    d = str(tmp_path / "ckp" / "Mmgnet" / "exp")
+    save_reference_checkpoint(d, synth.make_weights(cfg), best=True, iteration=1234, eva_res=56.5)
+    m = VLSATModel(cfg, DEV)
+    assert m.load(d, best=True) and m.eval() is m and m.to(DEV) is m
+    assert (m.iteration, m.eva_res) == (1234, 56.5)
+    b = synth.make_batch(1, 8, 256, seed0=1000)
+    x = {k: torch.from_numpy(v).to(DEV) for k, v in b.items()}
+    g = torch.Generator().manual_seed(5)
+    gt_cls = torch.randint(0, 160, (8,), generator=g).to(DEV)
+    gt_rel = (torch.rand(56, 26, generator=g) < 0.1).long().to(DEV)
+    out = m.process_val(x["obj_points"], x["obj_2d_feats"], gt_cls, x["descriptor"], gt_rel,
+                        x["edge_indices"].t().contiguous(), x["batch_ids"], use_triplet=True)
+    assert len(out) == 10 and out[0].shape == (8,) and out[4].shape == out[2].shape and out[6].shape[1] == 5
+    z = np.load(os.path.join(golden_dir, "cfg1_n8_p256_l2.npz"))
+    o = m(x["obj_points"], x["obj_2d_feats"], x["edge_indices"], x["descriptor"], x["batch_ids"])
+    assert float(np.abs(o[0].cpu().numpy() - z["obj3d"]).max()) < 1e-4
+    m.close()
