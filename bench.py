@@ -98,6 +98,7 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no MI355X visible; the HIP path has no CPU fallback", file=sys.stderr)
         sys.exit(3)
+    local = local % torch.cuda.device_count()          # (a 2-rank gloo dry run may share one GPU)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     from vlsat_amd.model import VLSATModel

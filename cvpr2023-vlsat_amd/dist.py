@@ -26,8 +26,8 @@ def env_rank() -> Tuple[int, int, int]:
 def init(backend: str | None = None) -> Tuple[int, int, int]:
     rank, local, world = env_rank()
     if world > 1 and not dist.is_initialized():
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"     # "nccl" is RCCL on ROCm
+        if backend is None:                                               # "nccl" is RCCL on ROCm
+            backend = os.environ.get("VLSAT_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
@@ -68,7 +68,12 @@ def scene_metrics(outputs, n_scenes: int) -> torch.Tensor:
 def allreduce_metrics(v: torch.Tensor) -> torch.Tensor:
     """The single collective of the path: sum of the metrics vector over ranks."""
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(v, op=dist.ReduceOp.SUM)
+        if v.is_cuda and dist.get_backend() == "gloo":      # test rigs without RCCL: reduce on the host
+            h = v.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            v.copy_(h)
+        else:
+            dist.all_reduce(v, op=dist.ReduceOp.SUM)
     return v
 
 
@@ -79,7 +84,7 @@ def barrier():
 
 def max_over_ranks(x: float, device) -> float:
     if dist.is_initialized() and dist.get_world_size() > 1:
-        t = torch.tensor([x], dtype=torch.float64, device=device)
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
     return x
