@@ -167,6 +167,20 @@ def test_single_object_scene_and_no_edges():
     _check(got, run_oracle(cfg, b), TIGHT, "scene with one object (no edges)")
 
 
+@pytest.mark.parametrize("n_obj,n_pts", [(1, 16), (2, 1), (3, 65), (9, 128)])
+def test_degenerate_shapes(n_obj, n_pts):
+    """Smallest graphs: a lone object (E = 0), two objects with ONE point each, odd point counts
+    (128 is the shipped config's num_points, config/mmgnet.json:73)."""
+    cfg = VLSATConfig(N_LAYERS=2)
+    sc = synth.make_scene(n_obj, max(n_pts, 2), 4200 + n_obj)     # descriptor needs >= 2 raw points (unbiased std)
+    if n_pts == 1:
+        sc["obj_points"] = np.ascontiguousarray(sc["obj_points"][:, :, :1])
+    b = synth.collate([sc])
+    got = run_hip(cfg, b)
+    assert got[2].shape == (n_obj * (n_obj - 1), 26)
+    _check(got, run_oracle(cfg, b), TIGHT, f"{n_obj} objects x {n_pts} points")
+
+
 def test_batch_independence_full_size():
     """cfg 2 at full batch size (64 scenes x 40 objects x 256 points, L=3): every scene's outputs
     must equal that scene run alone (block-diagonal attention), and scene 0 must match
