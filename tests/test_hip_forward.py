@@ -60,7 +60,7 @@ def _check(got, ref, tol, what):
         r = torch.as_tensor(r)
         assert g.shape == r.shape, (what, n, g.shape, r.shape)
         assert torch.isfinite(g).all(), f"{what} {n}: non-finite output"
-        errs[n] = float((g - r.float()).abs().max())
+        errs[n] = float((g - r.float()).abs().max()) if g.numel() else 0.0
     print(what, {k: f"{v:.2e}" for k, v in errs.items()})
     bad = {k: v for k, v in errs.items() if v > tol}
     assert not bad, f"{what}: max-abs-err over {tol}: {bad}"
