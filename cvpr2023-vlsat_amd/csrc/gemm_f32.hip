@@ -38,17 +38,20 @@ namespace vlsat {
 // ADD (compile time, so the 64 accumulator-init loads per lane are branch-free and batched):
 //   bit 0 = residual, bit 1 = gathered rows g0, bit 2 = gathered rows g1.
 // PREC: 0 = exact fp32 (PipeF32), 1 / 3 = bf16 / split-bf16 operands (PipeBF16, gemm_core.h).
-template <int BM, int BN, int ADD, int PREC>
+// KSL: k-slices (of 32) moved per pipeline step.  2 for small single-round problems, which are bound
+//      by the global-load round trip per step, not by MFMA issue: half the steps, twice the bytes in flight.
+template <int BM, int BN, int ADD, int PREC, int KSL>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int n_tiles, int nbn) {
     constexpr int TM = BM / 64, TN = BN / 64;
     using Pipe = typename PipeSel<BM, BN, PREC>::type;
-    constexpr int STAGE = Pipe::STAGE_BYTES;
+    constexpr int SLICE = Pipe::STAGE_BYTES;
+    constexpr int STAGE = SLICE * KSL;
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int g8 = gridDim.x >> 3, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int KT = p.K / BK;
+    const int KT = p.K / (BK * KSL);
 
     int round = 0;
     int v = xcd * g8 + slot;                 // tile of round r: (r*8 + xcd)*g8 + slot
@@ -57,10 +60,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int n_tile
 
     f32x16 acc[TM][TN];
     zero_acc<TM, TN>(acc);
-    typename Pipe::Regs regs;
+    typename Pipe::Regs regs[KSL];
 
-    Pipe::load(p, m0, n0, 0, regs, tid);
-    Pipe::store(smem, regs, tid, p.relu_a);
+#pragma unroll
+    for (int ks = 0; ks < KSL; ++ks) Pipe::load(p, m0, n0, ks * BK, regs[ks], tid);
+#pragma unroll
+    for (int ks = 0; ks < KSL; ++ks) Pipe::store(smem + ks * SLICE, regs[ks], tid, p.relu_a);
     __syncthreads();
 
     int buf = 0;
@@ -74,8 +79,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int n_tile
             const bool last = kt == KT - 1;
             const bool more = !last || next_tile;
             if (more) {
-                const int lm0 = last ? nm0 : m0, ln0 = last ? nn0 : n0, lk = last ? 0 : (kt + 1) * BK;
-                Pipe::load(p, lm0, ln0, lk, regs, tid);
+                const int lm0 = last ? nm0 : m0, ln0 = last ? nn0 : n0, lk = last ? 0 : (kt + 1) * BK * KSL;
+#pragma unroll
+                for (int ks = 0; ks < KSL; ++ks) Pipe::load(p, lm0, ln0, lk + ks * BK, regs[ks], tid);
             }
             if (ADD != 0 && kt == 0) {
                 // additive epilogue operands (residual / gathered rows) are loaded straight into
@@ -106,8 +112,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int n_tile
                         }
                 }
             }
-            Pipe::mma(cur, wm, wn, acc, lane);
-            if (more) Pipe::store(nxt, regs, tid, p.relu_a);
+#pragma unroll
+            for (int ks = 0; ks < KSL; ++ks) Pipe::mma(cur + ks * SLICE, wm, wn, acc, lane);
+            if (more) {
+#pragma unroll
+                for (int ks = 0; ks < KSL; ++ks) Pipe::store(nxt + ks * SLICE, regs[ks], tid, p.relu_a);
+            }
             __syncthreads();
             if (last) {
                 // ---- epilogue: lane holds column n, 16 rows per 32x32 tile ----
@@ -208,12 +218,12 @@ static int slots() {
     return g_slots;
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int KSL = 1>
 static int launch_t(const GemmArgs& a, int n_tiles, int grid, hipStream_t s) {
     const int nbn = (a.N + BN - 1) / BN;
     const int add = (a.resid ? 1 : 0) | (a.g0 ? 2 : 0) | (a.g1 ? 4 : 0);
 #define VLSAT_GEMM_CASE(ADD, PREC) \
-    case (PREC) * 8 + (ADD): hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, ADD, PREC>), dim3(grid), dim3(256), 0, s, a, n_tiles, nbn); break;
+    case (PREC) * 8 + (ADD): hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, ADD, PREC, KSL>), dim3(grid), dim3(256), 0, s, a, n_tiles, nbn); break;
     switch (a.prec * 8 + add) {
         VLSAT_GEMM_CASE(0, 0) VLSAT_GEMM_CASE(1, 0) VLSAT_GEMM_CASE(2, 0) VLSAT_GEMM_CASE(3, 0)
         VLSAT_GEMM_CASE(4, 0) VLSAT_GEMM_CASE(5, 0) VLSAT_GEMM_CASE(6, 0) VLSAT_GEMM_CASE(7, 0)
@@ -247,6 +257,7 @@ static int run_tiled(const GemmArgs& a, hipStream_t s) {
     const long T = (long)nbm * nbn;
     if (T <= G) {                                   // one round: grid = tiles (rounded up to 8)
         const int grid = (int)((T + 7) / 8) * 8;
+        if (BM == 64 && BN == 64 && a.K % (2 * BK) == 0) return launch_t<64, 64, 2>(a, (int)T, grid, s);   // latency-bound
         return launch_t<BM, BN>(a, (int)T, grid, s);
     }
     // full rounds with this tile; the remaining M-panels go to a smaller tile (see header)
