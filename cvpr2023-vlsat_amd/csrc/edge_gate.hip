@@ -16,6 +16,7 @@
 //   logits^T[m][row] : A = W3 (LDS), B = hidden^T registers of layer 1 (no LDS round trip)
 // so the softmax over the 32 channels is 15 in-lane ops + one lane^32 exchange.
 // One wave = 32 rows = 4 edges per step (192 MFMAs); a block of 4 waves walks 16-edge groups.
+#include <cstdlib>
 #include "gemm_core.h"
 #include "kernels.h"
 
@@ -120,7 +121,15 @@ int launch_edge_gate(const GateArgs& a, hipStream_t s) {
     if (a.n_edges <= 0) return 0;
     if ((a.ld_node & 3) || (a.gq_off & 3)) return fail(-1, "edge_gate: ld_node/gq_off must be multiples of 4");
     const int n_groups = (a.n_edges + 15) / 16;
-    const int grid = n_groups < 2048 ? n_groups : 2048;
+    // persistent: 3 blocks per CU are resident (51.7 KB LDS each); every block stages the weights once
+    // and walks ~n_groups/768 groups, so there is no partial last wave of blocks
+    static int cap = 0;
+    if (!cap) {
+        const char* e = getenv("VLSAT_GATE_GRID");
+        cap = e ? atoi(e) : 768;
+        if (cap < 1) cap = 768;
+    }
+    const int grid = n_groups < cap ? n_groups : cap;
     hipLaunchKernelGGL(edge_gate_kernel, dim3(grid), dim3(256), 0, s, a);
     VLSAT_LAUNCH_CHECK("edge_gate");
     return 0;
