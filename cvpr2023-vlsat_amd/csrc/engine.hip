@@ -690,6 +690,13 @@ int vlsat_debug_buffer(vlsat_plan p, const char* name, void** ptr, int64_t* rows
     return fail(VLSAT_EINVAL, std::string("unknown buffer ") + name);
 }
 
+// debug: while `buf` (device, >= 4 * 512 int64) is set, every persistent GEMM block writes
+// {shader cycles, 100 MHz wall ticks, tiles done, 1} at exit: effective clock = cycles / (ticks / 1e8)
+int vlsat_debug_gemm_clock_probe(int64_t* buf) {
+    gemm_set_clock_probe(reinterpret_cast<long long*>(buf));
+    return 0;
+}
+
 // debug: synchronous strided copy of a named workspace buffer into dst (device, row pitch dst_ld floats)
 int vlsat_debug_read(vlsat_plan p, const char* name, float* dst, int64_t dst_ld) {
     void* src = nullptr; int64_t rows = 0; int32_t cols = 0, ld = 0;

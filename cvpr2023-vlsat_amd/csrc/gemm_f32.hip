@@ -56,6 +56,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int n_tile
     int round = 0;
     int v = xcd * g8 + slot;                 // tile of round r: (r*8 + xcd)*g8 + slot
     if (v >= n_tiles) return;
+    const long long t_start = p.clock_probe ? clock64() : 0, w_start = p.clock_probe ? wall_clock64() : 0;
     int m0 = (v / nbn) * BM, n0 = (v % nbn) * BN;
 
     f32x16 acc[TM][TN];
@@ -191,7 +192,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int n_tile
             }
             buf ^= 1;
         }
-        if (!next_tile) break;
+        if (!next_tile) {
+            if (p.clock_probe && tid == 0) {       // DVFS probe: shader cycles (s_memtime) vs 100 MHz wall clock per block
+                long long* d = p.clock_probe + (size_t)blockIdx.x * 4;
+                d[0] = clock64() - t_start; d[1] = wall_clock64() - w_start; d[2] = round + 1; d[3] = 1;
+            }
+            break;
+        }
         ++round;
         m0 = nm0;
         n0 = nn0;
@@ -271,7 +278,12 @@ static int run_tiled(const GemmArgs& a, hipStream_t s) {
     return launch_gemm(tail_of(a, (int)(main_panels * BM)), s);   // strictly fewer rows: terminates
 }
 
-int launch_gemm(const GemmArgs& a, hipStream_t s) {
+static long long* g_clock_probe = nullptr;
+void gemm_set_clock_probe(long long* buf) { g_clock_probe = buf; }
+
+int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
+    GemmArgs a = a_in;
+    a.clock_probe = g_clock_probe;
     if (!a.A || !a.W || !a.C) return fail(-1, "gemm: null A/W/C");
     if (a.M <= 0 || a.N <= 0) return 0;
     if (a.K <= 0 || a.K % BK) return fail(-1, "gemm: K must be a positive multiple of 32");

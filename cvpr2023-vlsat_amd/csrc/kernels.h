@@ -25,9 +25,11 @@ struct GemmArgs {
     int prec = 0;
     const uint16_t* Whi = nullptr;
     const uint16_t* Wlo = nullptr;
+    long long* clock_probe = nullptr;           // optional [grid][4] DVFS probe buffer (vlsat_debug_gemm_clock_probe)
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
 double gemm_flops(const GemmArgs& a);
+void gemm_set_clock_probe(long long* buf);
 long gemm_kernel_launches();   // kernels launched so far by launch_gemm (main + tail launches)
 
 // ---- PointNet object encoder (fused conv1..conv3 + ReLU + max over points) ----

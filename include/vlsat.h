@@ -192,6 +192,11 @@ int vlsat_debug_buffer(vlsat_plan p, const char* name, void** ptr, int64_t* rows
 /* Synchronous strided device-to-device copy of that buffer into dst (row pitch dst_ld floats). */
 int vlsat_debug_read(vlsat_plan p, const char* name, float* dst, int64_t dst_ld);
 
+/* DVFS probe: while buf (device, >= 4*512 int64, zeroed) is non-NULL every block of the persistent GEMM
+ * writes {shader cycles (s_memtime), 100 MHz wall ticks (s_memrealtime), tiles done, 1} when it exits;
+ * cycles / (ticks / 1e8) is the shader clock the kernel actually ran at. NULL disables. */
+int vlsat_debug_gemm_clock_probe(int64_t* buf);
+
 #ifdef __cplusplus
 }
 #endif
