@@ -697,6 +697,13 @@ int vlsat_debug_gemm_clock_probe(int64_t* buf) {
     return 0;
 }
 
+// debug: experimental GEMM variant for the full rounds of large-M fp32 launches (see vlsat.h)
+int vlsat_debug_gemm_variant(int32_t variant) {
+    if (variant < 0 || variant > 2) return fail(VLSAT_EINVAL, "gemm_variant: 0, 1 or 2");
+    gemm_set_variant(variant);
+    return 0;
+}
+
 // debug: synchronous strided copy of a named workspace buffer into dst (device, row pitch dst_ld floats)
 int vlsat_debug_read(vlsat_plan p, const char* name, float* dst, int64_t dst_ld) {
     void* src = nullptr; int64_t rows = 0; int32_t cols = 0, ld = 0;

@@ -279,6 +279,8 @@ static int run_tiled(const GemmArgs& a, hipStream_t s) {
 }
 
 static long long* g_clock_probe = nullptr;
+static int g_variant = -1;                       // -1: not set yet (VLSAT_GEMM_BIG decides on first use)
+void gemm_set_variant(int v) { g_variant = v; }
 void gemm_set_clock_probe(long long* buf) { g_clock_probe = buf; }
 
 int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
@@ -296,6 +298,30 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
         return fail(-1, "gemm: A/W must be 16-byte aligned");
     const int G = slots();
     auto blocks = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
+    // Opt-in (vlsat_debug_gemm_variant / VLSAT_GEMM_BIG): full rounds of 256x128 tiles of large-M fp32
+    // launches on the one-wave-per-SIMD kernel (gemm_f32_big.hip); whatever does not fill a round falls
+    // through to the 4-wave tiles below.
+    if (g_variant < 0) {
+        const char* e = getenv("VLSAT_GEMM_BIG");
+        g_variant = e ? atoi(e) : 0;
+    }
+    if (g_variant > 0 && a.prec == 0 && a.N >= 128 && !a.rowscale) {
+        const int G1 = G / 2;                                  // one block per CU
+        const long nbm = (a.M + 255) / 256, nbn = (a.N + 127) / 128;
+        const long rounds = nbm * nbn / G1;
+        const long main_panels = rounds * G1 / nbn;
+        const int add = (a.resid ? 1 : 0) | (a.g0 ? 2 : 0) | (a.g1 ? 4 : 0);
+        if (main_panels > 0 && main_panels * 256 <= a.M && (add == 0 || g_variant == 2)) {
+            GemmArgs m = a;
+            m.M = (int)(main_panels * 256);
+            if (launch_gemm_big(m, (int)(main_panels * nbn), G1, s) == 0) {
+                ++g_kernel_launches;
+                if (m.M == a.M) return 0;
+                return launch_gemm(tail_of(a, m.M), s);
+            }
+            if (hipGetLastError() != hipSuccess) return fail(-2, "launch gemm_f32_big failed");
+        }
+    }
     // Largest tile that still gives every resident slot a tile; small problems (and the tails
     // of big ones) take smaller tiles so the launch covers as many CUs as the problem allows.
     if (a.N > 64 && blocks(128, 128) >= G) return run_tiled<128, 128>(a, s);

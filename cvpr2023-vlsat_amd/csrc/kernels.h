@@ -30,6 +30,10 @@ struct GemmArgs {
 int launch_gemm(const GemmArgs& a, hipStream_t s);
 double gemm_flops(const GemmArgs& a);
 void gemm_set_clock_probe(long long* buf);
+// one-wave-per-SIMD 256x128 variant with a 4-stage LDS ring for the full rounds of large-M fp32 launches
+// (gemm_f32_big.hip, opt-in); returns 1 if the operand combination is not built
+int launch_gemm_big(const GemmArgs& a, int n_tiles, int grid, hipStream_t s);
+void gemm_set_variant(int v);
 long gemm_kernel_launches();   // kernels launched so far by launch_gemm (main + tail launches)
 
 // ---- PointNet object encoder (fused conv1..conv3 + ReLU + max over points) ----

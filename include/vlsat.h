@@ -197,6 +197,12 @@ int vlsat_debug_read(vlsat_plan p, const char* name, float* dst, int64_t dst_ld)
  * cycles / (ticks / 1e8) is the shader clock the kernel actually ran at. NULL disables. */
 int vlsat_debug_gemm_clock_probe(int64_t* buf);
 
+/* Experimental fp32 GEMM variant for the full rounds of large-M launches (process-wide):
+ * 0 = default (two 4-wave blocks per CU), 1 = one-wave-per-SIMD 256x128 kernel (gemm_f32_big.hip) for
+ * launches without additive operands, 2 = that kernel for every combination it is built for.
+ * Same results to fp32 rounding-order differences; kept opt-in because it is not faster end to end. */
+int vlsat_debug_gemm_variant(int32_t variant);
+
 #ifdef __cplusplus
 }
 #endif
