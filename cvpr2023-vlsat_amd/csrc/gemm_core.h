@@ -15,6 +15,7 @@
 // (start bank = 36*row mod 64 -> conflict-free, MI355X_MICROARCH.md §LDS).
 #pragma once
 #include "common.h"
+#include "kernels.h"
 
 namespace vlsat {
 
@@ -106,15 +107,18 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[TM][TN]) {
 // ------------------------------------------------------------------------------------------------
 // Operand pipelines of the persistent GEMM (gemm_f32.hip): how a [BM|BN][32] k-slice travels
 // HBM -> registers -> LDS -> MFMA fragments.  PipeF32 is the exact-fp32 path above.
-struct GemmArgs;
+struct NoCtx {
+    template <class Args> __device__ __forceinline__ NoCtx(const Args&, int) {}
+};
 
 template <int BM, int BN>
 struct PipeF32 {
     static constexpr int TM = BM / 64, TN = BN / 64;
     static constexpr int STAGE_BYTES = (BM + BN) * LDT * 4;
     struct Regs { f32x4 a[BM / 32], b[BN / 32]; };
+    using Ctx = NoCtx;
     template <class Args>
-    static __device__ __forceinline__ void load(const Args& p, int m0, int n0, int k0, Regs& r, int tid) {
+    static __device__ __forceinline__ void load(const Ctx&, const Args& p, int m0, int n0, int k0, Regs& r, int tid, char*) {
         stage_load<BM>(p.A, p.lda, m0, p.M - 1, k0, r.a, tid);
         stage_load<BN>(p.W, p.ldw, n0, p.N - 1, k0, r.b, tid);
     }
@@ -127,6 +131,91 @@ struct PipeF32 {
     static __device__ __forceinline__ void mma(const char* stage, int wm, int wn, f32x16 (&acc)[TM][TN], int lane) {
         const float* s = reinterpret_cast<const float*>(stage);
         mma_slice<TM, TN>(s + (wm * TM * 32) * LDT, s + BM * LDT + (wn * TN * 32) * LDT, acc, lane);
+    }
+};
+
+// Exact-fp32 path with LDS-direct staging: `buffer_load_dwordx4 ... lds` moves the k-slice HBM/L2 -> LDS
+// without the VGPR round trip and without ds_write.  tools/vmem_issue_probe.hip: a global_load_dwordx4 plus
+// its ds_write_b128 takes ~64 matrix-pipe cycles away from the issuing SIMD, a buffer_load ... lds ~40; at 8
+// loads per wave per 64-MFMA slice that is the difference between 12.5 % and 8 % of the slice.
+//
+// The LDS-direct write puts lane l's 16 bytes at base + 16 l (tools/lds_dma_check.hip), so one wave
+// instruction fills 8 consecutive UNPADDED 128-byte rows and padding cannot be used against bank conflicts.
+// Instead the 16-byte chunks of a row are XOR-swizzled: logical chunk c of row r lives at chunk
+// c ^ ((r >> 1) & 7).  A ds_read_b128 by 16 consecutive lanes (rows r..r+15, same logical chunk) then
+// touches 2 row parities x 8 distinct chunks = all 64 banks exactly once.  The swizzle is applied on the
+// global side (the lane that writes physical chunk j of a row fetches logical chunk j ^ sw from HBM -- the 8
+// lanes of a row still cover one full 128-byte line) and on the fragment reads.
+// Rows past the matrix edge are not clamped: the buffer descriptor's num_records makes them read as zero
+// (the whole offset travels in the VGPR: on gfx9 the range check does not see the SGPR offset).
+template <int BM, int BN>
+struct PipeF32Dma {
+    static constexpr int TM = BM / 64, TN = BN / 64;
+    static constexpr int STAGE_BYTES = (BM + BN) * BK * 4;
+    struct Regs {};
+    struct Ctx {
+        int na, nw;                         // bytes addressable behind A / W (buffer num_records)
+        unsigned va, vw;                    // per-lane byte offsets inside an 8-row group (swizzled chunk)
+        template <class Args>
+        __device__ __forceinline__ Ctx(const Args& p, int tid) {
+            const int wave = tid >> 6, l = tid & 63;
+            na = (int)(((size_t)(p.M - 1) * p.lda + p.K) * 4);
+            nw = (int)(((size_t)(p.N - 1) * p.ldw + p.K) * 4);
+            const int row = 8 * wave + (l >> 3);                       // row inside a 32-row instruction group
+            const int chunk = (l & 7) ^ ((row >> 1) & 7);              // logical chunk this lane fetches
+            va = (unsigned)(row * p.lda + 4 * chunk) * 4u;
+            vw = (unsigned)(row * p.ldw + 4 * chunk) * 4u;
+        }
+    };
+    // instruction i of a wave covers tile rows 32 i + 8 wave .. + 7 (so the swizzle term does not depend on i)
+    static __device__ __forceinline__ void load(const Ctx& c, const GemmArgs& p, int m0, int n0, int k0, Regs&, int tid, char* stage) {
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        float* s = reinterpret_cast<float*>(stage) + wave * 8 * BK;
+        // (the descriptor type cannot be a struct member: the host pass of hipcc rejects it; these are 8 SGPRs
+        //  of loop-invariant scalar code)
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, c.na, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.W), 0, c.nw, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < BM / 32; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, s + i * 32 * BK, 16, c.va + (unsigned)(((m0 + 32 * i) * p.lda + k0) * 4), 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < BN / 32; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, s + (BM + i * 32) * BK, 16, c.vw + (unsigned)(((n0 + 32 * i) * p.ldw + k0) * 4), 0, 0, 0);
+    }
+    // the slice has had a whole slice of MFMAs to land; the caller's barrier publishes it
+    static __device__ __forceinline__ void store(char*, Regs&, int, int) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    static __device__ __forceinline__ void mma(const char* stage, int wm, int wn, f32x16 (&acc)[TM][TN], int lane) {
+        const int li = lane & 31, hi = lane >> 5;
+        const int sw = (li >> 1) & 7;
+        const float* sA = reinterpret_cast<const float*>(stage) + (wm * TM * 32 + li) * BK + 4 * ((hi ^ sw) & 1);
+        const float* sB = sA + (BM + wn * TN * 32 - wm * TM * 32) * BK;
+        const int y = sw >> 1;
+        f32x4 a[2][TM], b[2][TN];
+        auto load = [&](int set, int kg) {
+            const int o = 8 * (kg ^ y);
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) a[set][tm] = *reinterpret_cast<const f32x4*>(sA + tm * 32 * BK + o);
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) b[set][tn] = *reinterpret_cast<const f32x4*>(sB + tn * 32 * BK + o);
+        };
+        load(0, 0);
+        load(1, 1);
+#pragma unroll
+        for (int kg = 0; kg < BK / 8; ++kg) {
+            const int set = kg & 1;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[set][tm][s], b[set][tn][s], acc[tm][tn], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kg + 2 < BK / 8) {
+                load(set, kg + 2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
     }
 };
 
@@ -149,8 +238,9 @@ struct PipeBF16 {
     static constexpr int A_PLANE = BM * PH * 2, W_PLANE = BN * PH * 2;       // bytes
     static constexpr int STAGE_BYTES = (A_PLANE + W_PLANE) * PL;
     struct Regs { f32x4 a[BM / 32]; uint4 w[PL][BN / 64]; };
+    using Ctx = NoCtx;
     template <class Args>
-    static __device__ __forceinline__ void load(const Args& p, int m0, int n0, int k0, Regs& r, int tid) {
+    static __device__ __forceinline__ void load(const Ctx&, const Args& p, int m0, int n0, int k0, Regs& r, int tid, char*) {
         stage_load<BM>(p.A, p.lda, m0, p.M - 1, k0, r.a, tid);
 #pragma unroll
         for (int pl = 0; pl < PL; ++pl) {
@@ -215,5 +305,6 @@ struct PipeBF16 {
 
 template <int BM, int BN, int PREC> struct PipeSel { using type = PipeBF16<BM, BN, PREC>; };
 template <int BM, int BN> struct PipeSel<BM, BN, 0> { using type = PipeF32<BM, BN>; };
+template <int BM, int BN> struct PipeSel<BM, BN, 4> { using type = PipeF32Dma<BM, BN>; };   // internal: fp32, LDS-direct staging
 
 }  // namespace vlsat

@@ -62,9 +62,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int n_tile
     f32x16 acc[TM][TN];
     zero_acc<TM, TN>(acc);
     typename Pipe::Regs regs[KSL];
+    const typename Pipe::Ctx ctx(p, tid);
 
 #pragma unroll
-    for (int ks = 0; ks < KSL; ++ks) Pipe::load(p, m0, n0, ks * BK, regs[ks], tid);
+    for (int ks = 0; ks < KSL; ++ks) Pipe::load(ctx, p, m0, n0, ks * BK, regs[ks], tid, smem + ks * SLICE);
 #pragma unroll
     for (int ks = 0; ks < KSL; ++ks) Pipe::store(smem + ks * SLICE, regs[ks], tid, p.relu_a);
     __syncthreads();
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int n_tile
             if (more) {
                 const int lm0 = last ? nm0 : m0, ln0 = last ? nn0 : n0, lk = last ? 0 : (kt + 1) * BK * KSL;
 #pragma unroll
-                for (int ks = 0; ks < KSL; ++ks) Pipe::load(p, lm0, ln0, lk + ks * BK, regs[ks], tid);
+                for (int ks = 0; ks < KSL; ++ks) Pipe::load(ctx, p, lm0, ln0, lk + ks * BK, regs[ks], tid, nxt + ks * SLICE);
             }
             if (ADD != 0 && kt == 0) {
                 // additive epilogue operands (residual / gathered rows) are loaded straight into
@@ -195,7 +196,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int n_tile
         if (!next_tile) {
             if (p.clock_probe && tid == 0) {       // DVFS probe: shader cycles (s_memtime) vs 100 MHz wall clock per block
                 long long* d = p.clock_probe + (size_t)blockIdx.x * 4;
-                d[0] = clock64() - t_start; d[1] = wall_clock64() - w_start; d[2] = round + 1; d[3] = 1;
+                unsigned hw_id, xcc_id;                       // where the block ran: HW_ID (wave/simd/cu/sh/se), XCC_ID
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+                d[0] = clock64() - t_start; d[1] = wall_clock64() - w_start;
+                d[2] = (round + 1) | ((long long)(hw_id & 0xffffu) << 16) | ((long long)(xcc_id & 0xfu) << 32); d[3] = 1;
             }
             break;
         }
@@ -210,6 +215,7 @@ double gemm_flops(const GemmArgs& a) { return 2.0 * a.M * (double)a.N * a.K; }
 static long g_kernel_launches = 0;          // a logical GEMM is a main launch plus (usually) a small-tile tail launch
 long gemm_kernel_launches() { return g_kernel_launches; }
 
+static int g_dma = -1;       // LDS-direct staging of fp32 operands (PipeF32Dma); VLSAT_GEMM_DMA=0 selects the VGPR-staged pipe
 static int g_slots = 0;      // resident 256-thread blocks the persistent grid may use (2 per CU)
 static int slots() {
     if (!g_slots) {
@@ -231,7 +237,18 @@ static int launch_t(const GemmArgs& a, int n_tiles, int grid, hipStream_t s) {
     const int add = (a.resid ? 1 : 0) | (a.g0 ? 2 : 0) | (a.g1 ? 4 : 0);
 #define VLSAT_GEMM_CASE(ADD, PREC) \
     case (PREC) * 8 + (ADD): hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, ADD, PREC, KSL>), dim3(grid), dim3(256), 0, s, a, n_tiles, nbn); break;
-    switch (a.prec * 8 + add) {
+    // exact fp32 launches without ReLU-on-A take the LDS-direct staging pipe (internal precision code 4) when
+    // the operands are addressable with 32-bit byte offsets and the additive mode is one the forward uses
+    int prec = a.prec;
+    if (g_dma < 0) {
+        const char* e = getenv("VLSAT_GEMM_DMA");
+        g_dma = e ? atoi(e) : 1;
+    }
+    if (prec == 0 && g_dma &&!a.relu_a && (add == 0 || add == 1 || add == 6) &&
+        ((size_t)a.M + 256) * a.lda * 4 < (1ull << 32) && ((size_t)a.N + 256) * a.ldw * 4 < (1ull << 32))
+        prec = 4;
+    switch (prec * 8 + add) {
+        VLSAT_GEMM_CASE(0, 4) VLSAT_GEMM_CASE(1, 4) VLSAT_GEMM_CASE(6, 4)
         VLSAT_GEMM_CASE(0, 0) VLSAT_GEMM_CASE(1, 0) VLSAT_GEMM_CASE(2, 0) VLSAT_GEMM_CASE(3, 0)
         VLSAT_GEMM_CASE(4, 0) VLSAT_GEMM_CASE(5, 0) VLSAT_GEMM_CASE(6, 0) VLSAT_GEMM_CASE(7, 0)
         VLSAT_GEMM_CASE(0, 1) VLSAT_GEMM_CASE(1, 1) VLSAT_GEMM_CASE(6, 1)

@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Per-scene latency of the reference's own calling pattern: `process_val` hands over ONE scene per call and
+every scene is a different graph (reference src/model/model.py:181-212 -> SGFN_MMG/model.py:443-472), so
+each call pays graph analysis (vlsat_plan_create) + the forward + the ranking step.
+
+    python tools/latency_probe.py [--scenes 60] [--points 256]
+
+Prints wall time per call, split into plan / forward / ranking, for scenes of 9..80 objects (the 3RScan
+range), and the same scenes in one batched call for comparison."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import vlsat_amd  # noqa: E402
+from vlsat_amd import VLSATConfig, synth, metrics  # noqa: E402
+from vlsat_amd.model import VLSATModel  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scenes", type=int, default=60)
+    ap.add_argument("--points", type=int, default=256)
+    ap.add_argument("--layers", type=int, default=3)
+    a = ap.parse_args()
+    dev = "cuda:0"
+    cfg = VLSATConfig(N_LAYERS=a.layers)
+    model = VLSATModel(cfg, dev).load_state(synth.make_weights(cfg)).eval()
+    rng = np.random.default_rng(5)
+    sizes = rng.integers(9, 81, a.scenes)
+    scenes = [synth.make_scene(int(n), a.points, seed=100 + i) for i, n in enumerate(sizes)]
+
+    def to_dev(b):
+        return {k: (torch.from_numpy(v).to(dev) if isinstance(v, np.ndarray) else v) for k, v in b.items()}
+    items = [to_dev(synth.collate([s])) for s in scenes]
+    gts = [(torch.from_numpy(rng.integers(0, 160, int(n))).to(dev),
+            torch.from_numpy((rng.random((int(n) * (int(n) - 1), 26)) < 0.04).astype(np.int64)).to(dev)) for n in sizes]
+
+    def call(it):
+        return model.forward(it["obj_points"], it["obj_2d_feats"], it["edge_indices"], it["descriptor"], it["batch_ids"])
+
+    for it in items[:3]:                                   # warm-up: allocator, kernels
+        call(it)
+    torch.cuda.synchronize()
+    for p in model._plans.values():
+        p.destroy()
+    model._plans.clear()
+    t_fwd, t_rank = [], []
+    for it, (gc, gr) in zip(items, gts):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = call(it)                                     # new graph every call -> plan + forward
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        metrics.eval_ranks(out[0], out[2], gc, gr, it["edge_indices"].t().contiguous())
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        t_fwd.append(t1 - t0)
+        t_rank.append(t2 - t1)
+    # same graphs again: plans cached
+    t_hot = []
+    for it in items:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        call(it)
+        torch.cuda.synchronize()
+        t_hot.append(time.perf_counter() - t0)
+    f, r, h = np.array(t_fwd) * 1e3, np.array(t_rank) * 1e3, np.array(t_hot) * 1e3
+    print(f"{a.scenes} scenes, 9..80 objects x {a.points} pts, one scene per call (fully connected, E = n(n-1)):")
+    print(f"  new graph each call : plan+forward {f.mean():6.2f} ms mean ({np.median(f):.2f} median, {f.max():.2f} max); "
+          f"ranking {r.mean():.2f} ms  -> {1e3 / (f.mean() + r.mean()):.0f} scenes/s")
+    print(f"  same graphs again   : forward {h.mean():6.2f} ms mean (plan cached)")
+    big = to_dev(synth.collate(scenes))
+    call(big)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    call(big)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"  all {a.scenes} in ONE call   : {dt * 1e3:6.2f} ms = {dt * 1e3 / a.scenes:.3f} ms per scene")
+
+
+if __name__ == "__main__":
+    main()
