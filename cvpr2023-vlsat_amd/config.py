@@ -19,6 +19,12 @@ class VLSATConfig:
     NUM_HEADS: int = 8
     DIM_ATTEN: int = 256
     GCN_AGGR: str = "max"          # "max" | "add" | "mean"
+    # config switches that change the path's ops (shipped values are the defaults)
+    USE_GCN_EDGE: bool = True      # gate MLP on cat[q, k] (128->128->32) vs on q alone (64->128->32)  network_MMG.py:72-75,99-102
+    WITH_BN: bool = False          # BatchNorm1d (eval affine) after fc1/fc2 of the relation heads        network_PointNet.py:320-337
+    multi_rel_outputs: bool = True  # relation head ends in sigmoid (multi-label) vs log_softmax       SGFN_MMG/model.py:113-130
+    USE_RGB: bool = False          # +3 point channels                                                   SGFN_MMG/model.py:31-35
+    USE_NORMAL: bool = False       # +3 point channels
     clip_feat_dim: int = 512
     # fixed by Mmgnet.__init__ (reference SGFN_MMG/model.py:41-86)
     dim_node: int = 512
@@ -32,6 +38,7 @@ class VLSATConfig:
     obj_logit_scale: float = field(default_factory=lambda: math.log(1.0 / 0.07))
 
     def __post_init__(self):
+        self.dim_point = 3 + (3 if self.USE_RGB else 0) + (3 if self.USE_NORMAL else 0)
         if self.GCN_AGGR not in ("max", "add", "mean"):
             raise ValueError(f"GCN_AGGR must be max/add/mean, got {self.GCN_AGGR}")
         if self.dim_node % self.NUM_HEADS or self.DIM_ATTEN % self.NUM_HEADS:
@@ -80,8 +87,12 @@ def param_shapes(cfg: VLSATConfig) -> "OrderedDict[str, tuple]":
             p = f"mmg.{g}.{l}"
             lin(f"{p}.edgeatten.nn_edge.0", D + cfg.dim_edge, 2 * D + cfg.dim_edge)
             lin(f"{p}.edgeatten.nn_edge.2", cfg.dim_edge, D + cfg.dim_edge)
-            conv(f"{p}.edgeatten.nn.0", dn + de, dn + de)
-            conv(f"{p}.edgeatten.nn.3", do, dn + de)
+            if cfg.USE_GCN_EDGE:
+                conv(f"{p}.edgeatten.nn.0", dn + de, dn + de)
+                conv(f"{p}.edgeatten.nn.3", do, dn + de)
+            else:
+                conv(f"{p}.edgeatten.nn.0", 2 * dn, dn)
+                conv(f"{p}.edgeatten.nn.3", do, 2 * dn)
             lin(f"{p}.edgeatten.proj_edge.0", cfg.dim_edge, cfg.dim_edge)
             lin(f"{p}.edgeatten.proj_query.0", D, D)
             lin(f"{p}.edgeatten.proj_value.0", A, D)
@@ -96,6 +107,10 @@ def param_shapes(cfg: VLSATConfig) -> "OrderedDict[str, tuple]":
         lin(b + ".fc1", 512, cfg.dim_edge)
         lin(b + ".fc2", 256, 512)
         lin(b + ".fc3", cfg.num_rel_class, 256)
+        if cfg.WITH_BN:
+            for bn, d in (("bn1", 512), ("bn2", 256)):
+                for k in ("weight", "bias", "running_mean", "running_var"):
+                    s[f"{b}.{bn}.{k}"] = (d,)
     lin("obj_predictor_3d", cfg.num_obj_class, cfg.clip_feat_dim)
     lin("obj_predictor_2d", cfg.num_obj_class, cfg.clip_feat_dim)
     return s

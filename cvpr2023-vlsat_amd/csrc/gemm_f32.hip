@@ -5,9 +5,11 @@
 // C[M,N] = act(rowscale * (A[M,K] . W[N,K]^T) + bias + resid_scale*resid + g0[gi0] + g1[gi1])
 //
 // Block = 256 threads = 4 waves in a 2x2 grid; block tile BM x BN, wave tile (BM/2) x (BN/2)
-// made of 32x32 MFMA tiles; K streamed in BK=32 slices through double-buffered LDS with
-// register staging (global loads of slice t+1 are issued before the MFMAs of slice t and
-// written to the other buffer afterwards; one barrier per slice).
+// made of 32x32 MFMA tiles; K streamed in BK=32 slices through double-buffered LDS, one barrier
+// per slice.  Default operand pipe (PipeF32Dma, gemm_core.h): the loads of slice t+1 are issued
+// before the MFMAs of slice t as `buffer_load_dwordx4 ... lds` straight into the other buffer
+// (XOR-swizzled unpadded rows, no VGPR round trip, no ds_write).  ReLU-on-A launches and operands
+// beyond 32-bit offsets use the VGPR-staged pipe (PipeF32: global_load -> registers -> ds_write).
 //
 // PERSISTENT + pipelined across tiles: the grid is (at most) 2 blocks per CU and every block
 // walks a list of output tiles.  The slice pipeline does not drain at a tile boundary: the

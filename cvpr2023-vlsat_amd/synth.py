@@ -36,7 +36,7 @@ def make_weights(cfg: VLSATConfig, seed: int = 0) -> "OrderedDict[str, np.ndarra
     for name, shape in param_shapes(cfg).items():
         g = _rng(name, seed)
         leaf = name.rsplit(".", 1)[1]
-        is_norm = (".layer_norm." in name or name.startswith("mlp_3d.1.")
+        is_norm = (".layer_norm." in name or name.startswith("mlp_3d.1.") or ".bn1." in name or ".bn2." in name
                    or name.startswith("mmg.self_attn_fc.2.") or name.startswith("mmg.self_attn_fc.5."))
         if is_norm:
             if leaf == "weight":
@@ -116,3 +116,28 @@ def collate(scenes: list) -> dict:
 def make_batch(n_scenes: int, n_obj: int, n_pts: int, seed0: int = 1000) -> dict:
     """Batch of ``n_scenes`` scenes with seeds seed0, seed0+1, ...."""
     return collate([make_scene(n_obj, n_pts, seed0 + s) for s in range(n_scenes)])
+
+
+# ---- config-switch parity cases (tests/golden/make_golden_switches.py makes their goldens from the real reference) ----
+SWITCH_CASES = {
+    "switch_with_bn": dict(N_LAYERS=2, WITH_BN=True),
+    "switch_no_gcn_edge": dict(N_LAYERS=2, USE_GCN_EDGE=False),
+    "switch_single_rel": dict(N_LAYERS=2, multi_rel_outputs=False, num_rel_class=27),
+    "switch_rgb_normal": dict(N_LAYERS=2, USE_RGB=True, USE_NORMAL=True),
+    "switch_all": dict(N_LAYERS=1, GCN_AGGR="mean", WITH_BN=True, USE_GCN_EDGE=False, multi_rel_outputs=False,
+                       num_rel_class=27, USE_RGB=True, USE_NORMAL=True),
+}
+
+
+def switch_scenes(cfg: VLSATConfig) -> list:
+    """The ragged pair of scenes (4 and 6 objects x 32 points) every switch case runs on; colour / normal channels
+    (cfg.dim_point > 3) are seeded uniform values in [-1, 1] appended after xyz."""
+    out = []
+    for i, n in enumerate((4, 6)):
+        sc = make_scene(n, 32, 5000 + i)
+        if cfg.dim_point > 3:
+            g = np.random.default_rng([5000 + i, cfg.dim_point])
+            extra = g.uniform(-1, 1, (n, cfg.dim_point - 3, 32)).astype(np.float32)
+            sc["obj_points"] = np.concatenate([sc["obj_points"], extra], 1)
+        out.append(sc)
+    return out

@@ -140,8 +140,10 @@ def mha(q_in: Tensor, kv_in: Tensor, w: W, prefix: str, n_heads: int,
 
 def edge_atten(x: Tensor, e: Tensor, ei: Tensor, w: W, prefix: str, n_heads: int,
                taps: Optional[dict] = None):
-    """MultiHeadedEdgeAttention.forward, attention='fat', use_edge=True
-    (reference network_MMG.py:84-112).  Returns (gated [E,A], edge' [E,512], prob [E,A/H,H]).
+    """MultiHeadedEdgeAttention.forward, attention='fat' (reference network_MMG.py:84-112).
+    Returns (gated [E,A], edge' [E,512], prob [E,A/H,H]).  USE_GCN_EDGE=False (recognised by the shape of
+    nn.0: [2 d_n, d_n] instead of [d_n+d_e, d_n+d_e]) feeds the gate MLP with the projected query alone
+    (:72-75,99-102; proj_edge is then computed by the reference but unused).
     NOTE the head-minor layout: view(E, d, heads) (:97-98)."""
     xi, xj = gen_index(x, ei, "target_to_source")
     E = e.shape[0]
@@ -152,8 +154,9 @@ def edge_atten(x: Tensor, e: Tensor, ei: Tensor, w: W, prefix: str, n_heads: int
     k = lin(e, w, p + "proj_edge.0")
     q = q.view(E, q.shape[1] // n_heads, n_heads)       # explicit dims: E may be 0 (single-object scene)
     k = k.view(E, k.shape[1] // n_heads, n_heads)
-    z = torch.cat([q, k], 1)                                             # [E, dn+de, H]
     w0, b0 = w[p + "nn.0.weight"][:, :, 0], w[p + "nn.0.bias"]
+    use_edge = w0.shape[1] == q.shape[1] + k.shape[1]
+    z = torch.cat([q, k], 1) if use_edge else q                          # [E, dn+de | dn, H]
     w3, b3 = w[p + "nn.3.weight"][:, :, 0], w[p + "nn.3.bias"]
     z = torch.relu(torch.einsum("oc,ech->eoh", w0, z) + b0[None, :, None])
     z = torch.einsum("oc,ech->eoh", w3, z) + b3[None, :, None]
@@ -198,11 +201,24 @@ def mmg(x3: Tensor, x2: Tensor, e3: Tensor, e2: Tensor, ei: Tensor, centre: Tens
     return x3, x2, e3, e2
 
 
-def rel_head(e: Tensor, w: W, prefix: str) -> Tensor:
-    """PointNetRelClsMulti.forward, use_bn=False, dropout=id (reference network_PointNet.py:328-341)."""
-    h = torch.relu(lin(e, w, prefix + ".fc1"))
-    h = torch.relu(lin(h, w, prefix + ".fc2"))
-    return torch.sigmoid(lin(h, w, prefix + ".fc3"))
+def _bn_eval(x: Tensor, w: W, prefix: str) -> Tensor:
+    """BatchNorm1d in eval mode: (x - running_mean) / sqrt(running_var + 1e-5) * weight + bias."""
+    return (x - w[prefix + ".running_mean"]) / torch.sqrt(w[prefix + ".running_var"] + 1e-5) * w[prefix + ".weight"] \
+        + w[prefix + ".bias"]
+
+
+def rel_head(e: Tensor, w: W, prefix: str, multi: bool = True) -> Tensor:
+    """PointNetRelClsMulti.forward (sigmoid, reference network_PointNet.py:328-341) or, with
+    multi_rel_outputs=False, PointNetRelCls.forward (log_softmax, :274-286); dropout=id at eval;
+    BatchNorm1d after fc1 / fc2 when the checkpoint has it (WITH_BN)."""
+    h = lin(e, w, prefix + ".fc1")
+    if prefix + ".bn1.weight" in w:
+        h = _bn_eval(h, w, prefix + ".bn1")
+    h = lin(torch.relu(h), w, prefix + ".fc2")
+    if prefix + ".bn2.weight" in w:
+        h = _bn_eval(h, w, prefix + ".bn2")
+    h = lin(torch.relu(h), w, prefix + ".fc3")
+    return torch.sigmoid(h) if multi else torch.log_softmax(h, dim=1)
 
 
 def obj_head(x: Tensor, w: W, prefix: str, logit_scale: float) -> Tensor:
@@ -228,8 +244,9 @@ def forward_scene(w: W, cfg, obj_points: Tensor, obj_2d_feats: Tensor, edge_indi
                          cfg.N_LAYERS, cfg.NUM_HEADS, cfg.GCN_AGGR, taps)        # :314-316
     if taps is not None:
         taps.update({"mmg.0": x3, "mmg.1": x2, "mmg.2": e3, "mmg.3": e2})
-    rel3 = rel_head(e3, w, "rel_predictor_3d")                                   # :324
-    rel2 = rel_head(e2, w, "rel_predictor_2d")                                   # :325
+    multi = bool(getattr(cfg, "multi_rel_outputs", True))
+    rel3 = rel_head(e3, w, "rel_predictor_3d", multi)                                   # :324
+    rel2 = rel_head(e2, w, "rel_predictor_2d", multi)                                   # :325
     obj3 = obj_head(x3, w, "obj_predictor_3d", cfg.obj_logit_scale)              # :329
     obj2 = obj_head(x2, w, "obj_predictor_2d", cfg.obj_logit_scale)              # :330
     return obj3, obj2, rel3, rel2

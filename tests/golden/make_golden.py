@@ -100,7 +100,7 @@ def install_standins():
     sys.path[:0] = [REF, os.path.join(REF, "src")]
 
 
-def build_reference(n_layers, aggr="max"):
+def build_reference(n_layers, aggr="max", num_rel=26, **model_overrides):
     from src.model.SGFN_MMG.model import Mmgnet
     from src.utils.config import Config
 
@@ -111,23 +111,29 @@ def build_reference(n_layers, aggr="max"):
     cfg.max_iteration = 10
     cfg.MODEL.N_LAYERS = n_layers
     cfg.MODEL.GCN_AGGR = aggr
+    for k, v in model_overrides.items():          # USE_GCN_EDGE, WITH_BN, multi_rel_outputs, USE_RGB, USE_NORMAL
+        setattr(cfg.MODEL, k, v)
     cfg.MODEL.adapter_path = os.path.join(REF, "clip_adapter", "checkpoint", "origin_mean.pth")
 
     def fixed_label_weight(self, *a, **k):
         g = torch.Generator().manual_seed(7)
         o = torch.randn(160, 512, generator=g)
-        r = torch.randn(26, 512, generator=g)
+        r = torch.randn(num_rel, 512, generator=g)
         return o / o.norm(dim=-1, keepdim=True), r / r.norm(dim=-1, keepdim=True)
 
     Mmgnet.get_label_weight = fixed_label_weight
-    model = Mmgnet(cfg, 160, 26).eval()
+    model = Mmgnet(cfg, 160, num_rel).eval()
     return model
 
 
 def load_formula_weights(model, vcfg, seed=0):
     w = synth.make_weights(vcfg, seed)
     sd = model.state_dict()
-    dead = ("triplet_projector_", "clip_adapter.obj_logit_scale", "obj_logit_scale", "num_batches_tracked")
+    # dead at eval: triplet projectors, logit scales that are never checkpointed, BN counters, the BatchNorm
+    # layers PointNetfeat creates under WITH_BN but whose output it discards (network_PointNet.py:141-164), and
+    # proj_edge under USE_GCN_EDGE=False is still live in the state_dict and in our inventory (computed, unused)
+    dead = ("triplet_projector_", "clip_adapter.obj_logit_scale", "obj_logit_scale", "num_batches_tracked",
+            "_encoder.bn", "_encoder_2d.bn", "_encoder_3d.bn")
     live = [k for k in sd if not any(d in k for d in dead)]
     assert sorted(live) == sorted(w.keys()), (set(live) ^ set(w.keys()))
     for k, v in w.items():

@@ -161,6 +161,26 @@ def test_gemm_big_variant_matches(lib, K):
         lib.check(l.vlsat_debug_gemm_variant(0))
 
 
+@pytest.mark.parametrize("M,N,K,lda", [(1000, 300, 96, 96), (70000, 512, 512, 512), (4097, 130, 64, 200), (33, 26, 256, 256)])
+def test_gemm_lds_direct_pipe_is_bit_identical_to_vgpr_pipe(lib, M, N, K, lda):
+    """Launches without ReLU-on-A stage their operands with buffer_load ... lds into swizzled LDS rows
+    (PipeF32Dma), ReLU-on-A launches through registers (PipeF32).  On a non-negative A both compute the same
+    sums in the same order, so the outputs must agree bit for bit -- ragged M/N (rows past the edge come back as
+    zeros from the buffer descriptor instead of being clamped) and a strided A included."""
+    g = torch.Generator().manual_seed(M + N)
+    Abuf = torch.randn(M, lda, generator=g).abs().to(DEV)
+    A = Abuf[:, :K]
+    W = (torch.randn(N, K, generator=g) * 0.1).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    resid = torch.randn(M, N, generator=g).to(DEV)
+    for kw in (dict(bias=bias, act=1), dict(bias=bias, resid=resid, resid_scale=0.25)):
+        dma = _gemm(lib, A, W, relu_a=0, **kw)
+        vgpr = _gemm(lib, A, W, relu_a=1, **kw)
+        assert torch.equal(dma, vgpr), f"max diff {float((dma - vgpr).abs().max()):.3e}"
+    ref = _ref_gemm(A, W, bias=bias, act=1)
+    assert float((_gemm(lib, A, W, bias=bias, act=1) - ref).abs().max()) < 2e-5 * math.sqrt(K / 64) + 2e-5
+
+
 def test_gemm_strided_a_and_inplace_residual(lib):
     """The forward feeds A with a 768 pitch and adds the residual in place (C == resid)."""
     g = torch.Generator().manual_seed(5)

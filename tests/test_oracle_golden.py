@@ -100,6 +100,19 @@ def test_general_edges_all_aggregators(golden_dir, aggr):
         _close(o, z[f"{aggr}.{name}"], name=f"{aggr}.{name}")
 
 
+@pytest.mark.parametrize("case", sorted(synth.SWITCH_CASES))
+def test_config_switches(golden_dir, case):
+    """WITH_BN / USE_GCN_EDGE=false / multi_rel_outputs=false / USE_RGB+USE_NORMAL (SURVEY 8a switch table) against
+    the real reference run with that switch (tests/golden/make_golden_switches.py)."""
+    z = np.load(os.path.join(golden_dir, case + ".npz"))
+    cfg = VLSATConfig(**synth.SWITCH_CASES[case])
+    w = O.to_torch(synth.make_weights(cfg))
+    b = _t(synth.collate(synth.switch_scenes(cfg)))
+    out = O.forward(w, cfg, b["obj_points"], b["obj_2d_feats"], b["edge_indices"], b["descriptor"], b["batch_ids"])
+    for name, o in zip(("obj3d", "obj2d", "rel3d", "rel2d"), out):
+        _close(o, z[name], name=f"{case}.{name}")
+
+
 def test_cfg2_scene_shape(golden_dir):
     z = np.load(os.path.join(golden_dir, "cfg2_n40_p256_l3.npz"))
     cfg = VLSATConfig(N_LAYERS=3)
