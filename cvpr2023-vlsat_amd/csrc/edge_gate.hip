@@ -55,8 +55,13 @@ __global__ __launch_bounds__(256, 2) void edge_gate_kernel(GateArgs p) {
         const int e = valid ? e_raw : p.n_edges - 1;
         const float* zrow = p.kproj + (size_t)e * 512 + h * 64 + 4 * hi;
         f32x4 z[8];
+        if (p.use_edge) {
 #pragma unroll
-        for (int kg = 0; kg < 8; ++kg) z[kg] = *reinterpret_cast<const f32x4*>(zrow + kg * 8);
+            for (int kg = 0; kg < 8; ++kg) z[kg] = *reinterpret_cast<const f32x4*>(zrow + kg * 8);
+        } else {                                   // USE_GCN_EDGE=false: hidden = relu(Gq), the edge half is absent
+#pragma unroll
+            for (int kg = 0; kg < 8; ++kg) z[kg] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         const int sn = p.src[e], dn = p.dst[e];
 
         // Per 32-wide slice `to` of the hidden layer: layer 1 (32 MFMAs) then immediately its

@@ -173,7 +173,11 @@ int prepare_gcn(vlsat_ctx* h, Prep& P, const std::string& pre, GcnW& w) {
     const std::string e = pre + ".edgeatten.";
     auto w_e0 = P.get(e + "nn_edge.0.weight", (size_t)2 * D * 3 * D), b_e0 = P.get(e + "nn_edge.0.bias", 2 * D);
     auto w_e2 = P.get(e + "nn_edge.2.weight", (size_t)D * 2 * D), b_e2 = P.get(e + "nn_edge.2.bias", D);
-    auto w_n0 = P.get(e + "nn.0.weight", (size_t)(dn + de) * (dn + de)), b_n0 = P.get(e + "nn.0.bias", dn + de);
+    // gate MLP input: cat[q, k] (USE_GCN_EDGE, dn+de columns) or q alone (dn columns, hidden width 2*dn); reference
+    // network_MMG.py:72-75
+    const int NIN = h->d.use_gcn_edge ? dn + de : dn;
+    if (!h->d.use_gcn_edge && 2 * dn != dn + de) return fail(VLSAT_EINVAL, "USE_GCN_EDGE=false needs d_n == d_e");
+    auto w_n0 = P.get(e + "nn.0.weight", (size_t)(dn + de) * NIN), b_n0 = P.get(e + "nn.0.bias", dn + de);
     auto w_n3 = P.get(e + "nn.3.weight", (size_t)dox * (dn + de)), b_n3 = P.get(e + "nn.3.bias", dox);
     auto w_pe = P.get(e + "proj_edge.0.weight", (size_t)D * D), b_pe = P.get(e + "proj_edge.0.bias", D);
     auto w_pq = P.get(e + "proj_query.0.weight", (size_t)D * D), b_pq = P.get(e + "proj_query.0.bias", D);
@@ -201,7 +205,7 @@ int prepare_gcn(vlsat_ctx* h, Prep& P, const std::string& pre, GcnW& w) {
             std::vector<double> row(D, 0.0);
             double bb = b_n0[o];
             for (int c = 0; c < dn; ++c) {
-                const double wc = w_n0[(size_t)o * HID + c];
+                const double wc = w_n0[(size_t)o * NIN + c];
                 const float* qrow = &w_pq[(size_t)(c * H + hh) * D];
                 for (int k = 0; k < D; ++k) row[k] += wc * qrow[k];
                 bb += wc * b_pq[c * H + hh];
@@ -220,9 +224,10 @@ int prepare_gcn(vlsat_ctx* h, Prep& P, const std::string& pre, GcnW& w) {
             std::memcpy(&wpe[(size_t)(hh * de + c) * D], &w_pe[(size_t)(c * H + hh) * D], D * sizeof(float));
             bpe[hh * de + c] = b_pe[c * H + hh];
         }
-    std::vector<float> w0k((size_t)HID * de);
-    for (int o = 0; o < HID; ++o)
-        for (int c = 0; c < de; ++c) w0k[(size_t)o * de + c] = w_n0[(size_t)o * HID + dn + c];
+    std::vector<float> w0k((size_t)HID * de, 0.f);           // edge half of layer 1 (unused without USE_GCN_EDGE)
+    if (h->d.use_gcn_edge)
+        for (int o = 0; o < HID; ++o)
+            for (int c = 0; c < de; ++c) w0k[(size_t)o * de + c] = w_n0[(size_t)o * NIN + dn + c];
     UP(wnode, w.wnode); UP(bnode, w.bnode); UP(we1, w.we1); UP(w_e2, w.we2); UP(b_e2, w.be2);
     UP(wpe, w.wpe); UP(bpe, w.bpe); UP(w0k, w.w0k); UP(w_n3, w.w3); UP(b_n3, w.b3);
     UP(w_p0, w.wp0); UP(b_p0, w.bp0); UP(w_p2, w.wp2); UP(b_p2, w.bp2);
@@ -335,15 +340,17 @@ int gcn_block(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const GcnW& w, float
     e1.g0 = p->NP; e1.gi0 = p->d_src; e1.ldg0 = NPC;
     e1.g1 = p->NP + 2 * D; e1.gi1 = p->d_dst; e1.ldg1 = NPC;
     RUN(gemm(h, s, e1));
-    GemmArgs kp = G(e, D, w.wpe, D, p->KP, D, E, D, w.bpe);
-    kp.relu_a = e_relu_pending;
-    RUN(gemm(h, s, kp));
+    if (h->d.use_gcn_edge) {              // proj_edge feeds only the gate MLP (reference network_MMG.py:98-102)
+        GemmArgs kp = G(e, D, w.wpe, D, p->KP, D, E, D, w.bpe);
+        kp.relu_a = e_relu_pending;
+        RUN(gemm(h, s, kp));
+    }
     RUN(gemm(h, s, G(p->Hbig, 2 * D, w.we2, 2 * D, e, D, E, D, w.be2)));   // e <- nn_edge output (pre-activation)
     {
         GateArgs g{};
         g.kproj = p->KP; g.node = p->NP; g.ld_node = NPC; g.gq_off = 4 * D; g.v_off = 4 * D + h->H * 128;
         g.src = p->d_src; g.dst = p->d_dst; g.w0k = w.w0k; g.w3 = w.w3; g.b3 = w.b3; g.gated = p->G;
-        g.prob = p->prob; g.n_edges = E;
+        g.prob = p->prob; g.n_edges = E; g.use_edge = h->d.use_gcn_edge;
         Scope sc(h, s, PC_GATE, (double)E * h->H * (2.0 * 64 * 128 + 2.0 * 128 * 32));
         RUN(launch_edge_gate(g, s));
     }
@@ -362,7 +369,12 @@ int rel_head(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const RelHeadW& w, co
     a.relu_a = relu_a;
     RUN(gemm(h, s, a));
     RUN(gemm(h, s, G(p->R1, 512, w.w2, 512, p->R2, 256, E, 256, w.b2, ACT_RELU)));
-    RUN(gemm(h, s, G(p->R2, 256, w.w3, 256, out, R, E, R, w.b3, ACT_SIGMOID)));
+    // multi_rel_outputs: sigmoid (PointNetRelClsMulti) or log_softmax over the R classes (PointNetRelCls)
+    RUN(gemm(h, s, G(p->R2, 256, w.w3, 256, out, R, E, R, w.b3, h->d.multi_rel_outputs ? ACT_SIGMOID : ACT_NONE)));
+    if (!h->d.multi_rel_outputs) {
+        Scope sc(h, s, PC_MISC, 0);
+        RUN(launch_softmax_rows(out, R, E, R, out, 1, s));
+    }
     return 0;
 }
 
@@ -391,7 +403,8 @@ int vlsat_create(const VlsatDims* d, vlsat_handle* out) {
     if (d->n_layers < 1 || d->n_layers > 16) return fail(VLSAT_EINVAL, "n_layers must be in [1,16]");
     if (d->n_heads != 8 || d->dim_atten != 256) return fail(VLSAT_EINVAL, "only NUM_HEADS=8, DIM_ATTEN=256 are built");
     if (d->gcn_aggr < 0 || d->gcn_aggr > 2) return fail(VLSAT_EINVAL, "gcn_aggr must be 0 (max), 1 (add) or 2 (mean)");
-    if (d->dim_point != 3) return fail(VLSAT_EINVAL, "dim_point must be 3 (USE_RGB/USE_NORMAL unsupported)");
+    if (d->dim_point != 3 && d->dim_point != 6 && d->dim_point != 9)
+        return fail(VLSAT_EINVAL, "dim_point must be 3, 6 or 9 (xyz [+ USE_RGB] [+ USE_NORMAL])");
     if (d->n_obj_class < 1 || d->n_rel_class < 1) return fail(VLSAT_EINVAL, "class counts must be positive");
     auto* h = new (std::nothrow) vlsat_ctx();
     if (!h) return fail(VLSAT_ENOMEM, "out of host memory");
@@ -429,7 +442,7 @@ int vlsat_finalize_weights(vlsat_handle h) {
     Prep P{h, ""};
     const int D = h->D, C = h->C_pt, L = h->d.n_layers;
     // object encoder
-    auto w1 = P.get("obj_encoder.conv1.weight", 64 * 3), b1 = P.get("obj_encoder.conv1.bias", 64);
+    auto w1 = P.get("obj_encoder.conv1.weight", 64 * (size_t)h->d.dim_point), b1 = P.get("obj_encoder.conv1.bias", 64);
     auto w2 = P.get("obj_encoder.conv2.weight", 128 * 64), b2 = P.get("obj_encoder.conv2.bias", 128);
     auto w3 = P.get("obj_encoder.conv3.weight", (size_t)C * 128), b3 = P.get("obj_encoder.conv3.bias", C);
     // mlp_3d with BatchNorm1d(eval) folded (reference SGFN_MMG/model.py:106-111)
@@ -500,6 +513,22 @@ int vlsat_finalize_weights(vlsat_handle h) {
         auto f2 = P.get(b + ".fc2.weight", 256 * 512), f2b = P.get(b + ".fc2.bias", 256);
         auto f3 = P.get(b + ".fc3.weight", (size_t)R * 256), f3b = P.get(b + ".fc3.bias", R);
         if (!P.missing.empty()) return fail(VLSAT_ESTATE, "missing weight: " + P.missing);
+        // MODEL.WITH_BN: BatchNorm1d(eval) after fc1 / fc2 (reference network_PointNet.py:320-337), recognised by
+        // its keys in the checkpoint and folded into the layer in front of it
+        auto fold = [&](const std::string& bn, std::vector<float>& wt, std::vector<float>& bs, int outs, int ins) -> int {
+            if (!h->host.count(bn + ".weight")) return 0;
+            auto g = P.get(bn + ".weight", outs), be = P.get(bn + ".bias", outs);
+            auto mu = P.get(bn + ".running_mean", outs), var = P.get(bn + ".running_var", outs);
+            if (!P.missing.empty()) return fail(VLSAT_ESTATE, "missing weight: " + P.missing);
+            for (int o = 0; o < outs; ++o) {
+                const double sc = (double)g[o] / std::sqrt((double)var[o] + 1e-5);
+                for (int k = 0; k < ins; ++k) wt[(size_t)o * ins + k] = (float)(wt[(size_t)o * ins + k] * sc);
+                bs[o] = (float)(((double)bs[o] - mu[o]) * sc + be[o]);
+            }
+            return 0;
+        };
+        RUN(fold(b + ".bn1", f1, f1b, 512, D));
+        RUN(fold(b + ".bn2", f2, f2b, 256, 512));
         UP(f1, r.w1); UP(f1b, r.b1); UP(f2, r.w2); UP(f2b, r.b2); UP(f3, r.w3); UP(f3b, r.b3);
     }
     const float es = std::exp(h->d.obj_logit_scale);
@@ -735,7 +764,7 @@ int vlsat_forward(vlsat_handle h, vlsat_plan p, const float* pts, const float* f
 
     {   // a-2 object encoder
         Scope sc(h, s, PC_POINTNET, 213376.0 * N * p->P);
-        RUN(launch_pointnet(pts, N, p->P, h->pn_w1, h->pn_b1, h->pn_w2, h->pn_b2, h->pn_w3, h->pn_b3, h->C_pt, p->F, s));
+        RUN(launch_pointnet(pts, N, p->P, h->d.dim_point, h->pn_w1, h->pn_b1, h->pn_w2, h->pn_b2, h->pn_w3, h->pn_b3, h->C_pt, p->F, s));
     }
     STAGE(1);
     // a-3 mlp_3d (+BN folded) + spatial tail -> X3[:, 0:512]
@@ -866,7 +895,7 @@ int vlsat_k_gemm(const float* A, int32_t lda, const float* W, int32_t ldw, float
 int vlsat_k_pointnet(const float* pts, int32_t n_obj, int32_t n_points, const float* w1, const float* b1,
                      const float* w2, const float* b2, const float* w3, const float* b3, int32_t n_out, float* out,
                      void* stream) {
-    return launch_pointnet(pts, n_obj, n_points, w1, b1, w2, b2, w3, b3, n_out, out, static_cast<hipStream_t>(stream));
+    return launch_pointnet(pts, n_obj, n_points, 3, w1, b1, w2, b2, w3, b3, n_out, out, static_cast<hipStream_t>(stream));
 }
 
 int vlsat_k_flash_attn(const float* Q, const float* K, const float* V, float* O, int32_t ld, const int64_t* tok_ptr,
@@ -904,7 +933,7 @@ int vlsat_fc_edges(const int32_t* node_ptr, const int64_t* edge_ptr, int32_t n_s
 
 int vlsat_k_softmax_rows(const float* x, int32_t ld, int32_t rows, int32_t cols, float* out, void* stream) {
     if (!x || !out) return fail(VLSAT_EINVAL, "softmax_rows: null argument");
-    return launch_softmax_rows(x, ld, rows, cols, out, static_cast<hipStream_t>(stream));
+    return launch_softmax_rows(x, ld, rows, cols, out, 0, static_cast<hipStream_t>(stream));
 }
 
 int vlsat_eval_ranks(const float* obj_logits, const float* obj_probs, const float* rel_probs, const int64_t* gt_class,

@@ -17,8 +17,9 @@
 namespace vlsat {
 
 // probs[n, :] = softmax(x[n, :])  (F.softmax in evaluate_triplet_topk :144); one wave per row
-__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, int ld, int rows, int cols,
-                                                           float* __restrict__ out) {
+// out may alias x (every element is read and written by the same lane); log_out: log_softmax instead of softmax
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* x, int ld, int rows, int cols, float* out,
+                                                           int log_out) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float* p = x + (size_t)row * ld;
@@ -28,7 +29,12 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     float s = 0.f;
     for (int c = lane; c < cols; c += 64) s += expf(p[c] - m);
     s = wave_sum(s);
-    for (int c = lane; c < cols; c += 64) out[(size_t)row * cols + c] = expf(p[c] - m) / s;
+    if (log_out) {
+        const float ls = logf(s);
+        for (int c = lane; c < cols; c += 64) out[(size_t)row * cols + c] = (p[c] - m) - ls;
+    } else {
+        for (int c = lane; c < cols; c += 64) out[(size_t)row * cols + c] = expf(p[c] - m) / s;
+    }
 }
 
 __global__ __launch_bounds__(256) void obj_rank_kernel(const float* __restrict__ pred, int ld, const int64_t* __restrict__ gt,
@@ -145,9 +151,10 @@ __global__ __launch_bounds__(256) void tri_rank_kernel(const float* __restrict__
     }
 }
 
-int launch_softmax_rows(const float* x, int ld, int rows, int cols, float* out, hipStream_t s) {
+int launch_softmax_rows(const float* x, int ld, int rows, int cols, float* out, int log_out, hipStream_t s) {
     if (rows <= 0) return 0;
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, ld, rows, cols, out);
+    if (x == out && ld != cols) return fail(-1, "softmax_rows: in-place needs ld == cols");
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, ld, rows, cols, out, log_out);
     VLSAT_LAUNCH_CHECK("softmax_rows");
     return 0;
 }

@@ -37,7 +37,7 @@ void gemm_set_variant(int v);
 long gemm_kernel_launches();   // kernels launched so far by launch_gemm (main + tail launches)
 
 // ---- PointNet object encoder (fused conv1..conv3 + ReLU + max over points) ----
-int launch_pointnet(const float* pts, int n_obj, int n_points, const float* w1, const float* b1,
+int launch_pointnet(const float* pts, int n_obj, int n_points, int cin, const float* w1, const float* b1,
                     const float* w2, const float* b2, const float* w3, const float* b3, int n_out,
                     float* out, hipStream_t s);
 
@@ -87,6 +87,7 @@ struct GateArgs {
     float* gated;            // [E, 256]  gated[e, m*8 + h]
     float* prob;             // optional [E, 32, 8] tap (tests) or nullptr
     int n_edges;
+    int use_edge = 1;        // MODEL.USE_GCN_EDGE: 0 -> the gate MLP sees the query alone (kproj / w0k unused)
 };
 int launch_edge_gate(const GateArgs& a, hipStream_t s);
 
@@ -99,7 +100,7 @@ int launch_aggregate(const float* gated, int n_ch, const int32_t* rowptr, const 
 int launch_split_bf16(const float* w, size_t n, uint16_t* hi, uint16_t* lo, hipStream_t s);
 
 // ---- eval ranking step: softmax + top-k ranks by counting ----
-int launch_softmax_rows(const float* x, int ld, int rows, int cols, float* out, hipStream_t s);
+int launch_softmax_rows(const float* x, int ld, int rows, int cols, float* out, int log_out, hipStream_t s);
 int launch_eval_ranks(const float* obj_logits, const float* obj_probs, const float* rel, const int64_t* gt_cls,
                       const int64_t* gt_rel, const int64_t* edges, int N, int E, int C, int R, int topk_obj,
                       int topk_rel, int topk_tri, float thr, int32_t* obj_rank, int32_t* rel_rank, int32_t* tri_rank,

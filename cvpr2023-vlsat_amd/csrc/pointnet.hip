@@ -5,7 +5,8 @@
 // here nothing but the [N,768] result touches HBM.
 //
 // One block (4 waves, 2x2) walks 64-point chunks of one object:
-//   conv1 (3->64)    VALU, 16 outputs per thread, result H1[64][64] in LDS
+//   conv1 (CIN->64)  VALU, 16 outputs per thread, result H1[64][64] in LDS; CIN = 3 (xyz), 6 or 9 (MODEL.USE_RGB /
+//                    USE_NORMAL add 3 channels each, reference SGFN_MMG/model.py:31-35)
 //   conv2 (64->128)  fp32 MFMA, A = H1 from LDS, B = W2 streamed through the stage buffers;
 //                    H2[64][128] = relu(.) overwrites H1's LDS (aliased)
 //   conv3 (128->768) fp32 MFMA, 6 column chunks x 4 k-slices of W3 double-buffered in LDS,
@@ -26,26 +27,27 @@ constexpr int PN_P1 = 68;     // H1 pitch
 constexpr int PN_P2 = 132;    // H2 pitch
 constexpr int PN_MAXNC = 6;   // n_out / 128 <= 6
 
+template <int CIN>
 __global__ __launch_bounds__(256, 2) void pointnet_kernel(
     const float* __restrict__ pts, int P, const float* __restrict__ w1, const float* __restrict__ b1,
     const float* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ w3,
     const float* __restrict__ b3, int n_out, float* __restrict__ out, int nsplit) {
     __shared__ __attribute__((aligned(16))) float sH[PN_M * PN_P2];          // H1 (pitch 68) then H2 (pitch 132)
     __shared__ __attribute__((aligned(16))) float sW[2 * 128 * LDT];         // weight slices [128][36] x 2
-    __shared__ __attribute__((aligned(16))) float sW1[64 * 4];               // (w_x, w_y, w_z, b) per channel
+    constexpr int S1 = (CIN + 4) & ~3;                                        // (w_0 .. w_{CIN-1}, b) per channel, padded to x4
+    __shared__ __attribute__((aligned(16))) float sW1[64 * S1];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, li = lane & 31, hi = lane >> 5;
     const int obj = blockIdx.x / nsplit, part = blockIdx.x % nsplit;
     const int n_chunks = (P + PN_M - 1) / PN_M;
     const int n_nc = n_out / 128;
-    const float* op = pts + (size_t)obj * 3 * P;
+    const float* op = pts + (size_t)obj * CIN * P;
 
     if (tid < 64) {
-        sW1[tid * 4 + 0] = w1[tid * 3 + 0];
-        sW1[tid * 4 + 1] = w1[tid * 3 + 1];
-        sW1[tid * 4 + 2] = w1[tid * 3 + 2];
-        sW1[tid * 4 + 3] = b1[tid];
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) sW1[tid * S1 + c] = w1[tid * CIN + c];
+        sW1[tid * S1 + CIN] = b1[tid];
     }
     float rmax[PN_MAXNC][2];
 #pragma unroll
@@ -59,14 +61,19 @@ __global__ __launch_bounds__(256, 2) void pointnet_kernel(
             const int pp = tid >> 2, cg = (tid & 3) * 16;
             int p = ch * PN_M + pp;
             p = p < P ? p : P - 1;
-            const float x = op[p], y = op[P + p], z = op[2 * P + p];
+            float xin[CIN];
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) xin[c] = op[(size_t)c * P + p];
 #pragma unroll
             for (int c4 = 0; c4 < 4; ++c4) {
                 f32x4 h;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const f32x4 w = *reinterpret_cast<const f32x4*>(sW1 + (cg + c4 * 4 + c) * 4);
-                    h[c] = fmaxf(fmaf(w[0], x, fmaf(w[1], y, fmaf(w[2], z, w[3]))), 0.f);
+                    const float* w = sW1 + (cg + c4 * 4 + c) * S1;
+                    float a = w[CIN];                                    // b + w_{CIN-1} x_{CIN-1} + ... + w_0 x_0
+#pragma unroll
+                    for (int k = CIN - 1; k >= 0; --k) a = fmaf(w[k], xin[k], a);
+                    h[c] = fmaxf(a, 0.f);
                 }
                 *reinterpret_cast<f32x4*>(sH + pp * PN_P1 + cg + c4 * 4) = h;
             }
@@ -138,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void pointnet_kernel(
     }
 }
 
-int launch_pointnet(const float* pts, int n_obj, int n_points, const float* w1, const float* b1,
+int launch_pointnet(const float* pts, int n_obj, int n_points, int cin, const float* w1, const float* b1,
                     const float* w2, const float* b2, const float* w3, const float* b3, int n_out,
                     float* out, hipStream_t s) {
     if (n_obj <= 0) return 0;
@@ -149,8 +156,14 @@ int launch_pointnet(const float* pts, int n_obj, int n_points, const float* w1, 
     if (nsplit > n_chunks) nsplit = n_chunks;
     if (nsplit < 1) nsplit = 1;
     if (nsplit > 1) VLSAT_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)n_obj * n_out * sizeof(float), s));
-    hipLaunchKernelGGL(pointnet_kernel, dim3(n_obj * nsplit), dim3(256), 0, s, pts, n_points, w1, b1, w2, b2, w3,
-                       b3, n_out, out, nsplit);
+#define VLSAT_PN_CASE(CIN) \
+    case CIN: hipLaunchKernelGGL(pointnet_kernel<CIN>, dim3(n_obj * nsplit), dim3(256), 0, s, pts, n_points, w1, b1, w2, \
+                                 b2, w3, b3, n_out, out, nsplit); break;
+    switch (cin) {
+        VLSAT_PN_CASE(3) VLSAT_PN_CASE(6) VLSAT_PN_CASE(9)
+        default: return fail(-1, "pointnet: point channels must be 3, 6 or 9");
+    }
+#undef VLSAT_PN_CASE
     VLSAT_LAUNCH_CHECK("pointnet");
     return 0;
 }

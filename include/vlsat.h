@@ -49,10 +49,13 @@ typedef struct {
     int32_t n_heads;         /* MODEL.NUM_HEADS (8) */
     int32_t dim_atten;       /* MODEL.DIM_ATTEN (256) */
     int32_t gcn_aggr;        /* MODEL.GCN_AGGR: 0 max, 1 add, 2 mean */
-    int32_t dim_point;       /* 3 (USE_RGB / USE_NORMAL unsupported) */
+    int32_t dim_point;       /* 3, +3 with MODEL.USE_RGB, +3 with MODEL.USE_NORMAL (SGFN_MMG/model.py:31-35) */
     int32_t n_obj_class;     /* 160 */
-    int32_t n_rel_class;     /* 26 */
+    int32_t n_rel_class;     /* 26 (27 in the single-label setting) */
     float   obj_logit_scale; /* log(1/0.07): never checkpointed by the reference */
+    int32_t use_gcn_edge;    /* MODEL.USE_GCN_EDGE (1): gate MLP on cat[q,k]; 0: on q alone (network_MMG.py:72-75) */
+    int32_t multi_rel_outputs; /* MODEL.multi_rel_outputs (1): sigmoid relation head; 0: log_softmax (SGFN_MMG/model.py:113-130) */
+    /* MODEL.WITH_BN needs no field: the relation heads' bn1/bn2 tensors are folded when the checkpoint has them */
 } VlsatDims;
 
 const char* vlsat_last_error(void);

@@ -32,7 +32,7 @@ def model_for(cfg):
     from vlsat_amd.model import VLSATModel
     if not torch.cuda.is_available():
         pytest.fail("no GPU visible: the HIP path cannot run and there is no fallback")
-    key = (cfg.N_LAYERS, cfg.GCN_AGGR)
+    key = (cfg.N_LAYERS, cfg.GCN_AGGR, cfg.USE_GCN_EDGE, cfg.WITH_BN, cfg.multi_rel_outputs, cfg.dim_point, cfg.num_rel_class)
     if key not in _MODELS:
         _MODELS[key] = VLSATModel(cfg, DEV).load_state(synth.make_weights(cfg)).eval()
     return _MODELS[key]
@@ -143,6 +143,19 @@ def test_general_edges_golden(golden_dir, aggr):
     sc["edge_indices"] = z["edge_indices"]
     got = run_hip(cfg, synth.collate([sc]))
     _check(got, [z[f"{aggr}.{n}"] for n in NAMES], TIGHT, f"general edges / {aggr}")
+
+
+@pytest.mark.parametrize("case", sorted(synth.SWITCH_CASES))
+def test_config_switches_golden(golden_dir, case):
+    """MODEL.WITH_BN / USE_GCN_EDGE=false / multi_rel_outputs=false (log_softmax, 27 classes) / USE_RGB+USE_NORMAL
+    (9 point channels) and all of them together: ragged 2-scene batch against the real reference run with that
+    switch (tests/golden/make_golden_switches.py), and against the oracle."""
+    cfg = VLSATConfig(**synth.SWITCH_CASES[case])
+    b = synth.collate(synth.switch_scenes(cfg))
+    z = np.load(os.path.join(golden_dir, case + ".npz"))
+    got = run_hip(cfg, b)
+    _check(got, [z[n] for n in NAMES], TIGHT, f"{case} vs reference golden")
+    _check(got, run_oracle(cfg, b), TIGHT, f"{case} vs oracle")
 
 
 def test_edges_interleaved_across_scenes():

@@ -61,9 +61,9 @@ def test_library_exports_every_declared_symbol(L):
 def test_c_abi_argument_validation_without_gpu(L):
     lib = L.load()
     h = C.c_void_p()
-    good = L.VlsatDims(2, 8, 256, 0, 3, 160, 26, 2.6593)
+    good = L.VlsatDims(2, 8, 256, 0, 3, 160, 26, 2.6593, 1, 1)
     for bad in (L.VlsatDims(0, 8, 256, 0, 3, 160, 26, 2.65), L.VlsatDims(2, 4, 256, 0, 3, 160, 26, 2.65),
-                L.VlsatDims(2, 8, 256, 3, 3, 160, 26, 2.65), L.VlsatDims(2, 8, 256, 0, 6, 160, 26, 2.65)):
+                L.VlsatDims(2, 8, 256, 3, 3, 160, 26, 2.65), L.VlsatDims(2, 8, 256, 0, 5, 160, 26, 2.65)):
         assert lib.vlsat_create(C.byref(bad), C.byref(h)) == -1
         assert len(lib.vlsat_last_error()) > 0
     assert lib.vlsat_create(C.byref(good), C.byref(h)) == 0
