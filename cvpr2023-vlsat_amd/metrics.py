@@ -24,10 +24,24 @@ def softmax_rows(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def multihot_targets(gt_rel: torch.Tensor, n_rel: int) -> torch.Tensor:
+    """The relation target as the multi-hot [E,R] matrix the ranking kernels take.  multi_rel_outputs=True: it
+    already is one.  Single-label setting (gt_rel [E] int, 0 = 'none'): get_gt keeps only labels > 0
+    (reference eva_utils_acc.py:19-22), i.e. a one-hot row with column 0 cleared."""
+    if gt_rel.dim() == 2:
+        return gt_rel
+    hot = torch.nn.functional.one_hot(gt_rel.long().view(-1), n_rel)
+    hot[:, 0] = 0
+    return hot
+
+
 def eval_ranks(obj_logits: torch.Tensor, rel_probs: torch.Tensor, gt_class: torch.Tensor, gt_rel: torch.Tensor,
-               edges: torch.Tensor, obj_probs: torch.Tensor | None = None) -> Dict[str, torch.Tensor]:
+               edges: torch.Tensor, obj_probs: torch.Tensor | None = None,
+               multi_rel_outputs: bool = True, rel_exp: torch.Tensor | None = None) -> Dict[str, torch.Tensor]:
     """Device tensors in, device tensors out (no sync).  ``edges`` is [E,2] (from, to) like the
-    ``edge_indices`` the reference hands to process_val; ``gt_rel`` the multi-hot [E,R] target.
+    ``edge_indices`` the reference hands to process_val; ``gt_rel`` the multi-hot [E,R] target, or the [E] label
+    vector of the single-label setting (multi_rel_outputs=False: ``rel_probs`` are then log-probabilities, ranked
+    as they are by evaluate_topk_predicate and exponentiated by evaluate_triplet_topk, eva_utils_acc.py:146-147).
     Returns flat rank tensors in the reference's order plus ``cnt`` (ranks per edge)."""
     lib = L.load()
     n, c = obj_logits.shape
@@ -35,7 +49,7 @@ def eval_ranks(obj_logits: torch.Tensor, rel_probs: torch.Tensor, gt_class: torc
     dev = obj_logits.device
     obj_logits, rel_probs = obj_logits.contiguous(), rel_probs.contiguous()
     gt_class = gt_class.to(torch.int64).contiguous().view(-1)
-    gt_rel = gt_rel.to(torch.int64).contiguous()
+    gt_rel = multihot_targets(gt_rel, r).to(torch.int64).contiguous()
     edges = edges.to(torch.int64).contiguous()
     if edges.shape != (e, 2) or gt_rel.shape != (e, r) or gt_class.numel() != n:
         raise L.VlsatError("eval_ranks: edges must be [E,2], gt_rel [E,R], gt_class [N]")
@@ -49,6 +63,13 @@ def eval_ranks(obj_logits: torch.Tensor, rel_probs: torch.Tensor, gt_class: torc
                                  gt_rel.data_ptr(), edges.data_ptr(), n, e, c, r, TOPK_OBJ, TOPK_REL, TOPK_TRIPLET,
                                  THRESHOLD, obj_rank.data_ptr(), rel_rank.data_ptr(), tri_rank.data_ptr(), cnt.data_ptr(),
                                  L.stream_ptr()))
+    if not multi_rel_outputs:            # triplet scores use exp(log_softmax); predicate ranks above used the raw values
+        tri_rank = torch.empty(e, r, dtype=torch.int32, device=dev)
+        rel_exp = (rel_probs.exp() if rel_exp is None else rel_exp).contiguous()
+        L.check(lib.vlsat_eval_ranks(obj_logits.data_ptr(), obj_probs.data_ptr(), rel_exp.data_ptr(), gt_class.data_ptr(),
+                                     gt_rel.data_ptr(), edges.data_ptr(), n, e, c, r, TOPK_OBJ, TOPK_REL, TOPK_TRIPLET,
+                                     THRESHOLD, obj_rank.data_ptr(), torch.empty_like(rel_rank).data_ptr(),
+                                     tri_rank.data_ptr(), torch.empty_like(cnt).data_ptr(), L.stream_ptr()))
     used = torch.arange(r, device=dev)[None, :] < cnt[:, None]          # first cnt[e] slots of each edge row
     return {"top_k_obj": obj_rank, "top_k_rel": rel_rank[used], "top_k_triplet": tri_rank[used], "cnt": cnt,
             "obj_probs": obj_probs}
@@ -58,6 +79,8 @@ def cls_matrix(gt_class: torch.Tensor, gt_rel: torch.Tensor, edges: torch.Tensor
     """[n,5] rows (sub_gt, sub_pred_rank, obj_gt, obj_pred_rank, predicate | -1) in the order
     evaluate_triplet_topk appends them (eva_utils_acc.py:185-199): per edge its gt predicates in
     ascending class order, or one row with -1 when the edge has no gt relation."""
+    if gt_rel.dim() == 1:
+        raise L.VlsatError("cls_matrix: pass the multi-hot target (metrics.multihot_targets)")
     e, r = gt_rel.shape
     has = gt_rel == 1
     none = ~has.any(1)
@@ -76,8 +99,10 @@ def process_val(model, obj_points, obj_2d_feats, gt_cls, descriptor, gt_rel_cls,
     reference's; the score lists come back stacked as tensors."""
     ei_t = edge_indices.t().contiguous()
     obj3, obj2, rel3, rel2 = model(obj_points, obj_2d_feats, ei_t, descriptor, batch_ids, istrain=False)
-    r3 = eval_ranks(obj3, rel3, gt_cls, gt_rel_cls, edge_indices)
-    r2 = eval_ranks(obj2, rel2, gt_cls, gt_rel_cls, edge_indices)
+    multi = bool(getattr(getattr(model, "config", None), "multi_rel_outputs", True))     # self.mconfig.multi_rel_outputs
+    gt_rel_cls = multihot_targets(gt_rel_cls, rel3.shape[1])
+    r3 = eval_ranks(obj3, rel3, gt_cls, gt_rel_cls, edge_indices, multi_rel_outputs=multi)
+    r2 = eval_ranks(obj2, rel2, gt_cls, gt_rel_cls, edge_indices, multi_rel_outputs=multi)
     cm = cls_matrix(gt_cls, gt_rel_cls, edge_indices, r3["top_k_obj"])     # obj_topk = 3D ranks for both (:469-470)
     np64 = lambda t: t.cpu().numpy().astype(np.int64)
     if not use_triplet:
@@ -86,7 +111,7 @@ def process_val(model, obj_points, obj_2d_feats, gt_cls, descriptor, gt_rel_cls,
     ei, _ = torch.nonzero(has, as_tuple=True)
     sub_scores = r3["obj_probs"][edge_indices[ei, 0]]
     obj_scores = r3["obj_probs"][edge_indices[ei, 1]]
-    rel_scores = rel3[ei]
+    rel_scores = rel3[ei] if multi else rel3[ei].exp()
     return (np64(r3["top_k_obj"]), np64(r2["top_k_obj"]), np64(r3["top_k_rel"]), np64(r2["top_k_rel"]),
             np64(r3["top_k_triplet"]), np64(r2["top_k_triplet"]), cm.cpu().numpy(), sub_scores, obj_scores, rel_scores)
 

@@ -80,6 +80,18 @@ def triplet_topk(obj_logits: torch.Tensor, rel_pred: torch.Tensor, gt_cls: torch
     return _edge_ranks(per_edge), np.asarray(cls, dtype=np.int64).reshape(-1, 5)
 
 
+def single_label_ranks(obj_logits: torch.Tensor, rel_logp: torch.Tensor, gt_cls: torch.Tensor, gt_rel_1d: torch.Tensor,
+                       edges: torch.Tensor, topk_rel: int, topk_tri: int, obj_topk: np.ndarray):
+    """multi_rel_outputs=False: the target is one label per edge, 0 = 'none' (get_gt keeps labels > 0,
+    eva_utils_acc.py:19-22), the head outputs log-probabilities; evaluate_topk_predicate ranks them as they are,
+    evaluate_triplet_topk exponentiates them first (:146-147).  Returns (top_k_rel, top_k_triplet, cls_matrix)."""
+    hot = torch.nn.functional.one_hot(gt_rel_1d.long().view(-1), rel_logp.shape[1])
+    hot[:, 0] = 0
+    rel_rank = topk_predicate(rel_logp, hot, topk_rel)
+    tri, cm = triplet_topk(obj_logits, rel_logp.exp(), gt_cls, hot, edges, topk_tri, obj_topk)
+    return rel_rank, tri, cm
+
+
 def mean_recall(triplet_rank: np.ndarray, cls_matrix: np.ndarray, topk=(50, 100)) -> np.ndarray:
     """eva_utils_acc.py:224-237 (note: classes 0..max-1 only, as the reference loops range(max))."""
     if len(cls_matrix) == 0:

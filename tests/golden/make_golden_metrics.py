@@ -57,7 +57,39 @@ def case(seed, n, e_keep, C=160, Rn=26, sharp=6.0):
     return out
 
 
+def case_single(seed, n, e_keep, C=160, Rn=27, sharp=6.0):
+    """multi_rel_outputs=False: one label per edge (0 = none), log_softmax predictions."""
+    g = torch.Generator().manual_seed(seed)
+    obj_logits = torch.randn(n, C, generator=g) * sharp
+    gt_cls = torch.randint(0, C, (n,), generator=g)
+    for i in range(0, n, 2):
+        obj_logits[i, gt_cls[i]] += 3 * sharp
+    pairs = [(a, b) for a in range(n) for b in range(n) if a != b]
+    pick = torch.randperm(len(pairs), generator=g)[:e_keep].tolist()
+    edges = torch.tensor([pairs[i] for i in pick], dtype=torch.long)
+    E = edges.shape[0]
+    rel = torch.log_softmax(torch.randn(E, Rn, generator=g) * 3.0, dim=1)
+    gt_rel = torch.randint(0, Rn, (E,), generator=g)
+    gt_rel[torch.rand(E, generator=g) < 0.4] = 0                               # 'none'
+    for e in range(0, E, 3):                                                   # some correct predictions
+        if gt_rel[e] > 0:
+            rel[e, gt_rel[e]] = rel[e].max() + 0.5
+    top_k_obj = R.evaluate_topk_object(obj_logits, gt_cls, topk=11)
+    gt_edges = R.get_gt(gt_cls, gt_rel, edges, False)
+    top_k_rel = R.evaluate_topk_predicate(rel, gt_edges, False, topk=6)
+    tri, cls_matrix, ss, _, _ = R.evaluate_triplet_topk(obj_logits, rel.clone(), gt_edges, edges, False, topk=101,
+                                                        use_clip=True, obj_topk=top_k_obj)
+    cm = np.array([[int(x) for x in row] for row in cls_matrix], dtype=np.int64)
+    return dict(obj_logits=obj_logits.numpy(), gt_cls=gt_cls.numpy(), edges=edges.numpy(), rel=rel.numpy(),
+                gt_rel=gt_rel.numpy(), top_k_obj=top_k_obj, top_k_rel=top_k_rel, top_k_triplet=tri, cls_matrix=cm)
+
+
 def main():
+    single = {}
+    for name, (seed, n, e) in {"a": (11, 7, 42), "b": (12, 10, 60)}.items():
+        for k, v in case_single(seed, n, e).items():
+            single[f"{name}.{k}"] = v
+    np.savez_compressed(os.path.join(HERE, "metrics_single_label.npz"), **single)
     allc = {}
     for name, (seed, n, e) in {"a": (1, 8, 56), "b": (2, 5, 11), "c": (3, 12, 70)}.items():
         for k, v in case(seed, n, e).items():

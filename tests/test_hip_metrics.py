@@ -48,6 +48,29 @@ def test_ranks_equal_reference_goldens(golden_dir, case):
         assert agree >= 0.98, agree
 
 
+@pytest.mark.parametrize("case", ["a", "b"])
+def test_single_label_ranks_equal_reference_goldens(golden_dir, case):
+    """multi_rel_outputs=False (SURVEY 8a switch table): [E] label targets with 0 = none, log-probabilities in."""
+    _need_gpu()
+    from vlsat_amd import metrics as M
+    z = np.load(os.path.join(golden_dir, "metrics_single_label.npz"))
+    g = lambda k: torch.from_numpy(z[f"{case}.{k}"])
+    logits, rel = g("obj_logits"), g("rel")
+    r = M.eval_ranks(logits.to(DEV), rel.to(DEV), g("gt_cls").to(DEV), g("gt_rel").to(DEV), g("edges").to(DEV),
+                     obj_probs=F.softmax(logits, dim=-1).to(DEV), multi_rel_outputs=False, rel_exp=rel.exp().to(DEV))
+    torch.cuda.synchronize()
+    assert np.array_equal(r["top_k_obj"].cpu().numpy(), z[f"{case}.top_k_obj"])
+    assert np.array_equal(r["top_k_rel"].cpu().numpy(), z[f"{case}.top_k_rel"])
+    assert np.array_equal(r["top_k_triplet"].cpu().numpy(), z[f"{case}.top_k_triplet"])
+    hot = M.multihot_targets(g("gt_rel").to(DEV), rel.shape[1])
+    cm = M.cls_matrix(g("gt_cls").to(DEV), hot, g("edges").to(DEV), r["top_k_obj"])
+    assert np.array_equal(cm.cpu().numpy(), z[f"{case}.cls_matrix"])
+    # device-side exp(): the same ranks up to last-bit ties
+    r2 = M.eval_ranks(logits.to(DEV), rel.to(DEV), g("gt_cls").to(DEV), g("gt_rel").to(DEV), g("edges").to(DEV),
+                      multi_rel_outputs=False)
+    assert (r2["top_k_triplet"].cpu().numpy() == z[f"{case}.top_k_triplet"]).mean() >= 0.98
+
+
 def test_ranks_equal_oracle_random_graph():
     _need_gpu()
     from vlsat_amd import metrics as M
@@ -100,6 +123,36 @@ def test_process_val_tuple_matches_oracle_pipeline():
     tri, cm = MO.triplet_topk(ref[0], ref[2], gt_cls, gt_rel, edges, 101, obj3)
     assert (out[4] == tri).mean() >= 0.97 and np.array_equal(out[6], cm)     # logits differ by ~4e-6: near-ties may flip
     assert out[7].shape == (int(gt_rel.sum()), 160) and out[9].shape == (int(gt_rel.sum()), 26)
+
+
+def test_process_val_single_label_setting():
+    """multi_rel_outputs=False end to end: log_softmax head over 27 classes, [E] label targets, ranks vs the oracles."""
+    _need_gpu()
+    from vlsat_amd import VLSATConfig, synth, metrics as M
+    from vlsat_amd.model import VLSATModel
+    from oracle import vlsat_oracle as O, metrics_oracle as MO
+    cfg = VLSATConfig(**synth.SWITCH_CASES["switch_single_rel"])
+    w = synth.make_weights(cfg)
+    b = synth.make_batch(1, 7, 48, seed0=8100)
+    g = torch.Generator().manual_seed(2)
+    n, e = 7, b["edge_indices"].shape[1]
+    gt_cls = torch.randint(0, 160, (n,), generator=g)
+    gt_rel = torch.randint(0, 27, (e,), generator=g)
+    gt_rel[torch.rand(e, generator=g) < 0.5] = 0
+    edges = torch.from_numpy(b["edge_indices"]).t().contiguous()
+    model = VLSATModel(cfg, DEV).load_state(w).eval()
+    d = {k: torch.from_numpy(v).to(DEV) for k, v in b.items()}
+    out = M.process_val(model, d["obj_points"], d["obj_2d_feats"], gt_cls.to(DEV), d["descriptor"], gt_rel.to(DEV),
+                        edges.to(DEV), d["batch_ids"])
+    c = {k: torch.from_numpy(v) for k, v in b.items()}
+    ref = O.forward(O.to_torch(w), cfg, c["obj_points"], c["obj_2d_feats"], c["edge_indices"], c["descriptor"], c["batch_ids"])
+    assert float((ref[2].exp().sum(1) - 1).abs().max()) < 1e-5                  # the head really is a log_softmax
+    obj3 = MO.topk_object(ref[0], gt_cls, 11)
+    rel3, tri3, cm = MO.single_label_ranks(ref[0], ref[2], gt_cls, gt_rel, edges, 6, 101, obj3)
+    assert np.array_equal(out[0], obj3)
+    assert (out[2] == rel3).mean() >= 0.97 and (out[4] == tri3).mean() >= 0.97   # ~1e-6 output differences: near-ties may flip
+    assert np.array_equal(out[6], cm)
+    assert out[9].shape == (int((gt_rel > 0).sum()), 27) and float(out[9].sum(1).sub(1).abs().max()) < 1e-4
 
 
 def test_sharded_validation_loop_single_rank():

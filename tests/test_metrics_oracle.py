@@ -26,3 +26,16 @@ def test_ranks_match_reference(golden_dir, case):
     assert np.array_equal(tri2, z[f"{case}.top_k_triplet_2d"])
     assert np.allclose(MO.mean_recall(tri, cm), z[f"{case}.mean_recall"])
     assert int(z[f"{case}.n_scores"][0]) == int((cm[:, -1] != -1).sum())
+
+
+@pytest.mark.parametrize("case", ["a", "b"])
+def test_single_label_ranks_match_reference(golden_dir, case):
+    """multi_rel_outputs=False: label targets (0 = none), log_softmax predictions, exp() before the triple scores."""
+    z = np.load(os.path.join(golden_dir, "metrics_single_label.npz"))
+    g = lambda k: torch.from_numpy(z[f"{case}.{k}"])
+    obj = MO.topk_object(g("obj_logits"), g("gt_cls"), 11)
+    assert np.array_equal(obj, z[f"{case}.top_k_obj"])
+    rel, tri, cm = MO.single_label_ranks(g("obj_logits"), g("rel"), g("gt_cls"), g("gt_rel"), g("edges"), 6, 101, obj)
+    assert np.array_equal(rel, z[f"{case}.top_k_rel"])
+    assert np.array_equal(tri, z[f"{case}.top_k_triplet"])
+    assert np.array_equal(cm, z[f"{case}.cls_matrix"])
