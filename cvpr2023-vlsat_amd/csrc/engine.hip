@@ -52,6 +52,7 @@ using namespace vlsat;
 
 struct vlsat_ctx {
     VlsatDims d{};
+    int edge_scope = 0;      // edge cross-attention keys: 0 = the query's scene, 1 = the whole batch (vlsat_set_edge_attention_scope)
     int D = 512, A = 256, H = 8, C_pt = 768;
     std::map<std::string, std::vector<float>> host;   // raw reference-layout tensors
     bool finalized = false;
@@ -603,12 +604,19 @@ int vlsat_plan_create(vlsat_handle h, const int64_t* bid, const int64_t* edges, 
     std::vector<int4> tiles;
     std::vector<int64_t> bias_ptr(p->S);
     int64_t bias_total = 0;
+    if (h->edge_scope == 1 && E > 0) {       // reference multi-scene call: one attention over all edges
+        for (int hh = 0; hh < h->H; ++hh)
+            for (int64_t q0 = 0; q0 < E; q0 += FLASH_BQ) tiles.push_back(make_int4(0, (int)E, (int)q0, hh));
+        p->flash_flops += 4.0 * (double)E * (double)E * h->D;
+    }
     for (int s = 0; s < p->S; ++s) {
         const int64_t T = p->edge_ptr[s + 1] - p->edge_ptr[s];
-        for (int hh = 0; hh < h->H; ++hh)
-            for (int64_t q0 = 0; q0 < T; q0 += FLASH_BQ)
-                tiles.push_back(make_int4((int)p->edge_ptr[s], (int)T, (int)q0, hh));
-        p->flash_flops += 4.0 * (double)T * (double)T * h->D;
+        if (h->edge_scope == 0) {
+            for (int hh = 0; hh < h->H; ++hh)
+                for (int64_t q0 = 0; q0 < T; q0 += FLASH_BQ)
+                    tiles.push_back(make_int4((int)p->edge_ptr[s], (int)T, (int)q0, hh));
+            p->flash_flops += 4.0 * (double)T * (double)T * h->D;
+        }
         const int64_t n = p->node_ptr[s + 1] - p->node_ptr[s];
         bias_ptr[s] = bias_total;
         bias_total += (int64_t)h->H * n * n;
@@ -723,6 +731,14 @@ int vlsat_debug_buffer(vlsat_plan p, const char* name, void** ptr, int64_t* rows
 // {shader cycles, 100 MHz wall ticks, tiles done, 1} at exit: effective clock = cycles / (ticks / 1e8)
 int vlsat_debug_gemm_clock_probe(int64_t* buf) {
     gemm_set_clock_probe(reinterpret_cast<long long*>(buf));
+    return 0;
+}
+
+// Keys of the edge cross-attention for plans created from now on (see vlsat.h)
+int vlsat_set_edge_attention_scope(vlsat_handle h, int32_t scope) {
+    if (!h) return fail(VLSAT_EINVAL, "null handle");
+    if (scope != 0 && scope != 1) return fail(VLSAT_EINVAL, "edge attention scope: 0 (per scene) or 1 (whole batch)");
+    h->edge_scope = scope;
     return 0;
 }
 

@@ -58,6 +58,7 @@ class VLSATModel:
         self._plans: "OrderedDict[tuple, _Plan]" = OrderedDict()
         self.training = False
         self.gemm_precision = "fp32"
+        self.batch_mode = "per_scene"
         # attributes MMGNet.validation reads on the model object (reference src/model/model.py:255,361)
         self.iteration, self.eva_res, self.epoch = 0, 0, -1
 
@@ -71,6 +72,22 @@ class VLSATModel:
             raise L.VlsatError(f"gemm precision must be one of {sorted(self.PRECISIONS)}")
         L.check(self._lib.vlsat_set_gemm_precision(self._h, self.PRECISIONS[mode]))
         self.gemm_precision = mode
+        return self
+
+    BATCH_MODES = {"per_scene": 0, "reference": 1}
+
+    def set_batch_mode(self, mode: str):
+        """How a call that carries several scenes is evaluated.  'per_scene' (default): every scene exactly as if it
+        were evaluated alone -- MMGNet.validation's contract (batch_size=1, reference src/model/model.py:185).
+        'reference': what Mmgnet.forward itself computes on such a batch -- its edge cross-attention has no scene mask
+        (network_MMG.py:228-234), so 2D edges attend to the 3D edges of every scene in the call."""
+        if mode not in self.BATCH_MODES:
+            raise L.VlsatError(f"batch mode must be one of {sorted(self.BATCH_MODES)}")
+        L.check(self._lib.vlsat_set_edge_attention_scope(self._h, self.BATCH_MODES[mode]))
+        for p in self._plans.values():          # plans bake the attention tile table in
+            p.destroy()
+        self._plans.clear()
+        self.batch_mode = mode
         return self
 
     # ---- nn.Module-like surface --------------------------------------------------------------

@@ -106,6 +106,13 @@ int vlsat_forward(vlsat_handle h, vlsat_plan p,
  * bf16 on the device at first use. */
 int vlsat_set_gemm_precision(vlsat_handle h, int32_t mode);
 
+/* Which 3D edges a 2D edge attends to in the edge cross-attention (reference network_MMG.py:228-234), for plans
+ * created AFTER the call.  0 (default): the edges of its own scene -- validation()'s contract, which runs one scene
+ * per call (src/model/model.py:185).  1: every edge of the batch -- what the reference computes when a single call
+ * carries several scenes, because that attention has no scene mask; the 3D outputs are identical in
+ * both modes, the 2D outputs are not. */
+int vlsat_set_edge_attention_scope(vlsat_handle h, int32_t scope);
+
 /* Per-kernel timing of the forward with HIP events on `stream` (bench.py roofline leg).
  * enable=1: every launch of every kernel class is bracketed by hipEventRecord on the launch
  * stream; vlsat_profile_read synchronises, accumulates and returns per-class totals since

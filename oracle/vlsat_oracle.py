@@ -284,5 +284,53 @@ def forward(w: W, cfg, obj_points: Tensor, obj_2d_feats: Tensor, edge_indices: T
     return obj3, obj2, rel3, rel2
 
 
+@torch.no_grad()
+def forward_cross_scene(w: W, cfg, obj_points: Tensor, obj_2d_feats: Tensor, edge_indices: Tensor,
+                        descriptor: Tensor, batch_ids: Tensor):
+    """What the reference computes when ONE call carries several scenes: node attention is masked per
+    scene and the GCNs are scene-local, but the edge cross-attention (network_MMG.py:228-234) has no mask, so every
+    2D edge attends to the 3D edges of the WHOLE batch.  The 3D outputs equal the per-scene ones; the 2D outputs do
+    not.  validation() never does this (batch_size=1); kept as the `reference batch` compatibility mode."""
+    bid = batch_ids.view(-1)
+    e_scene = bid[edge_indices[0]]
+    sc = []
+    for s in torch.unique_consecutive(bid).tolist():
+        nodes = torch.nonzero(bid == s).view(-1)
+        lo, hi = int(nodes[0]), int(nodes[-1]) + 1
+        eids = torch.nonzero(e_scene == s).view(-1)
+        ei = edge_indices[:, eids] - lo
+        d = descriptor[lo:hi]
+        x3 = node_embed(pointnet_feat(obj_points[lo:hi], w, "obj_encoder"), d, w)
+        ed = edge_descriptor(d, ei)
+        sc.append(dict(eids=eids, ei=ei, x3=x3, x2=adapter(obj_2d_feats[lo:hi], w),
+                       e2=pointnet_feat(ed[:, :, None], w, "rel_encoder_2d"),
+                       e3=pointnet_feat(ed[:, :, None], w, "rel_encoder_3d"), bias=distance_bias(d[:, :3], w)))
+    L, H = cfg.N_LAYERS, cfg.NUM_HEADS
+    for l in range(L):
+        for c in sc:
+            c["x3"] = mha(c["x3"], c["x3"], w, f"mmg.self_attn.{l}", H, c["bias"])
+            c["x2"] = mha(c["x2"], c["x3"], w, f"mmg.cross_attn.{l}", H, c["bias"])
+            c["x3"], c["e3"] = gcn_layer(c["x3"], c["e3"], c["ei"], w, f"mmg.gcn_3ds.{l}", H, cfg.GCN_AGGR)
+            c["x2"], c["e2"] = gcn_layer(c["x2"], c["e2"], c["ei"], w, f"mmg.gcn_2ds.{l}", H, cfg.GCN_AGGR)
+        e2_all = mha(torch.cat([c["e2"] for c in sc]), torch.cat([c["e3"] for c in sc]), w, f"mmg.cross_attn_rel.{l}", H)
+        o = 0
+        for c in sc:
+            n = c["e2"].shape[0]
+            c["e2"] = e2_all[o:o + n]
+            o += n
+            if l < L - 1 or L == 1:
+                c["x3"], c["x2"], c["e3"], c["e2"] = (torch.relu(c[k]) for k in ("x3", "x2", "e3", "e2"))
+    multi = bool(getattr(cfg, "multi_rel_outputs", True))
+    obj3 = torch.cat([obj_head(c["x3"], w, "obj_predictor_3d", cfg.obj_logit_scale) for c in sc])
+    obj2 = torch.cat([obj_head(c["x2"], w, "obj_predictor_2d", cfg.obj_logit_scale) for c in sc])
+    order = torch.cat([c["eids"] for c in sc])
+    r3 = torch.cat([rel_head(c["e3"], w, "rel_predictor_3d", multi) for c in sc])
+    r2 = torch.cat([rel_head(c["e2"], w, "rel_predictor_2d", multi) for c in sc])
+    rel3, rel2 = torch.empty_like(r3), torch.empty_like(r2)
+    rel3[order] = r3
+    rel2[order] = r2
+    return obj3, obj2, rel3, rel2
+
+
 def to_torch(weights_np: dict, dtype=torch.float32) -> W:
     return {k: torch.from_numpy(v).to(dtype) for k, v in weights_np.items()}

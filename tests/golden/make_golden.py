@@ -237,6 +237,8 @@ def main():
     bb = run(m, synth.collate(scenes))
     cat["batched_obj3d"] = bb["obj3d"]
     cat["batched_rel3d"] = bb["rel3d"]
+    cat["batched_obj2d"] = bb["obj2d"]          # differ from the per-scene ones: the edge cross-attention of a
+    cat["batched_rel2d"] = bb["rel2d"]          # multi-scene call is not masked per scene
     np.savez(os.path.join(HERE, "ragged_n5_n7_p64_l2.npz"), **cat)
 
     # ---- general (non fully-connected, unsorted, with empty source segments) edge list,

@@ -134,6 +134,24 @@ def test_ragged_batch_golden(golden_dir):
     _check(got, [z[n] for n in NAMES], TIGHT, "ragged 2-scene batch vs per-scene reference")
 
 
+def test_reference_batch_mode_golden(golden_dir):
+    """set_batch_mode('reference'): the multi-scene call exactly as Mmgnet.forward computes it (edge cross-attention
+    over the whole batch) against the real reference's batched call; switching back restores the
+    per-scene contract."""
+    from vlsat_amd.model import VLSATModel
+    cfg = VLSATConfig(N_LAYERS=2)
+    b = synth.collate([synth.make_scene(5, 64, 2000), synth.make_scene(7, 64, 2001)])
+    z = np.load(os.path.join(golden_dir, "ragged_n5_n7_p64_l2.npz"))
+    m = VLSATModel(cfg, DEV).load_state(synth.make_weights(cfg)).eval()
+    d = _dev(b)
+    call = lambda: [o.cpu() for o in m(d["obj_points"], d["obj_2d_feats"], d["edge_indices"], d["descriptor"], d["batch_ids"])]
+    m.set_batch_mode("reference")
+    _check(call(), [z["batched_" + n] for n in NAMES], TIGHT, "reference batch mode vs the reference's batched call")
+    m.set_batch_mode("per_scene")
+    _check(call(), [z[n] for n in NAMES], TIGHT, "back to per-scene")
+    m.close()
+
+
 @pytest.mark.parametrize("aggr", ["max", "add", "mean"])
 def test_general_edges_golden(golden_dir, aggr):
     """Non fully-connected, unsorted edge list with an empty source segment; L=1 (ReLU applies)."""

@@ -100,6 +100,20 @@ def test_general_edges_all_aggregators(golden_dir, aggr):
         _close(o, z[f"{aggr}.{name}"], name=f"{aggr}.{name}")
 
 
+def test_cross_scene_batch_call_of_the_reference(golden_dir):
+    """One reference call carrying two scenes: the edge cross-attention spans the whole batch, so the 2D
+    outputs differ from the per-scene ones; the 3D outputs do not."""
+    z = np.load(os.path.join(golden_dir, "ragged_n5_n7_p64_l2.npz"))
+    cfg = VLSATConfig(N_LAYERS=2)
+    w = O.to_torch(synth.make_weights(cfg))
+    b = _t(synth.collate([synth.make_scene(5, 64, 2000), synth.make_scene(7, 64, 2001)]))
+    out = O.forward_cross_scene(w, cfg, b["obj_points"], b["obj_2d_feats"], b["edge_indices"], b["descriptor"], b["batch_ids"])
+    for name, o in zip(("batched_obj3d", "batched_obj2d", "batched_rel3d", "batched_rel2d"), out):
+        _close(o, z[name], name=name)
+    assert float(np.abs(z["batched_rel2d"] - z["rel2d"]).max()) > 1e-3          # the two contracts really differ
+    _close(out[0], z["obj3d"], name="3D branch is batch-independent")
+
+
 @pytest.mark.parametrize("case", sorted(synth.SWITCH_CASES))
 def test_config_switches(golden_dir, case):
     """WITH_BN / USE_GCN_EDGE=false / multi_rel_outputs=false / USE_RGB+USE_NORMAL (SURVEY 8a switch table) against
