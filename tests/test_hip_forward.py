@@ -176,6 +176,28 @@ def test_config_switches_golden(golden_dir, case):
     _check(got, run_oracle(cfg, b), TIGHT, f"{case} vs oracle")
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_random_graphs_vs_oracle(seed):
+    """Randomised batches: 1..5 scenes of 1..11 objects, random point counts, arbitrary edge lists (random subsets of
+    all ordered pairs INCLUDING self loops and duplicate edges, in random order across scenes), all three aggregators."""
+    g = np.random.default_rng(100 + seed)
+    cfg = VLSATConfig(N_LAYERS=int(g.integers(1, 4)), GCN_AGGR=("max", "add", "mean")[seed % 3])
+    n_pts = int(g.integers(2, 130))              # >= 2: the descriptor's unbiased std needs two points
+    scenes = []
+    for s in range(int(g.integers(1, 6))):
+        n = int(g.integers(1, 12))
+        sc = synth.make_scene(n, n_pts, 9000 + 10 * seed + s)
+        pairs = np.stack(np.meshgrid(np.arange(n), np.arange(n), indexing="ij"), 0).reshape(2, -1)      # with self loops
+        k = int(g.integers(0, pairs.shape[1] + 3))
+        pick = g.integers(0, pairs.shape[1], k) if k else np.zeros(0, np.int64)                          # with duplicates
+        sc["edge_indices"] = np.ascontiguousarray(pairs[:, pick]).astype(np.int64).reshape(2, -1)
+        scenes.append(sc)
+    b = synth.collate(scenes)
+    perm = g.permutation(b["edge_indices"].shape[1])
+    b["edge_indices"] = np.ascontiguousarray(b["edge_indices"][:, perm])
+    _check(run_hip(cfg, b), run_oracle(cfg, b), TIGHT, f"random graph batch #{seed} ({len(scenes)} scenes, E={len(perm)})")
+
+
 def test_edges_interleaved_across_scenes():
     """Edges not grouped by scene: the glue permutes them (VLSAT_EGRAPH path) and un-permutes
     the relation outputs."""
