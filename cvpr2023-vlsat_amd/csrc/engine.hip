@@ -52,6 +52,7 @@ using namespace vlsat;
 
 struct vlsat_ctx {
     VlsatDims d{};
+    int fa_split = 1;        // allow the split-key edge attention for small plans (VLSAT_FLASH_SPLIT=0 disables)
     int edge_scope = 0;      // edge cross-attention keys: 0 = the query's scene, 1 = the whole batch (vlsat_set_edge_attention_scope)
     int D = 512, A = 256, H = 8, C_pt = 768;
     std::map<std::string, std::vector<float>> host;   // raw reference-layout tensors
@@ -102,6 +103,10 @@ struct vlsat_plan_s {
     int64_t* d_bias_ptr;
     int4* d_tiles;
     int n_tiles = 0;
+    // split-key mode of the edge attention for plans with too few blocks to fill the chip (flash_attn_f32.hip)
+    int fa_parts = 1;
+    int4* d_krange = nullptr;
+    float *fa_opart = nullptr, *fa_m = nullptr, *fa_l = nullptr;
     double flash_flops = 0;
     // device float buffers
     float *F, *X3, *X2, *NP, *QKVn, *On, *T256, *T768, *rs, *bias;
@@ -410,6 +415,7 @@ int vlsat_create(const VlsatDims* d, vlsat_handle* out) {
     auto* h = new (std::nothrow) vlsat_ctx();
     if (!h) return fail(VLSAT_ENOMEM, "out of host memory");
     h->d = *d;
+    if (const char* e = getenv("VLSAT_FLASH_SPLIT")) h->fa_split = atoi(e);
     *out = h;
     return 0;
 }
@@ -621,6 +627,26 @@ int vlsat_plan_create(vlsat_handle h, const int64_t* bid, const int64_t* edges, 
         bias_ptr[s] = bias_total;
         bias_total += (int64_t)h->H * n * n;
     }
+    // Few blocks (one scene alone: ceil(T/128)*8 ~ 100 for 256 CUs): cut every block's key range into `parts`
+    // pieces so that about two rounds of 512 resident blocks exist; each piece keeps at least two key tiles.
+    std::vector<int4> krange;
+    if (!tiles.empty() && tiles.size() < 512 && h->fa_split) {
+        int parts = (int)std::min<size_t>(16, 1024 / tiles.size());
+        if (parts > 1) {
+            std::vector<int4> split;
+            for (const int4& t : tiles) {
+                const int kt = (t.y + 31) / 32;
+                const int ps = std::max(1, std::min(parts, kt / 2));          // parts actually used by this scene
+                for (int q = 0; q < parts; ++q) {
+                    split.push_back(t);
+                    const int a = q < ps ? (int)((int64_t)kt * q / ps) : 0, b = q < ps ? (int)((int64_t)kt * (q + 1) / ps) : 0;
+                    krange.push_back(make_int4(a, b, q, 0));
+                }
+            }
+            tiles.swap(split);
+            p->fa_parts = parts;
+        }
+    }
     p->n_tiles = (int)tiles.size();
     // ---- one device arena ----
     const size_t Ns = (size_t)N, Es = (size_t)std::max<int64_t>(E, 1);
@@ -635,6 +661,11 @@ int vlsat_plan_create(vlsat_handle h, const int64_t* bid, const int64_t* edges, 
     want(&p->H1, Es * 128); want(&p->H2, Es * 128); want(&p->E3, Es * 512); want(&p->E2, Es * 512);
     want(&p->Hbig, Es * 1024); want(&p->KP, Es * 512); want(&p->G, Es * 256);
     want(&p->Qe, Es * 512); want(&p->KVe, Es * 1024); want(&p->Oe, Es * 512);
+    if (p->fa_parts > 1) {
+        want(&p->d_krange, krange.size());
+        want(&p->fa_opart, (size_t)p->fa_parts * Es * 512);
+        want(&p->fa_m, (size_t)p->fa_parts * Es * h->H); want(&p->fa_l, (size_t)p->fa_parts * Es * h->H);
+    }
     size_t total = 0;
     for (auto& it : items) total += (it.bytes + 255) & ~size_t(255);
     {   // smallest pooled arena that fits (and is not absurdly larger), else a fresh allocation
@@ -668,6 +699,7 @@ int vlsat_plan_create(vlsat_handle h, const int64_t* bid, const int64_t* edges, 
         if (er == hipSuccess) er = cp(p->d_dst, dst.data(), E * 4);
         if (er == hipSuccess) er = cp(p->d_order, order.data(), E * 4);
         if (er == hipSuccess && !tiles.empty()) er = cp(p->d_tiles, tiles.data(), tiles.size() * sizeof(int4));
+        if (er == hipSuccess && !krange.empty()) er = cp(p->d_krange, krange.data(), krange.size() * sizeof(int4));
     }
     if (er == hipSuccess) er = cp(p->d_rowptr, rowptr.data(), (N + 1) * 4);
     if (er == hipSuccess) er = cp(p->d_scene_ptr, p->node_ptr.data(), (p->S + 1) * 4);
@@ -833,8 +865,11 @@ int vlsat_forward(vlsat_handle h, vlsat_plan p, const float* pts, const float* f
             RUN(gemm(h, s, G(p->E3, D, w.wkv, D, p->KVe, 2 * D, E, 2 * D, w.bkv)));
             {
                 Scope sc(h, s, PC_FLASH, p->flash_flops);
+                FlashSplit sp;
+                sp.parts = p->fa_parts; sp.krange = p->d_krange; sp.o_part = p->fa_opart; sp.m_part = p->fa_m;
+                sp.l_part = p->fa_l; sp.part_stride = (size_t)E * D; sp.rows = E; sp.heads = h->H;
                 RUN(launch_flash_attn(p->Qe, D, p->KVe, p->KVe + D, 2 * D, p->Oe, D, p->d_tiles, p->n_tiles,
-                                      0.125f * 1.4426950408889634f, s));
+                                      0.125f * 1.4426950408889634f, s, &sp));
             }
             GemmArgs o = G(p->Oe, D, w.wo, D, p->E2, D, E, D, w.bo);
             o.resid = p->E2; o.ldr = D;

@@ -17,6 +17,10 @@
 //   online softmax with running (m, l) per query, exp2 with log2(e) folded into the scale.
 // K/V tiles are double-buffered in LDS via register staging; one barrier per key tile
 // (64 MFMAs = 4096 cycles per wave between barriers).
+// Split keys (small problems): one scene alone gives only ceil(T/128)*8 ~ 100 blocks for 256 CUs and a lone block
+// runs at ~27 % of a CU's matrix rate, so when a plan has fewer than 512 blocks the key range of every
+// (query tile, head) is cut into `parts` pieces, each block writes its un-normalised O plus (m, l) per query, and
+// flash_merge_kernel combines them (flash-decoding).  393 -> ~100 us per call at T ~ 2000.
 // Roofline: fp32 MFMA.  Algorithmic work 4*T^2*64 flop per (scene, head); HBM traffic is
 // Q,O once and K,V re-read once per 128-query block out of L2 (K,V of one scene-head =
 // T*64*4*2 B, 0.8 MB at T=1560): the same-scene blocks are made consecutive on one XCD.
@@ -32,12 +36,15 @@ constexpr int FA_PITCH = 68;     // LDS row pitch (floats): 16-B pad -> conflict
 __global__ __launch_bounds__(256, 2) void flash_attn_f32_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
     float* __restrict__ O, int ldq, int ldkv, int ldo, const int4* __restrict__ tiles, int n_tiles,
-    float scale_log2e) {
+    float scale_log2e, FlashSplit sp) {
     __shared__ __attribute__((aligned(16))) float smem[2 * 2 * FA_KV * FA_PITCH];   // [buf][K|V][32][68]
     constexpr int BUF = 2 * FA_KV * FA_PITCH;
 
-    const int4 t = tiles[xcd_remap(blockIdx.x, n_tiles)];
+    const int tile_id = xcd_remap(blockIdx.x, n_tiles);
+    const int4 t = tiles[tile_id];
     const int row_base = t.x, n_tok = t.y, q0 = t.z, head = t.w;
+    // split mode: sp.krange[tile] = {first key tile, end key tile, part, -}
+    const int4 kr = sp.parts > 1 ? sp.krange[tile_id] : make_int4(0, (n_tok + FA_KV - 1) / FA_KV, 0, 0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, hi = lane >> 5;
     const size_t col0 = (size_t)head * FA_D;
@@ -87,14 +94,17 @@ __global__ __launch_bounds__(256, 2) void flash_attn_f32_kernel(
     };
 
     const int n_kv_tiles = (n_tok + FA_KV - 1) / FA_KV;
-    load_tile(0);
-    store_tile(smem);
+    const int kt0 = kr.x, kt1 = kr.y;
+    if (kt0 < kt1) {
+        load_tile(kt0 * FA_KV);
+        store_tile(smem + (kt0 & 1) * BUF);
+    }
     __syncthreads();
 
-    for (int kt = 0; kt < n_kv_tiles; ++kt) {
+    for (int kt = kt0; kt < kt1; ++kt) {
         const float* sK = smem + (kt & 1) * BUF;
         const float* sV = sK + FA_KV * FA_PITCH;
-        const bool more = kt + 1 < n_kv_tiles;
+        const bool more = kt + 1 < kt1;
         if (more) load_tile((kt + 1) * FA_KV);
 
         if (wave_active) {
@@ -146,8 +156,19 @@ __global__ __launch_bounds__(256, 2) void flash_attn_f32_kernel(
         __syncthreads();
     }
 
-    // ---- normalise, transpose through LDS (wave-private [32 q][68]), coalesced store ----
-    const float inv_l = 1.f / l_run;
+    // ---- normalise (or, in split mode, keep un-normalised and record m, l), transpose through LDS
+    //      (wave-private [32 q][68]), coalesced store ----
+    const bool split = sp.parts > 1;
+    const float inv_l = split ? 1.f : 1.f / l_run;
+    if (split) {
+        O = sp.o_part + (size_t)kr.z * sp.part_stride;
+        const int qr = q0 + wave * 32 + li;
+        if (hi == 0 && qr < n_tok) {
+            const size_t i = ((size_t)kr.z * sp.rows + row_base + qr) * sp.heads + head;
+            sp.m_part[i] = m_run;
+            sp.l_part[i] = l_run;
+        }
+    }
     float* so = smem + wave * (32 * FA_PITCH);     // 4 x 8704 B = all of smem
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -166,13 +187,51 @@ __global__ __launch_bounds__(256, 2) void flash_attn_f32_kernel(
     }
 }
 
+// O[row, h*64 + d] = sum_p 2^(m_p - m) O_p[row, h*64 + d] / sum_p 2^(m_p - m) l_p,  m = max_p m_p  (per row, head)
+__global__ __launch_bounds__(256) void flash_merge_kernel(float* __restrict__ O, int ldo, FlashSplit sp) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;       // one float4 of one row
+    const int per_row = sp.heads * (FA_D / 4);
+    const size_t row = idx / per_row;
+    if (row >= (size_t)sp.rows) return;
+    const int c4 = (int)(idx % per_row), head = c4 / (FA_D / 4);
+    float m = -INFINITY;
+    for (int p = 0; p < sp.parts; ++p) m = fmaxf(m, sp.m_part[((size_t)p * sp.rows + row) * sp.heads + head]);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float den = 0.f;
+    for (int p = 0; p < sp.parts; ++p) {
+        const size_t i = ((size_t)p * sp.rows + row) * sp.heads + head;
+        const float w = __builtin_amdgcn_exp2f(sp.m_part[i] - m);
+        if (w > 0.f) {                                   // an empty part has m = -inf: its O slot was never written
+            den += w * sp.l_part[i];
+            const f32x4 o = *reinterpret_cast<const f32x4*>(sp.o_part + (size_t)p * sp.part_stride + row * ldo + c4 * 4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] += w * o[c];
+        }
+    }
+    const float inv = 1.f / den;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] *= inv;
+    *reinterpret_cast<f32x4*>(O + row * ldo + c4 * 4) = acc;
+}
+
 int launch_flash_attn(const float* Q, int ldq, const float* K, const float* V, int ldkv, float* O, int ldo,
-                      const int4* tiles, int n_tiles, float scale_log2e, hipStream_t s) {
+                      const int4* tiles, int n_tiles, float scale_log2e, hipStream_t s, const FlashSplit* split) {
     if (n_tiles <= 0) return 0;
     if ((ldq | ldkv | ldo) & 3) return fail(-1, "flash_attn: leading dims must be multiples of 4");
+    FlashSplit sp{};
+    if (split && split->parts > 1) {
+        sp = *split;
+        if (!sp.krange || !sp.o_part || !sp.m_part || !sp.l_part || sp.heads * FA_D > ldo)
+            return fail(-1, "flash_attn: incomplete split-key workspace");
+    }
     hipLaunchKernelGGL(flash_attn_f32_kernel, dim3(n_tiles), dim3(256), 0, s, Q, K, V, O, ldq, ldkv, ldo, tiles,
-                       n_tiles, scale_log2e);
+                       n_tiles, scale_log2e, sp);
     VLSAT_LAUNCH_CHECK("flash_attn_f32");
+    if (sp.parts > 1) {
+        const size_t n4 = (size_t)sp.rows * sp.heads * (FA_D / 4);
+        hipLaunchKernelGGL(flash_merge_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, O, ldo, sp);
+        VLSAT_LAUNCH_CHECK("flash_merge");
+    }
     return 0;
 }
 

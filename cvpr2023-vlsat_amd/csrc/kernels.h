@@ -43,8 +43,18 @@ int launch_pointnet(const float* pts, int n_obj, int n_points, int cin, const fl
 
 // ---- edge cross-attention (flash style, fp32 MFMA) ----
 // tiles: device array of int4 {row_base, n_tokens, q0, head}; one block per entry.
+// Split-key mode (plans with too few blocks to fill the chip): tile i covers key tiles [krange[i].x, krange[i].y)
+// as part krange[i].z of `parts`; partial results go to o_part [parts][rows][ldo] (un-normalised), m_part / l_part
+// [parts][rows][heads]; a merge kernel writes O.  A tile with an empty key range records m = -inf, l = 0.
+struct FlashSplit {
+    int parts = 1;
+    const int4* krange = nullptr;
+    float* o_part = nullptr; float* m_part = nullptr; float* l_part = nullptr;
+    size_t part_stride = 0;      // floats between parts of o_part (= rows * ldo)
+    int rows = 0, heads = 0;
+};
 int launch_flash_attn(const float* Q, int ldq, const float* K, const float* V, int ldkv, float* O, int ldo,
-                      const int4* tiles, int n_tiles, float scale_log2e, hipStream_t s);
+                      const int4* tiles, int n_tiles, float scale_log2e, hipStream_t s, const FlashSplit* split = nullptr);
 constexpr int FLASH_BQ = 128;   // queries per block
 
 // ---- node attention with distance bias (per scene, per head) ----
