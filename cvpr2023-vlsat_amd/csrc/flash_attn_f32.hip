@@ -142,8 +142,12 @@ __global__ __launch_bounds__(256, 2) void flash_attn_f32_kernel(
         rs += __shfl_xor(rs, 32);
         l_run = l_run * alpha + rs;
         m_run = m_new;
+        // rescale the running output only when some query's maximum moved (alpha == 1 exactly otherwise: after the
+        // first few key tiles this skips 32 multiplies per tile for the whole wave without changing a bit)
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+        }
         // ---- O^T[d][query] += sum_key V[key][d] * P[key][query] ----
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
