@@ -36,15 +36,32 @@ def fields(n_rel: int = N_REL):
     return f
 
 
+_IDX_CACHE: Dict[int, Dict[str, int]] = {}
+
+
+def _index(n_rel: int) -> Dict[str, int]:
+    if n_rel not in _IDX_CACHE:
+        _IDX_CACHE[n_rel] = {k: i for i, k in enumerate(fields(n_rel))}
+    return _IDX_CACHE[n_rel]
+
+
 def accumulate(vec: np.ndarray, ranks: Dict[str, np.ndarray], cls_matrix: np.ndarray, n_scenes: int, n_rel: int = N_REL):
-    """Add one batch's rank arrays (process_val outputs) into the counts vector (in place)."""
-    idx = {k: i for i, k in enumerate(fields(n_rel))}
+    """Add one batch's rank arrays (process_val outputs) into the counts vector (in place).  Histogram form
+    (bincount per predicate class) of the per-class loops of get_mean_recall / compute_mean_predicate."""
+    idx = _index(n_rel)
     vec[idx["scenes"]] += n_scenes
-    pred = cls_matrix[:, -1] if len(cls_matrix) else np.zeros(0, dtype=np.int64)
-    for k in range(1, n_rel + 1):
-        vec[idx[f"cm_ge{k}"]] += int((cls_matrix >= k).sum()) if len(cls_matrix) else 0
+    cm = np.asarray(cls_matrix, dtype=np.int64).reshape(-1, 5) if len(cls_matrix) else np.zeros((0, 5), np.int64)
+    pred = cm[:, -1]
+    if len(cm):                                      # #entries >= k for k = 1..n_rel, from one histogram of the matrix
+        h = np.bincount(np.clip(cm.ravel(), 0, n_rel), minlength=n_rel + 1)
+        ge = np.cumsum(h[::-1])[::-1]                # ge[k] = #entries >= k (entries above n_rel were clipped to n_rel)
+        for k in range(1, n_rel + 1):
+            vec[idx[f"cm_ge{k}"]] += int(ge[k])
+    has = pred >= 0
+    pc = pred[has]
     for br, o, r, t in (("3d", ranks["top_k_obj"], ranks["top_k_rel"], ranks["top_k_triplet"]),
                         ("2d", ranks["top_k_obj_2d"], ranks["top_k_rel_2d"], ranks["top_k_triplet_2d"])):
+        o, r, t = np.asarray(o), np.asarray(r), np.asarray(t)
         vec[idx[f"obj_n_{br}"]] += len(o)
         vec[idx[f"rel_n_{br}"]] += len(r)
         vec[idx[f"tri_n_{br}"]] += len(t)
@@ -54,21 +71,24 @@ def accumulate(vec: np.ndarray, ranks: Dict[str, np.ndarray], cls_matrix: np.nda
             vec[idx[f"rel_hit@{k}_{br}"]] += int((r <= k).sum())
         for k in _TRI_K:
             vec[idx[f"tri_hit@{k}_{br}"]] += int((t <= k).sum())
-        for c in range(n_rel):                       # rows of cls_matrix align with the rank lists entry by entry
-            sel = pred == c
-            if not sel.any():
+        # rows of cls_matrix align with the rank lists entry by entry; predicate -1 = "no relation" rows
+        n_c = np.bincount(pc, minlength=n_rel)
+        tri_c = {k: np.bincount(pc, weights=(t[has] <= k), minlength=n_rel) for k in _TRI_K}
+        rel_c = {k: np.bincount(pc, weights=(r[has] <= k), minlength=n_rel) for k in _REL_K}
+        for c in np.nonzero(n_c)[0]:
+            if c >= n_rel:
                 continue
-            vec[idx[f"cls{c}_n_{br}"]] += int(sel.sum())
+            vec[idx[f"cls{c}_n_{br}"]] += int(n_c[c])
             for k in _TRI_K:
-                vec[idx[f"cls{c}_tri@{k}_{br}"]] += int((t[sel] <= k).sum())
+                vec[idx[f"cls{c}_tri@{k}_{br}"]] += int(tri_c[k][c])
             for k in _REL_K:
-                vec[idx[f"cls{c}_rel@{k}_{br}"]] += int((r[sel] <= k).sum())
+                vec[idx[f"cls{c}_rel@{k}_{br}"]] += int(rel_c[k][c])
     return vec
 
 
 def summarize(vec: np.ndarray, n_rel: int = N_REL) -> Dict[str, float]:
     """Percentages validation() prints, from the (all-reduced) counts."""
-    idx = {k: i for i, k in enumerate(fields(n_rel))}
+    idx = _index(n_rel)
     out = {"scenes": float(vec[idx["scenes"]])}
     for br in ("3d", "2d"):
         for name, ks in (("obj", _OBJ_K), ("rel", _REL_K), ("tri", _TRI_K)):
