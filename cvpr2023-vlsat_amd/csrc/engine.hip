@@ -52,6 +52,9 @@ using namespace vlsat;
 
 struct vlsat_ctx {
     VlsatDims d{};
+    int dual_stream = 1;     // run the 2D twin stages of small plans on a second stream (VLSAT_DUAL_STREAM=0 disables)
+    hipStream_t side = nullptr;
+    std::vector<hipEvent_t> sync_ev;     // fork/join events (timing disabled), created on first use
     int fa_split = 1;        // allow the split-key edge attention for small plans (VLSAT_FLASH_SPLIT=0 disables)
     int edge_scope = 0;      // edge cross-attention keys: 0 = the query's scene, 1 = the whole batch (vlsat_set_edge_attention_scope)
     int D = 512, A = 256, H = 8, C_pt = 768;
@@ -111,7 +114,20 @@ struct vlsat_plan_s {
     // device float buffers
     float *F, *X3, *X2, *NP, *QKVn, *On, *T256, *T768, *rs, *bias;
     float *H1, *H2, *E3, *E2, *Hbig, *KP, *G, *Qe, *KVe, *Oe, *R1, *R2, *prob;
+    // Small plans (launch-bound: one scene per call) run the 2D twin of every stage -- relation encoder, adapter,
+    // gcn_2ds, the query projection of the edge attention, the 2D heads -- on a second stream, concurrently with
+    // the 3D twin.  The twins never touch each other's tensors; they only shared scratch, so the 2D side gets its own.
+    bool dual = false;
+    float *NP2 = nullptr, *Hbig2 = nullptr, *KP2 = nullptr, *G2 = nullptr, *T768b = nullptr, *rs2 = nullptr, *H2b = nullptr;
 };
+
+// scratch buffers of one modality branch
+struct Scratch { float *NP, *Hbig, *KP, *G, *T768, *R1, *R2, *rs, *H2; };
+static Scratch scratch_of(const vlsat_plan_s* p, int branch) {
+    if (branch == 1 && p->dual)
+        return {p->NP2, p->Hbig2, p->KP2, p->G2, p->T768b, p->Hbig2, p->Hbig2 + (size_t)std::max<int64_t>(p->E, 1) * 512, p->rs2, p->H2b};
+    return {p->NP, p->Hbig, p->KP, p->G, p->T768, p->R1, p->R2, p->rs, p->H2};
+}
 
 namespace {
 
@@ -338,60 +354,62 @@ int attn_block(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const AttnW& w, flo
 }
 
 int gcn_block(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const GcnW& w, float* x, float* e, int e_relu_pending,
-              int out_relu) {
+              int out_relu, const Scratch& sc) {
     const int N = (int)p->N, E = (int)p->E, D = h->D, A = h->A, LDX = 768, NPC = 3328;
-    RUN(gemm(h, s, G(x, LDX, w.wnode, D, p->NP, NPC, N, NPC, w.bnode)));
-    GemmArgs e1 = G(e, D, w.we1, D, p->Hbig, 2 * D, E, 2 * D, nullptr, ACT_RELU);
+    RUN(gemm(h, s, G(x, LDX, w.wnode, D, sc.NP, NPC, N, NPC, w.bnode)));
+    GemmArgs e1 = G(e, D, w.we1, D, sc.Hbig, 2 * D, E, 2 * D, nullptr, ACT_RELU);
     e1.relu_a = e_relu_pending;
-    e1.g0 = p->NP; e1.gi0 = p->d_src; e1.ldg0 = NPC;
-    e1.g1 = p->NP + 2 * D; e1.gi1 = p->d_dst; e1.ldg1 = NPC;
+    e1.g0 = sc.NP; e1.gi0 = p->d_src; e1.ldg0 = NPC;
+    e1.g1 = sc.NP + 2 * D; e1.gi1 = p->d_dst; e1.ldg1 = NPC;
     RUN(gemm(h, s, e1));
     if (h->d.use_gcn_edge) {              // proj_edge feeds only the gate MLP (reference network_MMG.py:98-102)
-        GemmArgs kp = G(e, D, w.wpe, D, p->KP, D, E, D, w.bpe);
+        GemmArgs kp = G(e, D, w.wpe, D, sc.KP, D, E, D, w.bpe);
         kp.relu_a = e_relu_pending;
         RUN(gemm(h, s, kp));
     }
-    RUN(gemm(h, s, G(p->Hbig, 2 * D, w.we2, 2 * D, e, D, E, D, w.be2)));   // e <- nn_edge output (pre-activation)
+    RUN(gemm(h, s, G(sc.Hbig, 2 * D, w.we2, 2 * D, e, D, E, D, w.be2)));   // e <- nn_edge output (pre-activation)
     {
         GateArgs g{};
-        g.kproj = p->KP; g.node = p->NP; g.ld_node = NPC; g.gq_off = 4 * D; g.v_off = 4 * D + h->H * 128;
-        g.src = p->d_src; g.dst = p->d_dst; g.w0k = w.w0k; g.w3 = w.w3; g.b3 = w.b3; g.gated = p->G;
+        g.kproj = sc.KP; g.node = sc.NP; g.ld_node = NPC; g.gq_off = 4 * D; g.v_off = 4 * D + h->H * 128;
+        g.src = p->d_src; g.dst = p->d_dst; g.w0k = w.w0k; g.w3 = w.w3; g.b3 = w.b3; g.gated = sc.G;
         g.prob = p->prob; g.n_edges = E; g.use_edge = h->d.use_gcn_edge;
-        Scope sc(h, s, PC_GATE, (double)E * h->H * (2.0 * 64 * 128 + 2.0 * 128 * 32));
+        Scope scope(h, s, PC_GATE, (double)E * h->H * (2.0 * 64 * 128 + 2.0 * 128 * 32));
         RUN(launch_edge_gate(g, s));
     }
     {
-        Scope sc(h, s, PC_AGGREGATE, 0);
-        RUN(launch_aggregate(p->G, A, p->d_rowptr, p->d_order, N, h->d.gcn_aggr, x, LDX, D, s));
+        Scope scope(h, s, PC_AGGREGATE, 0);
+        RUN(launch_aggregate(sc.G, A, p->d_rowptr, p->d_order, N, h->d.gcn_aggr, x, LDX, D, s));
     }
-    RUN(gemm(h, s, G(x, LDX, w.wp0, D + A, p->T768, D + A, N, D + A, w.bp0, ACT_RELU)));
-    RUN(gemm(h, s, G(p->T768, D + A, w.wp2, D + A, x, LDX, N, D, w.bp2, out_relu ? ACT_RELU : ACT_NONE)));
+    RUN(gemm(h, s, G(x, LDX, w.wp0, D + A, sc.T768, D + A, N, D + A, w.bp0, ACT_RELU)));
+    RUN(gemm(h, s, G(sc.T768, D + A, w.wp2, D + A, x, LDX, N, D, w.bp2, out_relu ? ACT_RELU : ACT_NONE)));
     return 0;
 }
 
-int rel_head(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const RelHeadW& w, const float* e, int relu_a, float* out) {
+int rel_head(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const RelHeadW& w, const float* e, int relu_a, float* out,
+             const Scratch& sc) {
     const int E = (int)p->E, D = h->D, R = h->d.n_rel_class;
-    GemmArgs a = G(e, D, w.w1, D, p->R1, 512, E, 512, w.b1, ACT_RELU);
+    GemmArgs a = G(e, D, w.w1, D, sc.R1, 512, E, 512, w.b1, ACT_RELU);
     a.relu_a = relu_a;
     RUN(gemm(h, s, a));
-    RUN(gemm(h, s, G(p->R1, 512, w.w2, 512, p->R2, 256, E, 256, w.b2, ACT_RELU)));
+    RUN(gemm(h, s, G(sc.R1, 512, w.w2, 512, sc.R2, 256, E, 256, w.b2, ACT_RELU)));
     // multi_rel_outputs: sigmoid (PointNetRelClsMulti) or log_softmax over the R classes (PointNetRelCls)
-    RUN(gemm(h, s, G(p->R2, 256, w.w3, 256, out, R, E, R, w.b3, h->d.multi_rel_outputs ? ACT_SIGMOID : ACT_NONE)));
+    RUN(gemm(h, s, G(sc.R2, 256, w.w3, 256, out, R, E, R, w.b3, h->d.multi_rel_outputs ? ACT_SIGMOID : ACT_NONE)));
     if (!h->d.multi_rel_outputs) {
-        Scope sc(h, s, PC_MISC, 0);
+        Scope scope(h, s, PC_MISC, 0);
         RUN(launch_softmax_rows(out, R, E, R, out, 1, s));
     }
     return 0;
 }
 
-int obj_head(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const float* x, const float* w, const float* b, float* out) {
+int obj_head(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const float* x, const float* w, const float* b, float* out,
+             const Scratch& sc) {
     const int N = (int)p->N, D = h->D, C = h->d.n_obj_class;
     {
-        Scope sc(h, s, PC_MISC, 0);
-        RUN(launch_row_invnorm(x, 768, N, D, std::exp(h->d.obj_logit_scale), p->rs, s));
+        Scope scope(h, s, PC_MISC, 0);
+        RUN(launch_row_invnorm(x, 768, N, D, std::exp(h->d.obj_logit_scale), sc.rs, s));
     }
     GemmArgs a = G(x, 768, w, D, out, C, N, C, b);
-    a.rowscale = p->rs;
+    a.rowscale = sc.rs;
     RUN(gemm(h, s, a));
     return 0;
 }
@@ -416,6 +434,7 @@ int vlsat_create(const VlsatDims* d, vlsat_handle* out) {
     if (!h) return fail(VLSAT_ENOMEM, "out of host memory");
     h->d = *d;
     if (const char* e = getenv("VLSAT_FLASH_SPLIT")) h->fa_split = atoi(e);
+    if (const char* e = getenv("VLSAT_DUAL_STREAM")) h->dual_stream = atoi(e);
     *out = h;
     return 0;
 }
@@ -426,6 +445,8 @@ void vlsat_destroy(vlsat_handle h) {
     for (auto& a : h->arena_pool) hipFree(a.first);
     for (auto& kv : h->split) { hipFree(kv.second.first); hipFree(kv.second.second); }
     for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
+    for (hipEvent_t e : h->sync_ev) hipEventDestroy(e);
+    if (h->side) hipStreamDestroy(h->side);
     delete h;
 }
 
@@ -661,6 +682,12 @@ int vlsat_plan_create(vlsat_handle h, const int64_t* bid, const int64_t* edges, 
     want(&p->H1, Es * 128); want(&p->H2, Es * 128); want(&p->E3, Es * 512); want(&p->E2, Es * 512);
     want(&p->Hbig, Es * 1024); want(&p->KP, Es * 512); want(&p->G, Es * 256);
     want(&p->Qe, Es * 512); want(&p->KVe, Es * 1024); want(&p->Oe, Es * 512);
+    // launch-bound plans (every edge GEMM fits one round of the grid): second scratch set for the 2D twin stages
+    p->dual = h->dual_stream && E > 0 && E <= 8192;
+    if (p->dual) {
+        want(&p->NP2, Ns * 3328); want(&p->Hbig2, Es * 1024); want(&p->KP2, Es * 512); want(&p->G2, Es * 256);
+        want(&p->T768b, Ns * 768); want(&p->rs2, Ns); want(&p->H2b, Es * 128);
+    }
     if (p->fa_parts > 1) {
         want(&p->d_krange, krange.size());
         want(&p->fa_opart, (size_t)p->fa_parts * Es * 512);
@@ -810,6 +837,37 @@ int vlsat_forward(vlsat_handle h, vlsat_plan p, const float* pts, const float* f
     h->last_end_ok = false;                // other work may have been enqueued on the stream since the last forward
 #define STAGE(id) do { if (stop == (id)) return 0; } while (0)
 
+    // Two-stream mode (small plans only; not while profiling or stopping at a debug stage): `t` carries the 2D twin
+    // of a stage while `s` carries the 3D one.  fork(): t waits for everything enqueued on s so far; join(): s waits
+    // for t.  Every forward ends joined, so the caller only ever sees its own stream.
+    const bool dual = p->dual && do2d && !h->prof && stop < 0;
+    hipStream_t t = s;
+    size_t ev_i = 0;
+    if (dual) {
+        if (!h->side) VLSAT_HIP_CHECK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+        t = h->side;
+    }
+    auto next_ev = [&](hipEvent_t* e) -> int {
+        if (ev_i == h->sync_ev.size()) {
+            hipEvent_t n;
+            VLSAT_HIP_CHECK(hipEventCreateWithFlags(&n, hipEventDisableTiming));
+            h->sync_ev.push_back(n);
+        }
+        *e = h->sync_ev[ev_i++];
+        return 0;
+    };
+    auto order = [&](hipStream_t first, hipStream_t then) -> int {       // `then` continues after `first`'s work so far
+        if (!dual) return 0;
+        hipEvent_t e;
+        RUN(next_ev(&e));
+        VLSAT_HIP_CHECK(hipEventRecord(e, first));
+        VLSAT_HIP_CHECK(hipStreamWaitEvent(then, e, 0));
+        return 0;
+    };
+    auto fork = [&]() { return order(s, t); };
+    auto join = [&]() { return order(t, s); };
+    const Scratch sc3 = scratch_of(p, 0), sc2 = scratch_of(p, dual ? 1 : 0);
+
     {   // a-2 object encoder
         Scope sc(h, s, PC_POINTNET, 213376.0 * N * p->P);
         RUN(launch_pointnet(pts, N, p->P, h->d.dim_point, h->pn_w1, h->pn_b1, h->pn_w2, h->pn_b2, h->pn_w3, h->pn_b3, h->C_pt, p->F, s));
@@ -827,19 +885,20 @@ int vlsat_forward(vlsat_handle h, vlsat_plan p, const float* pts, const float* f
         Scope sc(h, s, PC_MISC, 0);
         RUN(launch_edge_embed(desc, p->d_src, p->d_dst, E, h->re_w1cat, h->re_b1cat, p->H1, s));
     }
-    RUN(gemm(h, s, G(p->H1, 128, h->re3_w2, 64, p->H2, 128, E, 128, h->re3_b2, ACT_RELU)));
-    RUN(gemm(h, s, G(p->H2, 128, h->re3_w3, 128, p->E3, D, E, D, h->re3_b3, ACT_RELU)));
+    RUN(fork());                                                            // t: 2D relation encoder + adapter
+    RUN(gemm(h, s, G(p->H1, 128, h->re3_w2, 64, sc3.H2, 128, E, 128, h->re3_b2, ACT_RELU)));
+    RUN(gemm(h, s, G(sc3.H2, 128, h->re3_w3, 128, p->E3, D, E, D, h->re3_b3, ACT_RELU)));
     if (do2d) {
-        RUN(gemm(h, s, G(p->H1 + 64, 128, h->re2_w2, 64, p->H2, 128, E, 128, h->re2_b2, ACT_RELU)));
-        RUN(gemm(h, s, G(p->H2, 128, h->re2_w3, 128, p->E2, D, E, D, h->re2_b3, ACT_RELU)));
+        RUN(gemm(h, t, G(p->H1 + 64, 128, h->re2_w2, 64, sc2.H2, 128, E, 128, h->re2_b2, ACT_RELU)));
+        RUN(gemm(h, t, G(sc2.H2, 128, h->re2_w3, 128, p->E2, D, E, D, h->re2_b3, ACT_RELU)));
     }
     STAGE(3);
     // a-6 adapter -> X2[:, 0:512]
     if (do2d) {
-        RUN(gemm(h, s, G(f2d, D, h->ad_w1, D, p->T256, 256, N, 256, h->ad_b1, ACT_RELU)));
+        RUN(gemm(h, t, G(f2d, D, h->ad_w1, D, p->T256, 256, N, 256, h->ad_b1, ACT_RELU)));
         GemmArgs a = G(p->T256, 256, h->ad_w2h, 256, p->X2, LDX, N, D, h->ad_b2h);
         a.resid = f2d; a.ldr = D; a.resid_scale = 0.5f;
-        RUN(gemm(h, s, a));
+        RUN(gemm(h, t, a));
     }
     STAGE(4);
     {   // a-7 distance bias
@@ -853,16 +912,19 @@ int vlsat_forward(vlsat_handle h, vlsat_plan p, const float* pts, const float* f
         const int base = 10 + 10 * l;
         RUN(attn_block(h, p, s, h->self_attn[l], p->X3, p->X3, true));                  // :217
         STAGE(base + 0);
+        RUN(join());                                          // X2 / E2 of the previous stage are complete
         if (do2d) RUN(attn_block(h, p, s, h->cross_attn[l], p->X2, p->X3, false));      // :218
         STAGE(base + 1);
-        RUN(gcn_block(h, p, s, h->gcn3[l], p->X3, p->E3, e3_pending_relu, inter));      // :224
+        RUN(fork());                                          // t: gcn_2ds + query projection; s: gcn_3ds + key/value projection
+        RUN(gcn_block(h, p, s, h->gcn3[l], p->X3, p->E3, e3_pending_relu, inter, sc3)); // :224
         STAGE(base + 2);
-        if (do2d) RUN(gcn_block(h, p, s, h->gcn2[l], p->X2, p->E2, 0, inter));          // :225
+        if (do2d) RUN(gcn_block(h, p, t, h->gcn2[l], p->X2, p->E2, 0, inter, sc2));     // :225
         STAGE(base + 3);
         if (do2d) {   // :231 edge cross-attention: q = 2D edges, k = v = 3D edges (pre-activation)
             const AttnW& w = h->cross_rel[l];
-            RUN(gemm(h, s, G(p->E2, D, w.wq, D, p->Qe, D, E, D, w.bq)));
+            RUN(gemm(h, t, G(p->E2, D, w.wq, D, p->Qe, D, E, D, w.bq)));
             RUN(gemm(h, s, G(p->E3, D, w.wkv, D, p->KVe, 2 * D, E, 2 * D, w.bkv)));
+            RUN(join());
             {
                 Scope sc(h, s, PC_FLASH, p->flash_flops);
                 FlashSplit sp;
@@ -881,12 +943,14 @@ int vlsat_forward(vlsat_handle h, vlsat_plan p, const float* pts, const float* f
         STAGE(base + 4);
     }
     // a-15 relation heads, a-16 object heads
+    RUN(fork());                                              // t: the 2D heads
     if (E > 0) {
-        RUN(rel_head(h, p, s, h->rel3, p->E3, e3_pending_relu, rel3d));
-        if (do2d) RUN(rel_head(h, p, s, h->rel2, p->E2, 0, rel2d));
+        RUN(rel_head(h, p, s, h->rel3, p->E3, e3_pending_relu, rel3d, sc3));
+        if (do2d) RUN(rel_head(h, p, t, h->rel2, p->E2, 0, rel2d, sc2));
     }
-    RUN(obj_head(h, p, s, p->X3, h->obj3_w, h->obj3_b, obj3d));
-    if (do2d) RUN(obj_head(h, p, s, p->X2, h->obj2_w, h->obj2_b, obj2d));
+    RUN(obj_head(h, p, s, p->X3, h->obj3_w, h->obj3_b, obj3d, sc3));
+    if (do2d) RUN(obj_head(h, p, t, p->X2, h->obj2_w, h->obj2_b, obj2d, sc2));
+    RUN(join());
 #undef STAGE
     return 0;
 }

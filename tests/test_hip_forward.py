@@ -198,6 +198,29 @@ def test_random_graphs_vs_oracle(seed):
     _check(run_hip(cfg, b), run_oracle(cfg, b), TIGHT, f"random graph batch #{seed} ({len(scenes)} scenes, E={len(perm)})")
 
 
+def test_two_stream_mode_is_bit_identical(monkeypatch):
+    """Small plans run the 2D twin stages on a second stream (engine.hip: fork/join around the relation encoder,
+    adapter, gcn_2ds, query projection and the 2D heads).  Same kernels on the same data, so the outputs must be
+    bit-identical to the single-stream schedule -- any difference is a race.  30 scenes x 3 repeats."""
+    from vlsat_amd.model import VLSATModel
+    cfg = VLSATConfig(N_LAYERS=3)
+    w = synth.make_weights(cfg)
+    dual = VLSATModel(cfg, DEV).load_state(w).eval()
+    monkeypatch.setenv("VLSAT_DUAL_STREAM", "0")
+    single = VLSATModel(cfg, DEV).load_state(w).eval()
+    g = np.random.default_rng(7)
+    for i in range(30):
+        b = _dev(synth.collate([synth.make_scene(int(g.integers(2, 60)), int(g.integers(8, 200)), 12000 + i)]))
+        ref = [o.clone() for o in single(b["obj_points"], b["obj_2d_feats"], b["edge_indices"], b["descriptor"], b["batch_ids"])]
+        for rep in range(3):
+            got = dual(b["obj_points"], b["obj_2d_feats"], b["edge_indices"], b["descriptor"], b["batch_ids"])
+            torch.cuda.synchronize()
+            for n, a, c in zip(NAMES, got, ref):
+                assert torch.equal(a, c), f"scene {i} rep {rep} {n}: max diff {float((a - c).abs().max()):.3e}"
+    dual.close()
+    single.close()
+
+
 def test_edges_interleaved_across_scenes():
     """Edges not grouped by scene: the glue permutes them (VLSAT_EGRAPH path) and un-permutes
     the relation outputs."""
