@@ -37,6 +37,10 @@ for name, M, N, K, scale in (("E x512 x512  A~N(0,1) W~N(0,0.05)", 99840 - 1536,
     ms = e0.elapsed_time(e1)
     tf = 2.0 * M * N * K / ms / 1e9
     mfma_cycles = 2.0 * M * N * K / 4096 * 64 / 1024            # busy cycles per SIMD
+    # two blocks share a CU and the first-dispatched one finishes early (tools/gemm_block_probe.py): the SIMD is
+    # occupied until the slower one ends = the upper half of the sorted per-block cycle counts
+    cyc = b[:, 0].sort().values
+    slow = cyc[len(cyc) // 2:].mean().item()
     print(f"{name:36s} {ms * 1e3:7.1f} us  {tf:6.1f} TFLOP/s  shader clock {ghz:.3f} GHz  "
           f"(fp32-MFMA ceiling at that clock {157.3 * ghz / 2.4:.1f} TF; matrix pipe busy "
-          f"{100 * mfma_cycles / (b[:, 0].mean().item()):.0f} % of the cycles it ran)")
+          f"{100 * mfma_cycles / slow:.0f} % of the cycles the slower block of each CU ran)")
