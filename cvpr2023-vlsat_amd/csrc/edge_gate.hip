@@ -9,7 +9,9 @@
 //   * proj_edge rows are permuted so k arrives head-major: kproj[e, h*64 + c] == k[e, c, h];
 //     the [E,512] matrix is then a contiguous [8E, 64] matrix of (edge, head) rows.
 // Per (edge, head) row:  hidden = relu(Gq + W0k . kproj_row);  logits = W3 . hidden + b3;
-// prob = softmax(logits);  gated[e, m*8+h] = prob[m] * value[dst[e], m*8+h].
+// prob = softmax(logits);  gated[e, h*32+m] = prob[m] * value[dst[e], h*32+m]   (value and gated are kept
+// HEAD-MAJOR -- the engine permutes proj_value's rows and prop.0's columns once -- so the four consecutive
+// channels m a lane owns per MFMA row group are one float4 load and one float4 store).
 //
 // fp32 MFMA, transposed products so that a lane owns ONE (edge, head) row:
 //   hidden^T[o][row] : A = W0k (LDS), B = kproj rows straight from HBM (float4 per lane)
@@ -109,14 +111,20 @@ __global__ __launch_bounds__(256, 2) void edge_gate_kernel(GateArgs p) {
         sum += __shfl_xor(sum, 32);
         const float inv = 1.f / sum;
         if (valid) {
-            const float* vrow = p.node + (size_t)dn * p.ld_node + p.v_off + h;
-            float* grow = p.gated + (size_t)e * 256 + h;
+            // lane's channels: m = 8*r4 + 4*hi + c  (crow32), c = 0..3 -> one float4 per r4
+            const float* vrow = p.node + (size_t)dn * p.ld_node + p.v_off + h * 32 + 4 * hi;
+            float* grow = p.gated + (size_t)e * 256 + h * 32 + 4 * hi;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = crow32(r, hi);
-                const float pr = lg[r] * inv;
-                grow[m * 8] = pr * vrow[m * 8];
-                if (p.prob) p.prob[(size_t)e * 256 + m * 8 + h] = pr;
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(vrow + 8 * r4);
+                f32x4 o;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) o[c] = lg[r4 * 4 + c] * inv * v[c];
+                *reinterpret_cast<f32x4*>(grow + 8 * r4) = o;
+            }
+            if (p.prob) {                      // test tap in the reference's [E, 32, 8] order
+#pragma unroll
+                for (int r = 0; r < 16; ++r) p.prob[(size_t)e * 256 + crow32(r, hi) * 8 + h] = lg[r] * inv;
             }
         }
     }
@@ -124,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void edge_gate_kernel(GateArgs p) {
 
 int launch_edge_gate(const GateArgs& a, hipStream_t s) {
     if (a.n_edges <= 0) return 0;
-    if ((a.ld_node & 3) || (a.gq_off & 3)) return fail(-1, "edge_gate: ld_node/gq_off must be multiples of 4");
+    if ((a.ld_node & 3) || (a.gq_off & 3) || (a.v_off & 3)) return fail(-1, "edge_gate: ld_node/gq_off/v_off must be multiples of 4");
     const int n_groups = (a.n_edges + 15) / 16;
     // persistent: 3 blocks per CU are resident (51.7 KB LDS each); every block stages the weights once
     // and walks ~n_groups/768 groups, so there is no partial last wave of blocks

@@ -236,9 +236,25 @@ int prepare_gcn(vlsat_ctx* h, Prep& P, const std::string& pre, GcnW& w) {
             for (int k = 0; k < D; ++k) dst[k] = (float)row[k];
             bnode[G0 + hh * HID + o] = (float)bb;
         }
+    // value rows HEAD-MAJOR: row h*dox + m <- proj_value row m*H + h, so that the gate kernel reads / writes the four
+    // consecutive channels a lane owns as one float4.  The gated and aggregated tensors inherit that channel order
+    // (max / add / mean are per channel) and the columns of prop.0 that read them are permuted to match below.
     const int V0 = G0 + H * HID;
-    std::memcpy(&wnode[(size_t)V0 * D], w_pv.data(), (size_t)A * D * sizeof(float));
-    for (int i = 0; i < A; ++i) bnode[V0 + i] = b_pv[i];
+    for (int hh = 0; hh < H; ++hh)
+        for (int m = 0; m < dox; ++m) {
+            std::memcpy(&wnode[(size_t)(V0 + hh * dox + m) * D], &w_pv[(size_t)(m * H + hh) * D], D * sizeof(float));
+            bnode[V0 + hh * dox + m] = b_pv[m * H + hh];
+        }
+    {
+        std::vector<float> perm(w_p0.size());
+        const int IN = D + A;
+        for (int o = 0; o < IN; ++o) {
+            std::memcpy(&perm[(size_t)o * IN], &w_p0[(size_t)o * IN], D * sizeof(float));
+            for (int hh = 0; hh < H; ++hh)
+                for (int m = 0; m < dox; ++m) perm[(size_t)o * IN + D + hh * dox + m] = w_p0[(size_t)o * IN + D + m * H + hh];
+        }
+        w_p0.swap(perm);
+    }
     // proj_edge rows permuted: row h*64 + c <- original row c*8 + h
     std::vector<float> wpe((size_t)D * D), bpe(D);
     for (int hh = 0; hh < H; ++hh)

@@ -88,13 +88,13 @@ struct GateArgs {
     const float* node;       // node-side buffer, row pitch ld_node
     int ld_node;
     int gq_off;              // column offset of Gq[h*128 + o] (layer-1 node part incl. bias)
-    int v_off;               // column offset of value[m*8 + h]
+    int v_off;               // column offset of value[h*32 + m]  (head-major, see edge_gate.hip)
     const int32_t* src;      // [E]
     const int32_t* dst;      // [E]
     const float* w0k;        // [128, 64]  layer-1 weights acting on the edge half
     const float* w3;         // [32, 128]
     const float* b3;         // [32]
-    float* gated;            // [E, 256]  gated[e, m*8 + h]
+    float* gated;            // [E, 256]  gated[e, h*32 + m]
     float* prob;             // optional [E, 32, 8] tap (tests) or nullptr
     int n_edges;
     int use_edge = 1;        // MODEL.USE_GCN_EDGE: 0 -> the gate MLP sees the query alone (kproj / w0k unused)

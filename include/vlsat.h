@@ -197,7 +197,8 @@ int vlsat_eval_ranks(const float* obj_logits, const float* obj_probs, const floa
  * 10+10l self-attention, +1 cross-attention, +2 gcn_3ds, +3 gcn_2ds, +4 edge cross-attention. */
 int vlsat_debug_stop_after(vlsat_handle h, int32_t stage);
 /* Device pointer and shape of a named workspace buffer of a plan ("X3","X2","E3","E2","F","G",
- * "AGG3","AGG2","H1","KP","NP","Hbig","bias","On","Oe","Qe","KVe"). */
+ * "AGG3","AGG2","H1","KP","NP","Hbig","bias","On","Oe","Qe","KVe").  "G" (gated values) and "AGG3"/"AGG2" keep
+ * their 256 channels head-major (h*32 + m); the reference's order is m*8 + h. */
 int vlsat_debug_buffer(vlsat_plan p, const char* name, void** ptr, int64_t* rows, int32_t* cols, int32_t* ld);
 /* Synchronous strided device-to-device copy of that buffer into dst (row pitch dst_ld floats). */
 int vlsat_debug_read(vlsat_plan p, const char* name, float* dst, int64_t dst_ld);

@@ -99,8 +99,10 @@ def test_staged_taps_cfg1():
     close(stage(4, "X2"), taps["clip_adapter"], "adapter")
     close(stage(10, "X3"), taps["self_attn0"], "self_attn0")
     close(stage(11, "X2"), taps["cross_attn0"], "cross_attn0")
-    close(stage(12, "G"), taps["gcn3d0.gated"], "gate3d (head layout)")
-    close(stage(12, "AGG3"), taps["gcn3d0.agg"], "aggregate3d")
+    # the engine keeps the gated / aggregated channels head-major (h*32 + m); the reference order is m*8 + h
+    ref_order = lambda t: t.view(t.shape[0], 8, 32).transpose(1, 2).reshape(t.shape[0], 256)
+    close(ref_order(stage(12, "G")), taps["gcn3d0.gated"], "gate3d (head layout)")
+    close(ref_order(stage(12, "AGG3")), taps["gcn3d0.agg"], "aggregate3d")
     close(stage(12, "E3"), taps["gcn3d0.edge"], "gcn3d edge")
     close(stage(12, "X3"), torch.relu(taps["gcn3d0.node"]), "gcn3d node (+inter-layer relu)")
     close(stage(13, "E2"), taps["gcn2d0.edge"], "gcn2d edge")
