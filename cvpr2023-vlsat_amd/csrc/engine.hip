@@ -76,14 +76,14 @@ struct vlsat_ctx {
     bool prof = false;
     struct Rec { int cls; hipEvent_t a, b; double flops; long kernels; };
     std::vector<Rec> recs;
+    Rec open{};              // interval of the kernel class currently being launched (see Scope)
+    bool open_ok = false;
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
     double acc_ms[PC_COUNT] = {0};
     int64_t acc_n[PC_COUNT] = {0};
     double acc_fl[PC_COUNT] = {0};
     int debug_stop = -1;
-    hipEvent_t last_end{};
-    bool last_end_ok = false;
     // GEMM operand precision: 0 exact fp32 MFMA, 1 bf16, 3 split-bf16 (vlsat_set_gemm_precision)
     int prec = 0;
     std::map<const float*, std::pair<uint16_t*, uint16_t*>> split;
@@ -281,35 +281,39 @@ hipEvent_t next_event(vlsat_ctx* h) {
     }
     return h->ev_pool[h->ev_used++];
 }
+// Per-class timing with as few events as possible: an event is recorded only where the kernel CLASS changes
+// (a run of consecutive launches of one class is one interval), plus one at the end of the forward.
 struct Scope {
     vlsat_ctx* h;
     hipStream_t s;
     int cls;
     double flops;
-    hipEvent_t a{};
     long k0 = 0;
     Scope(vlsat_ctx* h_, hipStream_t s_, int cls_, double fl) : h(h_), s(s_), cls(cls_), flops(fl) {
         k0 = gemm_kernel_launches();
-        if (h->prof) {
-            // consecutive launches of one forward share a boundary event (end of the previous
-            // scope = start of this one): one event per launch instead of two
-            if (h->last_end_ok) a = h->last_end;
-            else {
-                a = next_event(h);
-                hipEventRecord(a, s);
-            }
-        }
+        if (!h->prof) return;
+        if (h->open_ok && h->open.cls == cls) return;              // same class: the open interval continues
+        hipEvent_t e = next_event(h);
+        hipEventRecord(e, s);
+        if (h->open_ok) { h->open.b = e; h->recs.push_back(h->open); }
+        h->open = {cls, e, e, 0.0, 0};
+        h->open_ok = true;
     }
     ~Scope() {
-        if (h->prof) {
-            hipEvent_t b = next_event(h);
-            hipEventRecord(b, s);
-            h->recs.push_back({cls, a, b, flops, cls == PC_GEMM ? gemm_kernel_launches() - k0 : 1});
-            h->last_end = b;
-            h->last_end_ok = true;
-        }
+        if (!h->prof) return;
+        h->open.flops += flops;
+        h->open.kernels += cls == PC_GEMM ? gemm_kernel_launches() - k0 : 1;
     }
 };
+// end of a forward (or of a debug-stopped one): close the open interval
+static void profile_close(vlsat_ctx* h, hipStream_t s) {
+    if (!h->prof || !h->open_ok) return;
+    hipEvent_t e = next_event(h);
+    hipEventRecord(e, s);
+    h->open.b = e;
+    h->recs.push_back(h->open);
+    h->open_ok = false;
+}
 
 int gemm(vlsat_ctx* h, hipStream_t s, const GemmArgs& a0) {
     GemmArgs a = a0;
@@ -850,8 +854,8 @@ int vlsat_forward(vlsat_handle h, vlsat_plan p, const float* pts, const float* f
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int N = (int)p->N, E = (int)p->E, D = h->D, L = h->d.n_layers, LDX = 768;
     const int stop = h->debug_stop;
-    h->last_end_ok = false;                // other work may have been enqueued on the stream since the last forward
-#define STAGE(id) do { if (stop == (id)) return 0; } while (0)
+    profile_close(h, s);                   // an interval left open by a failed forward must not span foreign work
+#define STAGE(id) do { if (stop == (id)) { profile_close(h, s); return 0; } } while (0)
 
     // Two-stream mode (small plans only; not while profiling or stopping at a debug stage): `t` carries the 2D twin
     // of a stage while `s` carries the 3D one.  fork(): t waits for everything enqueued on s so far; join(): s waits
@@ -967,6 +971,7 @@ int vlsat_forward(vlsat_handle h, vlsat_plan p, const float* pts, const float* f
     RUN(obj_head(h, p, s, p->X3, h->obj3_w, h->obj3_b, obj3d, sc3));
     if (do2d) RUN(obj_head(h, p, t, p->X2, h->obj2_w, h->obj2_b, obj2d, sc2));
     RUN(join());
+    profile_close(h, s);
 #undef STAGE
     return 0;
 }
