@@ -25,6 +25,7 @@ class VLSATConfig:
     multi_rel_outputs: bool = True  # relation head ends in sigmoid (multi-label) vs log_softmax       SGFN_MMG/model.py:113-130
     USE_RGB: bool = False          # +3 point channels                                                   SGFN_MMG/model.py:31-35
     USE_NORMAL: bool = False       # +3 point channels
+    feature_transform: bool = False  # STNkd 64x64 feature transform after conv1 of all three encoders  network_PointNet.py:52-86,146-150
     clip_feat_dim: int = 512
     # fixed by Mmgnet.__init__ (reference SGFN_MMG/model.py:41-86)
     dim_node: int = 512
@@ -65,13 +66,28 @@ def param_shapes(cfg: VLSATConfig) -> "OrderedDict[str, tuple]":
         s[name + ".weight"] = (d,)
         s[name + ".bias"] = (d,)
 
+    def stn(prefix):        # STNkd(k=64): its BatchNorm layers ARE applied (eval affine), unlike PointNetfeat's own
+        conv(prefix + ".conv1", 64, 64)
+        conv(prefix + ".conv2", 128, 64)
+        conv(prefix + ".conv3", 1024, 128)
+        lin(prefix + ".fc1", 512, 1024)
+        lin(prefix + ".fc2", 256, 512)
+        lin(prefix + ".fc3", 64 * 64, 256)
+        for bn, d in (("bn1", 64), ("bn2", 128), ("bn3", 1024), ("bn4", 512), ("bn5", 256)):
+            for k in ("weight", "bias", "running_mean", "running_var"):
+                s[f"{prefix}.{bn}.{k}"] = (d,)
+
     conv("obj_encoder.conv1", 64, cfg.dim_point)
     conv("obj_encoder.conv2", 128, 64)
     conv("obj_encoder.conv3", cfg.point_feature, 128)
+    if cfg.feature_transform:
+        stn("obj_encoder.fstn")
     for b in ("rel_encoder_2d", "rel_encoder_3d"):
         conv(b + ".conv1", 64, cfg.dim_descriptor)
         conv(b + ".conv2", 128, 64)
         conv(b + ".conv3", cfg.dim_edge, 128)
+        if cfg.feature_transform:
+            stn(b + ".fstn")
     lin("mlp_3d.0", D - 8, cfg.point_feature)
     for k in ("weight", "bias", "running_mean", "running_var"):
         s["mlp_3d.1." + k] = (D - 8,)

@@ -45,6 +45,8 @@ struct GcnW {           // one GraphEdgeAttenNetwork block
     float *wp0, *bp0, *wp2, *bp2;
 };
 struct RelHeadW { float *w1, *b1, *w2, *b2, *w3, *b3; };
+// STNkd(k=64) with its five BatchNorm1d(eval) layers folded and the identity folded into the last bias
+struct StnW { float *c1, *c1b, *c2, *c2b, *c3, *c3b, *f1, *f1b, *f2, *f2b, *f3, *f3b; };
 
 }  // namespace vlsat
 
@@ -71,6 +73,7 @@ struct vlsat_ctx {
     std::vector<AttnW> self_attn, cross_attn, cross_rel;
     std::vector<GcnW> gcn3, gcn2;
     RelHeadW rel3{}, rel2{};
+    StnW stn_obj{}, stn_re3{}, stn_re2{};          // MODEL.feature_transform
     float *obj3_w, *obj3_b, *obj2_w, *obj2_b;
     // profiling
     bool prof = false;
@@ -117,6 +120,8 @@ struct vlsat_plan_s {
     // Small plans (launch-bound: one scene per call) run the 2D twin of every stage -- relation encoder, adapter,
     // gcn_2ds, the query projection of the edge attention, the 2D heads -- on a second stream, concurrently with
     // the 3D twin.  The twins never touch each other's tensors; they only shared scratch, so the 2D side gets its own.
+    float* stn_ws = nullptr;                        // MODEL.feature_transform scratch (carved per phase in stn_phase)
+    size_t stn_ws_floats = 0;
     bool dual = false;
     float *NP2 = nullptr, *Hbig2 = nullptr, *KP2 = nullptr, *G2 = nullptr, *T768b = nullptr, *rs2 = nullptr, *H2b = nullptr;
 };
@@ -269,6 +274,37 @@ int prepare_gcn(vlsat_ctx* h, Prep& P, const std::string& pre, GcnW& w) {
     UP(wnode, w.wnode); UP(bnode, w.bnode); UP(we1, w.we1); UP(w_e2, w.we2); UP(b_e2, w.be2);
     UP(wpe, w.wpe); UP(bpe, w.bpe); UP(w0k, w.w0k); UP(w_n3, w.w3); UP(b_n3, w.b3);
     UP(w_p0, w.wp0); UP(b_p0, w.bp0); UP(w_p2, w.wp2); UP(b_p2, w.bp2);
+    return 0;
+}
+
+// STNkd weights of encoder `enc` (reference network_PointNet.py:52-86): conv/fc + BatchNorm1d(eval) folded in fp64,
+// "+ eye(64)" folded into fc3's bias
+int prepare_stn(vlsat_ctx* h, Prep& P, const std::string& enc, StnW& w) {
+    const std::string f = enc + ".fstn.";
+    struct L { const char* name; const char* bn; int out, in; };
+    const L layers[6] = {{"conv1", "bn1", 64, 64}, {"conv2", "bn2", 128, 64}, {"conv3", "bn3", 1024, 128},
+                         {"fc1", "bn4", 512, 1024}, {"fc2", "bn5", 256, 512}, {"fc3", nullptr, 4096, 256}};
+    float** dst[6][2] = {{&w.c1, &w.c1b}, {&w.c2, &w.c2b}, {&w.c3, &w.c3b}, {&w.f1, &w.f1b}, {&w.f2, &w.f2b}, {&w.f3, &w.f3b}};
+    for (int i = 0; i < 6; ++i) {
+        const L& l = layers[i];
+        auto wt = P.get(f + l.name + ".weight", (size_t)l.out * l.in), bs = P.get(f + l.name + ".bias", l.out);
+        if (l.bn) {
+            const std::string b = f + l.bn;
+            auto g = P.get(b + ".weight", l.out), be = P.get(b + ".bias", l.out);
+            auto mu = P.get(b + ".running_mean", l.out), var = P.get(b + ".running_var", l.out);
+            if (!P.missing.empty()) return 0;
+            for (int o = 0; o < l.out; ++o) {
+                const double sc = (double)g[o] / std::sqrt((double)var[o] + 1e-5);
+                for (int k = 0; k < l.in; ++k) wt[(size_t)o * l.in + k] = (float)(wt[(size_t)o * l.in + k] * sc);
+                bs[o] = (float)(((double)bs[o] - mu[o]) * sc + be[o]);
+            }
+        } else {
+            if (!P.missing.empty()) return 0;
+            for (int d = 0; d < 64; ++d) bs[d * 64 + d] += 1.f;
+        }
+        UP(wt, *dst[i][0]);
+        UP(bs, *dst[i][1]);
+    }
     return 0;
 }
 
@@ -449,6 +485,7 @@ int vlsat_create(const VlsatDims* d, vlsat_handle* out) {
     if (d->gcn_aggr < 0 || d->gcn_aggr > 2) return fail(VLSAT_EINVAL, "gcn_aggr must be 0 (max), 1 (add) or 2 (mean)");
     if (d->dim_point != 3 && d->dim_point != 6 && d->dim_point != 9)
         return fail(VLSAT_EINVAL, "dim_point must be 3, 6 or 9 (xyz [+ USE_RGB] [+ USE_NORMAL])");
+    if (d->feature_transform != 0 && d->feature_transform != 1) return fail(VLSAT_EINVAL, "feature_transform must be 0 or 1");
     if (d->n_obj_class < 1 || d->n_rel_class < 1) return fail(VLSAT_EINVAL, "class counts must be positive");
     auto* h = new (std::nothrow) vlsat_ctx();
     if (!h) return fail(VLSAT_ENOMEM, "out of host memory");
@@ -517,6 +554,11 @@ int vlsat_finalize_weights(vlsat_handle h) {
         auto c3 = P.get(b + ".conv3.weight", (size_t)D * 128), c3b = P.get(b + ".conv3.bias", D);
         if (b == "rel_encoder_3d") { r3w2 = c2; r3b2 = c2b; r3w3 = c3; r3b3 = c3b; }
         else { r2w2 = c2; r2b2 = c2b; r2w3 = c3; r2b3 = c3b; }
+    }
+    if (h->d.feature_transform) {
+        RUN(prepare_stn(h, P, "obj_encoder", h->stn_obj));
+        RUN(prepare_stn(h, P, "rel_encoder_3d", h->stn_re3));
+        RUN(prepare_stn(h, P, "rel_encoder_2d", h->stn_re2));
     }
     // adapter: 0.5*(W2 h + b2) + 0.5*x  -> halve W2,b2 (exact), residual scale 0.5
     auto aw1 = P.get("clip_adapter.fc1.weight", 256 * (size_t)D), ab1 = P.get("clip_adapter.fc1.bias", 256);
@@ -708,6 +750,14 @@ int vlsat_plan_create(vlsat_handle h, const int64_t* bid, const int64_t* edges, 
         want(&p->NP2, Ns * 3328); want(&p->Hbig2, Es * 1024); want(&p->KP2, Es * 512); want(&p->G2, Es * 256);
         want(&p->T768b, Ns * 768); want(&p->rs2, Ns); want(&p->H2b, Es * 128);
     }
+    if (h->d.feature_transform) {
+        // point rows R = N*P (objects) or E (relation encoders, P = 1), one phase at a time:
+        //   rows [R,64] h1, [R,64], [R,128], [R,1024] STN convs (the last two double as conv2/conv3 of the main chain),
+        //   [R,64] h1';  per object: 1024 + 512 + 256 + 4096
+        const size_t R = std::max<size_t>(Ns * (size_t)P, Es), O = std::max(Ns, Es);
+        p->stn_ws_floats = R * (64 + 64 + 128 + 1024 + 64) + O * (1024 + 512 + 256 + 4096);
+        want(&p->stn_ws, p->stn_ws_floats);
+    }
     if (p->fa_parts > 1) {
         want(&p->d_krange, krange.size());
         want(&p->fa_opart, (size_t)p->fa_parts * Es * 512);
@@ -840,6 +890,47 @@ int vlsat_debug_read(vlsat_plan p, const char* name, float* dst, int64_t dst_ld)
     return 0;
 }
 
+// One encoder with MODEL.feature_transform: h1 [R,64] (row pitch ldh) -> T = STNkd(h1) per object (objects own P
+// consecutive rows) -> h1' = h1 . T -> relu(conv2) -> relu(conv3) [R, n_out]; the caller takes the max over an
+// object's rows (or uses the rows directly when P == 1).  Returns the conv3 output rows in *out_rows (pitch n_out).
+namespace {
+int stn_encoder(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const StnW& w, const float* h1, int ldh, size_t R, int P,
+                const float* w2, const float* b2, const float* w3, const float* b3, int n_out, float** out_rows) {
+    const size_t O = R / P;
+    float* ws = p->stn_ws;
+    float* a64 = ws;             ws += R * 64;
+    float* a128 = ws;            ws += R * 128;
+    float* a1024 = ws;           ws += R * 1024;
+    float* h1t = ws;             ws += R * 64;
+    float* g = ws;               ws += O * 1024;
+    float* f1 = ws;              ws += O * 512;
+    float* f2 = ws;              ws += O * 256;
+    float* T = ws;               ws += O * 4096;
+    if ((size_t)(ws - p->stn_ws) > p->stn_ws_floats) return fail(VLSAT_ESTATE, "feature_transform scratch too small");
+    const int Ri = (int)R, Oi = (int)O;
+    RUN(gemm(h, s, G(h1, ldh, w.c1, 64, a64, 64, Ri, 64, w.c1b, ACT_RELU)));
+    RUN(gemm(h, s, G(a64, 64, w.c2, 64, a128, 128, Ri, 128, w.c2b, ACT_RELU)));
+    RUN(gemm(h, s, G(a128, 128, w.c3, 128, a1024, 1024, Ri, 1024, w.c3b, ACT_RELU)));
+    const float* gp = a1024;
+    if (P > 1) {
+        Scope sc(h, s, PC_MISC, 0);
+        RUN(launch_rowmax(a1024, 1024, Oi, P, 1024, g, 1024, s));
+        gp = g;
+    }
+    RUN(gemm(h, s, G(gp, 1024, w.f1, 1024, f1, 512, Oi, 512, w.f1b, ACT_RELU)));
+    RUN(gemm(h, s, G(f1, 512, w.f2, 512, f2, 256, Oi, 256, w.f2b, ACT_RELU)));
+    RUN(gemm(h, s, G(f2, 256, w.f3, 256, T, 4096, Oi, 4096, w.f3b)));
+    {
+        Scope sc(h, s, PC_MISC, 0);
+        RUN(launch_apply_stn(h1, ldh, T, R, P, h1t, 64, s));
+    }
+    RUN(gemm(h, s, G(h1t, 64, w2, 64, a128, 128, Ri, 128, b2, ACT_RELU)));
+    RUN(gemm(h, s, G(a128, 128, w3, 128, a1024, n_out, Ri, n_out, b3, ACT_RELU)));
+    *out_rows = a1024;
+    return 0;
+}
+}  // namespace
+
 // -------------------------------------------------------------------------------------------
 int vlsat_forward(vlsat_handle h, vlsat_plan p, const float* pts, const float* f2d, const float* desc,
                   float* obj3d, float* obj2d, float* rel3d, float* rel2d, void* stream) {
@@ -888,9 +979,20 @@ int vlsat_forward(vlsat_handle h, vlsat_plan p, const float* pts, const float* f
     auto join = [&]() { return order(t, s); };
     const Scratch sc3 = scratch_of(p, 0), sc2 = scratch_of(p, dual ? 1 : 0);
 
-    {   // a-2 object encoder
+    const bool ft = h->d.feature_transform != 0;
+    if (!ft) {   // a-2 object encoder
         Scope sc(h, s, PC_POINTNET, 213376.0 * N * p->P);
         RUN(launch_pointnet(pts, N, p->P, h->d.dim_point, h->pn_w1, h->pn_b1, h->pn_w2, h->pn_b2, h->pn_w3, h->pn_b3, h->C_pt, p->F, s));
+    } else {     // a-2 with the STNkd feature transform: conv1 as point rows, then GEMMs + a max over each object's rows
+        float* rows = p->stn_ws + p->stn_ws_floats - (size_t)N * p->P * 64;       // h1 rows live at the end of the scratch
+        {
+            Scope sc(h, s, PC_MISC, 0);
+            RUN(launch_pts_conv1_rows(pts, N, p->P, h->d.dim_point, h->pn_w1, h->pn_b1, rows, s));
+        }
+        float* out = nullptr;
+        RUN(stn_encoder(h, p, s, h->stn_obj, rows, 64, (size_t)N * p->P, p->P, h->pn_w2, h->pn_b2, h->pn_w3, h->pn_b3, h->C_pt, &out));
+        Scope sc(h, s, PC_MISC, 0);
+        RUN(launch_rowmax(out, h->C_pt, N, p->P, h->C_pt, p->F, 768, s));
     }
     STAGE(1);
     // a-3 mlp_3d (+BN folded) + spatial tail -> X3[:, 0:512]
@@ -906,11 +1008,20 @@ int vlsat_forward(vlsat_handle h, vlsat_plan p, const float* pts, const float* f
         RUN(launch_edge_embed(desc, p->d_src, p->d_dst, E, h->re_w1cat, h->re_b1cat, p->H1, s));
     }
     RUN(fork());                                                            // t: 2D relation encoder + adapter
-    RUN(gemm(h, s, G(p->H1, 128, h->re3_w2, 64, sc3.H2, 128, E, 128, h->re3_b2, ACT_RELU)));
-    RUN(gemm(h, s, G(sc3.H2, 128, h->re3_w3, 128, p->E3, D, E, D, h->re3_b3, ACT_RELU)));
-    if (do2d) {
-        RUN(gemm(h, t, G(p->H1 + 64, 128, h->re2_w2, 64, sc2.H2, 128, E, 128, h->re2_b2, ACT_RELU)));
-        RUN(gemm(h, t, G(sc2.H2, 128, h->re2_w3, 128, p->E2, D, E, D, h->re2_b3, ACT_RELU)));
+    if (!ft) {
+        RUN(gemm(h, s, G(p->H1, 128, h->re3_w2, 64, sc3.H2, 128, E, 128, h->re3_b2, ACT_RELU)));
+        RUN(gemm(h, s, G(sc3.H2, 128, h->re3_w3, 128, p->E3, D, E, D, h->re3_b3, ACT_RELU)));
+        if (do2d) {
+            RUN(gemm(h, t, G(p->H1 + 64, 128, h->re2_w2, 64, sc2.H2, 128, E, 128, h->re2_b2, ACT_RELU)));
+            RUN(gemm(h, t, G(sc2.H2, 128, h->re2_w3, 128, p->E2, D, E, D, h->re2_b3, ACT_RELU)));
+        }
+    } else if (E > 0) {   // P = 1: one row per edge; both encoders share the scratch, so they run one after the other on s
+        for (int br = 0; br < (do2d ? 2 : 1); ++br) {
+            float* out = nullptr;
+            RUN(stn_encoder(h, p, s, br ? h->stn_re2 : h->stn_re3, p->H1 + 64 * br, 128, (size_t)E, 1, br ? h->re2_w2 : h->re3_w2,
+                            br ? h->re2_b2 : h->re3_b2, br ? h->re2_w3 : h->re3_w3, br ? h->re2_b3 : h->re3_b3, D, &out));
+            VLSAT_HIP_CHECK(hipMemcpyAsync(br ? p->E2 : p->E3, out, (size_t)E * D * sizeof(float), hipMemcpyDeviceToDevice, s));
+        }
     }
     STAGE(3);
     // a-6 adapter -> X2[:, 0:512]

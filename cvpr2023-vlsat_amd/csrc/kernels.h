@@ -82,6 +82,12 @@ int launch_layernorm(float* x, int ld, int rows, int dim, const float* gamma, co
 // rowscale[m] = scale / ||x[m,:]||_2  (dim == 512)
 int launch_row_invnorm(const float* x, int ld, int rows, int dim, float scale, float* out, hipStream_t s);
 
+// ---- MODEL.feature_transform glue (stn.hip): conv1 as point rows, max over an object's rows, per-object 64x64 ----
+int launch_pts_conv1_rows(const float* pts, int n_obj, int P, int cin, const float* w1, const float* b1, float* rows,
+                          hipStream_t s);
+int launch_rowmax(const float* x, int ld, int n_obj, int P, int cols, float* out, int ldo, hipStream_t s);
+int launch_apply_stn(const float* h, int ldh, const float* T, size_t rows, int P, float* out, int ldo, hipStream_t s);
+
 // ---- 'fat' edge gate: per (edge, head) MLP 128->128->32, softmax over 32, times value ----
 struct GateArgs {
     const float* kproj;      // [E, 512] head-major: kproj[e, h*64 + c]

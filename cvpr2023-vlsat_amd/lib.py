@@ -22,7 +22,7 @@ class VlsatDims(C.Structure):
     _fields_ = [("n_layers", C.c_int32), ("n_heads", C.c_int32), ("dim_atten", C.c_int32),
                 ("gcn_aggr", C.c_int32), ("dim_point", C.c_int32), ("n_obj_class", C.c_int32),
                 ("n_rel_class", C.c_int32), ("obj_logit_scale", C.c_float), ("use_gcn_edge", C.c_int32),
-                ("multi_rel_outputs", C.c_int32)]
+                ("multi_rel_outputs", C.c_int32), ("feature_transform", C.c_int32)]
 
 
 class VlsatError(RuntimeError):

@@ -49,7 +49,7 @@ class VLSATModel:
         c = self.config
         dims = L.VlsatDims(c.N_LAYERS, c.NUM_HEADS, c.DIM_ATTEN, _AGGR[c.GCN_AGGR], c.dim_point,
                            c.num_obj_class, c.num_rel_class, float(c.obj_logit_scale), int(c.USE_GCN_EDGE),
-                           int(c.multi_rel_outputs))
+                           int(c.multi_rel_outputs), int(c.feature_transform))
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
             L.check(self._lib.vlsat_create(C.byref(dims), C.byref(self._h)))

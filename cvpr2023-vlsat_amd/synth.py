@@ -36,7 +36,7 @@ def make_weights(cfg: VLSATConfig, seed: int = 0) -> "OrderedDict[str, np.ndarra
     for name, shape in param_shapes(cfg).items():
         g = _rng(name, seed)
         leaf = name.rsplit(".", 1)[1]
-        is_norm = (".layer_norm." in name or name.startswith("mlp_3d.1.") or ".bn1." in name or ".bn2." in name
+        is_norm = (".layer_norm." in name or name.startswith("mlp_3d.1.") or any(f".bn{i}." in name for i in range(1, 6))
                    or name.startswith("mmg.self_attn_fc.2.") or name.startswith("mmg.self_attn_fc.5."))
         if is_norm:
             if leaf == "weight":
@@ -124,7 +124,8 @@ SWITCH_CASES = {
     "switch_no_gcn_edge": dict(N_LAYERS=2, USE_GCN_EDGE=False),
     "switch_single_rel": dict(N_LAYERS=2, multi_rel_outputs=False, num_rel_class=27),
     "switch_rgb_normal": dict(N_LAYERS=2, USE_RGB=True, USE_NORMAL=True),
-    "switch_all": dict(N_LAYERS=1, GCN_AGGR="mean", WITH_BN=True, USE_GCN_EDGE=False, multi_rel_outputs=False,
+    "switch_feature_transform": dict(N_LAYERS=1, feature_transform=True),
+    "switch_all": dict(feature_transform=True, N_LAYERS=1, GCN_AGGR="mean", WITH_BN=True, USE_GCN_EDGE=False, multi_rel_outputs=False,
                        num_rel_class=27, USE_RGB=True, USE_NORMAL=True),
 }
 

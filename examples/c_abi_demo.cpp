@@ -52,7 +52,7 @@ int main(int argc, char** argv) {
         fclose(f);
     }
     printf("%s\n", vlsat_version());
-    VlsatDims dims = {L, 8, 256, 0, 3, 160, 26, (float)std::log(1.0 / 0.07), 1, 1};
+    VlsatDims dims = {L, 8, 256, 0, 3, 160, 26, (float)std::log(1.0 / 0.07), 1, 1, 0};
     vlsat_handle h = nullptr;
     CK(vlsat_create(&dims, &h));                                             // Mmgnet.__init__
     {

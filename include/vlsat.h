@@ -55,6 +55,7 @@ typedef struct {
     float   obj_logit_scale; /* log(1/0.07): never checkpointed by the reference */
     int32_t use_gcn_edge;    /* MODEL.USE_GCN_EDGE (1): gate MLP on cat[q,k]; 0: on q alone (network_MMG.py:72-75) */
     int32_t multi_rel_outputs; /* MODEL.multi_rel_outputs (1): sigmoid relation head; 0: log_softmax (SGFN_MMG/model.py:113-130) */
+    int32_t feature_transform; /* MODEL.feature_transform (0): STNkd 64x64 transform after conv1 of the three encoders */
     /* MODEL.WITH_BN needs no field: the relation heads' bn1/bn2 tensors are folded when the checkpoint has them */
 } VlsatDims;
 

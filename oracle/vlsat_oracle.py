@@ -49,6 +49,15 @@ def pointnet_feat(pts: Tensor, w: W, prefix: str) -> Tensor:
     pts [N,C,P] -> [N,out]: max_p relu(conv3(relu(conv2(relu(conv1 x)))))."""
     h = pts.transpose(1, 2)
     h = torch.relu(lin(h, w, prefix + ".conv1"))
+    if prefix + ".fstn.conv1.weight" in w:                 # MODEL.feature_transform: STNkd(k=64), :52-86 and :146-150
+        f = prefix + ".fstn"
+        t = torch.relu(_bn_eval(lin(h, w, f + ".conv1"), w, f + ".bn1"))
+        t = torch.relu(_bn_eval(lin(t, w, f + ".conv2"), w, f + ".bn2"))
+        t = torch.relu(_bn_eval(lin(t, w, f + ".conv3"), w, f + ".bn3")).max(dim=1)[0]             # [N,1024]
+        t = torch.relu(_bn_eval(lin(t, w, f + ".fc1"), w, f + ".bn4"))
+        t = torch.relu(_bn_eval(lin(t, w, f + ".fc2"), w, f + ".bn5"))
+        trans = lin(t, w, f + ".fc3").view(-1, 64, 64) + torch.eye(64, dtype=h.dtype)
+        h = torch.bmm(h, trans)                               # x^T . T per object: h'[n,p,j] = sum_i h[n,p,i] T[n,i,j]
     h = torch.relu(lin(h, w, prefix + ".conv2"))
     h = torch.relu(lin(h, w, prefix + ".conv3"))
     return h.max(dim=1)[0]

@@ -111,7 +111,7 @@ def build_reference(n_layers, aggr="max", num_rel=26, **model_overrides):
     cfg.max_iteration = 10
     cfg.MODEL.N_LAYERS = n_layers
     cfg.MODEL.GCN_AGGR = aggr
-    for k, v in model_overrides.items():          # USE_GCN_EDGE, WITH_BN, multi_rel_outputs, USE_RGB, USE_NORMAL
+    for k, v in model_overrides.items():          # USE_GCN_EDGE, WITH_BN, multi_rel_outputs, USE_RGB, USE_NORMAL, feature_transform
         setattr(cfg.MODEL, k, v)
     cfg.MODEL.adapter_path = os.path.join(REF, "clip_adapter", "checkpoint", "origin_mean.pth")
 
@@ -133,7 +133,7 @@ def load_formula_weights(model, vcfg, seed=0):
     # layers PointNetfeat creates under WITH_BN but whose output it discards (network_PointNet.py:141-164), and
     # proj_edge under USE_GCN_EDGE=False is still live in the state_dict and in our inventory (computed, unused)
     dead = ("triplet_projector_", "clip_adapter.obj_logit_scale", "obj_logit_scale", "num_batches_tracked",
-            "_encoder.bn", "_encoder_2d.bn", "_encoder_3d.bn")
+            "obj_encoder.bn", "_encoder_2d.bn", "_encoder_3d.bn")
     live = [k for k in sd if not any(d in k for d in dead)]
     assert sorted(live) == sorted(w.keys()), (set(live) ^ set(w.keys()))
     for k, v in w.items():

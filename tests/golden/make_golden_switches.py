@@ -11,6 +11,7 @@ outputs are stored.
   switch_no_gcn_edge    MODEL.USE_GCN_EDGE=false    gate MLP on the projected query alone (64->128->32)
   switch_single_rel     MODEL.multi_rel_outputs=false, 27 relation classes: log_softmax head
   switch_rgb_normal     MODEL.USE_RGB=USE_NORMAL=true: 9 point channels
+  switch_feature_transform  MODEL.feature_transform=true: STNkd 64x64 transform after conv1 of all three encoders
   switch_all            all of the above together, GCN_AGGR=mean, L=1
 """
 import os
@@ -30,7 +31,7 @@ def main():
     MG.install_standins()
     for name, kw in synth.SWITCH_CASES.items():
         cfg = VLSATConfig(**kw)
-        over = {k: v for k, v in kw.items() if k in ("WITH_BN", "USE_GCN_EDGE", "multi_rel_outputs", "USE_RGB", "USE_NORMAL")}
+        over = {k: v for k, v in kw.items() if k in ("WITH_BN", "USE_GCN_EDGE", "multi_rel_outputs", "USE_RGB", "USE_NORMAL", "feature_transform")}
         m = MG.build_reference(cfg.N_LAYERS, cfg.GCN_AGGR, num_rel=cfg.num_rel_class, **over)
         MG.load_formula_weights(m, cfg)
         per = [MG.run(m, synth.collate([s])) for s in synth.switch_scenes(cfg)]

@@ -32,7 +32,7 @@ def model_for(cfg):
     from vlsat_amd.model import VLSATModel
     if not torch.cuda.is_available():
         pytest.fail("no GPU visible: the HIP path cannot run and there is no fallback")
-    key = (cfg.N_LAYERS, cfg.GCN_AGGR, cfg.USE_GCN_EDGE, cfg.WITH_BN, cfg.multi_rel_outputs, cfg.dim_point, cfg.num_rel_class)
+    key = (cfg.N_LAYERS, cfg.GCN_AGGR, cfg.USE_GCN_EDGE, cfg.WITH_BN, cfg.multi_rel_outputs, cfg.dim_point, cfg.num_rel_class, cfg.feature_transform)
     if key not in _MODELS:
         _MODELS[key] = VLSATModel(cfg, DEV).load_state(synth.make_weights(cfg)).eval()
     return _MODELS[key]

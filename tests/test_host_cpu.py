@@ -61,7 +61,7 @@ def test_library_exports_every_declared_symbol(L):
 def test_c_abi_argument_validation_without_gpu(L):
     lib = L.load()
     h = C.c_void_p()
-    good = L.VlsatDims(2, 8, 256, 0, 3, 160, 26, 2.6593, 1, 1)
+    good = L.VlsatDims(2, 8, 256, 0, 3, 160, 26, 2.6593, 1, 1, 0)
     for bad in (L.VlsatDims(0, 8, 256, 0, 3, 160, 26, 2.65), L.VlsatDims(2, 4, 256, 0, 3, 160, 26, 2.65),
                 L.VlsatDims(2, 8, 256, 3, 3, 160, 26, 2.65), L.VlsatDims(2, 8, 256, 0, 5, 160, 26, 2.65)):
         assert lib.vlsat_create(C.byref(bad), C.byref(h)) == -1
