@@ -90,9 +90,10 @@ void vlsat_plan_destroy(vlsat_plan p);
 int vlsat_plan_info(vlsat_plan p, int32_t* n_scenes, size_t* workspace_bytes, int32_t* is_fc);
 
 /* Mmgnet.forward(..., istrain=False), reference SGFN_MMG/model.py:288-335.
- * Device pointers: obj_points [N,3,P], obj_2d_feats [N,512], descriptor [N,11];
+ * Device pointers: obj_points [N,dim_point,P], obj_2d_feats [N,512], descriptor [N,11];
  * outputs obj_logits_3d/2d [N,n_obj_class] (logits x exp(scale)), rel_cls_3d/2d
- * [E,n_rel_class] (post-sigmoid).  Edge order of the outputs = edge order given to the plan.
+ * [E,n_rel_class] (post-sigmoid; log_softmax when multi_rel_outputs = 0).  Edge order of the outputs = edge
+ * order given to the plan.
  * 3D-only mode: pass NULL for BOTH obj_logits_2d and rel_cls_2d (obj_2d_feats may then be NULL too):
  * the whole 2D branch is skipped -- exact, because the 3D branch never reads 2D tensors. */
 int vlsat_forward(vlsat_handle h, vlsat_plan p,
