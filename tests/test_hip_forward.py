@@ -223,6 +223,14 @@ def test_two_stream_mode_is_bit_identical(monkeypatch):
     single.close()
 
 
+def test_feature_transform_ragged_vs_oracle():
+    """MODEL.feature_transform on a ragged batch: a single-object scene without edges, 100 points per object (not a
+    multiple of anything), L=2, all four outputs against the oracle (which is pinned to the reference for this switch)."""
+    cfg = VLSATConfig(N_LAYERS=2, feature_transform=True)
+    b = synth.collate([synth.make_scene(1, 100, 13000), synth.make_scene(9, 100, 13001), synth.make_scene(3, 100, 13002)])
+    _check(run_hip(cfg, b), run_oracle(cfg, b), TIGHT, "feature_transform ragged batch")
+
+
 def test_edges_interleaved_across_scenes():
     """Edges not grouped by scene: the glue permutes them (VLSAT_EGRAPH path) and un-permutes
     the relation outputs."""
