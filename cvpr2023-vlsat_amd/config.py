@@ -26,6 +26,9 @@ class VLSATConfig:
     USE_RGB: bool = False          # +3 point channels                                                   SGFN_MMG/model.py:31-35
     USE_NORMAL: bool = False       # +3 point channels
     feature_transform: bool = False  # STNkd 64x64 feature transform after conv1 of all three encoders  network_PointNet.py:52-86,146-150
+    # forward(istrain=True) extras need triplet_projector_2d (SGFN_MMG/model.py:95-100,319-322); dead at eval, so its
+    # weights are only part of the inventory when this is set
+    train_outputs: bool = False
     clip_feat_dim: int = 512
     # fixed by Mmgnet.__init__ (reference SGFN_MMG/model.py:41-86)
     dim_node: int = 512
@@ -129,4 +132,7 @@ def param_shapes(cfg: VLSATConfig) -> "OrderedDict[str, tuple]":
                     s[f"{b}.{bn}.{k}"] = (d,)
     lin("obj_predictor_3d", cfg.num_obj_class, cfg.clip_feat_dim)
     lin("obj_predictor_2d", cfg.num_obj_class, cfg.clip_feat_dim)
+    if cfg.train_outputs:            # Sequential(Linear(1536,1024), Dropout, ReLU, Linear(1024,512))
+        lin("triplet_projector_2d.0", 2 * D, 2 * D + cfg.dim_edge)
+        lin("triplet_projector_2d.3", D, 2 * D)
     return s

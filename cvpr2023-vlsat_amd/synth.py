@@ -57,6 +57,20 @@ def make_weights(cfg: VLSATConfig, seed: int = 0) -> "OrderedDict[str, np.ndarra
     return out
 
 
+def make_weights_stress(cfg: VLSATConfig, scale: float, seed: int = 0) -> "OrderedDict[str, np.ndarray]":
+    """Trained-scale stress weights: the formula weights with every GCN matrix (nn_edge, proj_*, the gate MLP, prop)
+    multiplied by ``scale`` and LayerNorm gains drawn from U(0.3, 3).  Exercises the node-side hoisting of
+    nn_edge.0 / proj_query / gate layer 1 (reference network_MMG.py:84-112) away from Xavier scale, where a
+    summation-order slip would hide below the tolerance."""
+    w = make_weights(cfg, seed)
+    for name in list(w):
+        if ".layer_norm.weight" in name:
+            w[name] = _rng(name + "/stress", seed).uniform(0.3, 3.0, w[name].shape).astype(np.float32)
+        elif (".gcn_2ds." in name or ".gcn_3ds." in name) and name.endswith(".weight"):
+            w[name] = (w[name] * np.float32(scale)).astype(np.float32)
+    return w
+
+
 def fc_edges(n: int) -> np.ndarray:
     """[2,E] source-major fully-connected pairs without self loops, E = n(n-1)."""
     src = np.repeat(np.arange(n, dtype=np.int64), n)

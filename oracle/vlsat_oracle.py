@@ -16,7 +16,11 @@ including the reference's single executable example of the gather/scatter conven
 (``network_util.py:75-99``).  Third-party arithmetic not vendored in the reference:
 ``torch_geometric`` (unpinned, README.md:31) / ``torch-scatter`` (README.md:28) -- only
 ``index_select`` gather and scatter add/mean/max (empty segment -> 0) are used; restated in
-``gen_index`` / ``aggre_index`` below.
+``gen_index`` / ``aggre_index`` below.  CAVEAT (common mode): at that boundary the golden generator's
+``MessagePassing`` stand-in (tests/golden/make_golden.py) and ``aggre_index`` here were written by the same
+hand from the same published PyG semantics and both call ``Tensor.scatter_reduce``; the reference holds no
+expected values for it (its example ``network_util.py:75-99`` only prints).  The gather direction and the
+empty-segment -> 0 rule are therefore restated, not pinned by independent data.
 
 Batch contract: one *scene* per reference call (``validation()`` uses batch_size=1,
 reference ``src/model/model.py:185``); a batch is evaluated scene by scene (the
@@ -235,17 +239,26 @@ def obj_head(x: Tensor, w: W, prefix: str, logit_scale: float) -> Tensor:
     return math.exp(logit_scale) * lin(x / x.norm(dim=-1, keepdim=True), w, prefix)
 
 
+def triplet_features_2d(x2: Tensor, e2: Tensor, ei: Tensor, w: W) -> Tensor:
+    """generate_object_pair_features + triplet_projector_2d (reference SGFN_MMG/model.py:259-264,95-100,319-322):
+    rows cat[x2[ei[0]], x2[ei[1]], e2] -> Linear(1536,1024) -> Dropout(eval: id) -> ReLU -> Linear(1024,512)."""
+    t = torch.cat([x2[ei[0]], x2[ei[1]], e2], -1)
+    return lin(torch.relu(lin(t, w, "triplet_projector_2d.0")), w, "triplet_projector_2d.3")
+
+
 def forward_scene(w: W, cfg, obj_points: Tensor, obj_2d_feats: Tensor, edge_indices: Tensor,
-                  descriptor: Tensor, taps: Optional[dict] = None):
-    """Mmgnet.forward(istrain=False) for one scene (reference SGFN_MMG/model.py:288-335).
-    The dead generate_object_pair_features / triplet_projector_2d (:319,322) are skipped:
-    their result is unused at eval."""
+                  descriptor: Tensor, taps: Optional[dict] = None, istrain: bool = False):
+    """Mmgnet.forward for one scene (reference SGFN_MMG/model.py:288-335).  istrain=False: the dead
+    generate_object_pair_features / triplet_projector_2d (:319,322) are skipped (result unused at eval).
+    istrain=True (modules still in eval mode, i.e. no dropout): additionally returns obj_feature_3d_mimic
+    (:291-292), obj_features_2d_mimic (:312), gcn_edge_feature_2d_dis (:319,322) and exp(logit scale) (:327)."""
     f = pointnet_feat(obj_points, w, "obj_encoder")                              # :290
     x3 = node_embed(f, descriptor, w)                                            # :294-299
     ed = edge_descriptor(descriptor, edge_indices)                               # :302-303
     e2 = pointnet_feat(ed[:, :, None], w, "rel_encoder_2d")                      # :305
     e3 = pointnet_feat(ed[:, :, None], w, "rel_encoder_3d")                      # :306
     x2 = adapter(obj_2d_feats, w)                                                # :309-310
+    mimic3, mimic2 = f[:, :512].clone(), x2.clone()
     if taps is not None:
         taps.update(obj_encoder=f, node_embed=x3, edge_descriptor=ed, rel_encoder_2d=e2,
                     rel_encoder_3d=e3, clip_adapter=x2)
@@ -258,7 +271,31 @@ def forward_scene(w: W, cfg, obj_points: Tensor, obj_2d_feats: Tensor, edge_indi
     rel2 = rel_head(e2, w, "rel_predictor_2d", multi)                                   # :325
     obj3 = obj_head(x3, w, "obj_predictor_3d", cfg.obj_logit_scale)              # :329
     obj2 = obj_head(x2, w, "obj_predictor_2d", cfg.obj_logit_scale)              # :330
+    if istrain:
+        dis = triplet_features_2d(x2, e2, edge_indices, w)
+        return obj3, obj2, rel3, rel2, mimic3, mimic2, dis
     return obj3, obj2, rel3, rel2
+
+
+@torch.no_grad()
+def forward_train_outputs(w: W, cfg, obj_points: Tensor, obj_2d_feats: Tensor, edge_indices: Tensor,
+                          descriptor: Tensor, batch_ids: Optional[Tensor] = None):
+    """The 8-tuple of Mmgnet.forward(istrain=True) (reference SGFN_MMG/model.py:332-333), scene by scene like
+    ``forward``; edges must be grouped by scene here (the extras are only tested on such batches)."""
+    n = obj_points.shape[0]
+    bid = (batch_ids if batch_ids is not None else torch.zeros(n, 1, dtype=torch.long)).view(-1)
+    e_scene = bid[edge_indices[0]]
+    parts = [[] for _ in range(7)]
+    for s in torch.unique_consecutive(bid).tolist():
+        nodes = torch.nonzero(bid == s).view(-1)
+        lo, hi = int(nodes[0]), int(nodes[-1]) + 1
+        eids = torch.nonzero(e_scene == s).view(-1)
+        assert eids.numel() == 0 or bool((eids[1:] == eids[:-1] + 1).all()), "edges must be grouped by scene"
+        o = forward_scene(w, cfg, obj_points[lo:hi], obj_2d_feats[lo:hi], edge_indices[:, eids] - lo, descriptor[lo:hi],
+                          istrain=True)
+        for a, b in zip(parts, o):
+            a.append(b)
+    return tuple(torch.cat(p) for p in parts) + (math.exp(cfg.obj_logit_scale),)
 
 
 @torch.no_grad()
