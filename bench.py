@@ -27,6 +27,14 @@ import vlsat_amd  # noqa: E402
 from vlsat_amd import VLSATConfig, synth, dist as vdist  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 dense (never the 2:1-sparse figure)
+# peak of the mode's matrix work counted in ALGORITHMIC flops: split-bf16 issues three bf16 MFMAs per product
+MODE_PEAK = {"fp32": PEAK_FP32_MFMA_TFLOPS, "bf16x3": PEAK_BF16_MFMA_TFLOPS / 3, "bf16": PEAK_BF16_MFMA_TFLOPS,
+             "bf16_mixed": PEAK_BF16_MFMA_TFLOPS}
+MODE_DTYPE = {"fp32": "f32",
+              "bf16x3": "bf16x3 (split-bf16 MFMA operands, 3 MFMAs per product, f32 accumulate; softmax/LN and HBM tensors f32)",
+              "bf16": "bf16 (single-rounded bf16 MFMA operands, f32 accumulate; softmax/LN and HBM tensors f32)",
+              "bf16_mixed": "bf16 on edge-row matrix work + bf16x3 on node rows (f32 accumulate; softmax/LN and HBM tensors f32)"}
 
 
 def f_alg(n, p, e, l):
@@ -34,6 +42,15 @@ def f_alg(n, p, e, l):
     return (213376 * n * p + 774144 * n + 297728 * e + 524288 * n + 2816 * n * n
             + l * (2 * (2097152 * n + 2048 * n * n) + 2 * (2949120 * e + 4849664 * n) + (2097152 * e + 2048 * e * e))
             + 2 * 799744 * e + 2 * 163840 * n)
+
+
+def oracle_all_scenes(cfg, batch_np, threads):
+    """fp32 CPU oracle on EVERY scene of this rank's batch (the parity figure of the JSON line covers all of them)."""
+    from oracle import vlsat_oracle as O
+    torch.set_num_threads(threads)
+    c = {k: torch.from_numpy(v) for k, v in batch_np.items()}
+    return O.forward(O.to_torch(synth.make_weights(cfg)), cfg, c["obj_points"], c["obj_2d_feats"], c["edge_indices"],
+                     c["descriptor"], c["batch_ids"])
 
 
 def cpu_baseline(cfg, n_obj, n_pts, budget_s=15.0, max_scenes=6):
@@ -85,8 +102,9 @@ def main():
     ap.add_argument("--layers", type=int, default=3)
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--gemm-precision", default="fp32", choices=["fp32", "bf16x3", "bf16"],
-                    help="fp32 = BASELINE configs[1] (default, the headline); bf16x3 = configs[2] (split-bf16 MFMA GEMMs)")
+    ap.add_argument("--gemm-precision", default="fp32", choices=["fp32", "bf16x3", "bf16_mixed", "bf16"],
+                    help="fp32 = BASELINE configs[1] (default, the headline); bf16x3 / bf16_mixed = configs[2] "
+                         "(split-bf16 MFMA: <=1e-3; mixed single/split bf16: <=1e-2)")
     args = ap.parse_args()
 
     rank, local, world = vdist.init()
@@ -149,8 +167,9 @@ def main():
         avg_ms = c["ms"] / max(c["launches"], 1)
         achieved = c["flops"] / (c["ms"] * 1e-3) / 1e12 if c["ms"] > 0 else 0.0
         traffic, traffic_src = None, None
-        default_wl = (args.scenes, args.objects, args.points, args.layers, args.gemm_precision) == (64, 40, 256, 3, "fp32")
-        pmc = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_bench_pmc.json")) \
+        default_wl = (args.scenes, args.objects, args.points, args.layers) == (64, 40, 256, 3)
+        tag = {"fp32": "_bench_pmc.json", "bf16x3": "_cfg3_pmc.json"}.get(args.gemm_precision, "_none_")
+        pmc = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith(tag)) \
             if os.path.isdir(os.path.join(ROOT, "profiles")) else []
         if default_wl and pmc:
             # HBM bytes per launch of the dominant kernel class from the committed rocprofv3 PMC passes of this
@@ -161,13 +180,16 @@ def main():
                 traffic_src = "profiles/" + pmc[-1]
             except Exception:
                 traffic = None
-        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+        peak = MODE_PEAK[args.gemm_precision]
+        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": round(peak, 1),
+                    "peak_note": {"fp32": "v_mfma_f32_32x32x2_f32", "bf16x3": "2.5 PF bf16 dense / 3 MFMAs per product",
+                                  "bf16": "2.5 PF bf16 dense", "bf16_mixed": "2.5 PF bf16 dense"}[args.gemm_precision],
+                    "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                     "traffic_unit": "HBM bytes per launch (PMC)", "traffic_source": traffic_src,
                     "launches_per_step": c["launches"] // args.steps, "avg_launch_ms": round(avg_ms, 4),
                     "flop_per_launch": c["flops"] / max(c["launches"], 1),
                     "whole_forward_tflops": round(falg * value / world / 1e12, 2),
-                    "whole_forward_frac": round(falg * value / world / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                    "whole_forward_frac": round(falg * value / world / 1e12 / peak, 4),
                     "time_share": {k: round(v["ms"] / max(sum(x["ms"] for x in classes.values()), 1e-9), 4)
                                    for k, v in classes.items()},
                     "class_tflops": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)
@@ -175,23 +197,23 @@ def main():
 
     cpu, err = None, None
     if world == 1 and not args.no_cpu:
-        cpu, ref0 = cpu_baseline(cfg, args.objects, args.points)
-        n, e = args.objects, e_scene
-        got0 = [out[0][:n], out[1][:n], out[2][:e], out[3][:e]]
-        err = {k: float((g.cpu() - r).abs().max()) for k, g, r in zip(("obj3d", "obj2d", "rel3d", "rel2d"), got0, ref0)}
+        cpu, _ = cpu_baseline(cfg, args.objects, args.points)
+        ref = oracle_all_scenes(cfg, batch, cpu["cores"])
+        err = {k: float((g.cpu() - r).abs().max()) for k, g, r in zip(("obj3d", "obj2d", "rel3d", "rel2d"), out, ref)}
+        err["scenes_checked"] = f"{n_scenes}/{n_scenes}"
 
     line = {
         "metric": "scenes/sec (3RScan-shaped, N=40 obj x 256 pts)", "value": round(value, 2), "unit": "scenes/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": {"fp32": "f32", "bf16x3": "bf16x3 GEMM operands (split-bf16 MFMA, f32 accumulate); attention/LN f32",
-                  "bf16": "bf16 GEMM operands (f32 accumulate); attention/LN f32"}[args.gemm_precision],
+        "dtype": MODE_DTYPE[args.gemm_precision],
         "data": "synthetic",
         "config": {"workload": f"{('BASELINE configs[1]' if args.gemm_precision == 'fp32' else 'BASELINE configs[2]') if (args.scenes, args.objects, args.points, args.layers) == (64, 40, 256, 3) else 'custom'}: batch of {args.scenes} synthetic scenes per GPU, "
                                f"{args.objects} objects x {args.points} pts, fully-connected edges "
-                               f"(E={e_scene}/scene), {args.layers} GNN layers, fp32",
+                               f"(E={e_scene}/scene), {args.layers} GNN layers, {args.gemm_precision}",
                    "scenes_per_gpu": args.scenes, "parallelism": f"scene-sharded x{world}"},
         "flop_per_scene_alg": falg,
+        "metrics_allreduced": {k: float(v) for k, v in zip(vdist.METRIC_FIELDS, metrics.tolist())},
         "roofline": roofline, "cpu_baseline": cpu, "max_abs_err_vs_cpu_oracle": err,
         "speedup_vs_cpu": round(value / cpu["value"], 1) if cpu else None,
     }

@@ -136,12 +136,7 @@ int launch_edge_gate(const GateArgs& a, hipStream_t s) {
     const int n_groups = (a.n_edges + 15) / 16;
     // persistent: 3 blocks per CU are resident (51.7 KB LDS each); every block stages the weights once
     // and walks ~n_groups/768 groups, so there is no partial last wave of blocks
-    static int cap = 0;
-    if (!cap) {
-        const char* e = getenv("VLSAT_GATE_GRID");
-        cap = e ? atoi(e) : 768;
-        if (cap < 1) cap = 768;
-    }
+    const int cap = a.grid_cap > 0 ? a.grid_cap : 768;
     const int grid = n_groups < cap ? n_groups : cap;
     hipLaunchKernelGGL(edge_gate_kernel, dim3(grid), dim3(256), 0, s, a);
     VLSAT_LAUNCH_CHECK("edge_gate");

@@ -1,0 +1,155 @@
+// Internal state of libvlsat_hip.so shared by the engine translation units:
+//   engine_weights.hip  handle life cycle, weight preparation (folding / hoisting / permutations), precision modes
+//   engine_plan.hip     graph plan: host-side graph analysis, one device arena, asynchronous index upload
+//   engine_forward.hip  the forward orchestration (vlsat_forward / vlsat_forward_train) and per-class profiling
+//   engine_api.hip      kernel-level C entry points and debug hooks
+// The public surface is include/vlsat.h.
+#pragma once
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/vlsat.h"
+#include "common.h"
+#include "kernels.h"
+
+namespace vlsat {
+
+enum ProfClass { PC_GEMM = 0, PC_FLASH, PC_POINTNET, PC_GATE, PC_NODE_ATTN, PC_LAYERNORM, PC_AGGREGATE, PC_MISC, PC_COUNT };
+
+struct AttnW {          // one MultiHeadAttention block
+    float *wq, *bq, *wkv, *bkv, *wo, *bo, *lng, *lnb;
+    float *wqkv, *bqkv;  // self-attention: fused [3D, D]
+};
+struct GcnW {           // one GraphEdgeAttenNetwork block
+    float *wnode, *bnode;   // [2*2D + H*(dn+de) + A, D]: Wi | Wj | Wgq | Wv
+    float *we1;             // [2D, D] edge part of nn_edge.0
+    float *we2, *be2;       // nn_edge.2
+    float *wpe, *bpe;       // proj_edge, rows permuted head-major
+    float *w0k, *w3, *b3;   // gate MLP
+    float *wp0, *bp0, *wp2, *bp2;
+};
+struct RelHeadW { float *w1, *b1, *w2, *b2, *w3, *b3; };
+// STNkd(k=64) with its five BatchNorm1d(eval) layers folded and the identity folded into the last bias
+struct StnW { float *c1, *c1b, *c2, *c2b, *c3, *c3b, *f1, *f1b, *f2, *f2b, *f3, *f3b; };
+// triplet_projector_2d (forward(istrain=True) only): Linear(3D, 2D) split into node-side [Wi | Wj] and edge part
+struct TripletW { float *wnode = nullptr, *bnode = nullptr, *we = nullptr, *w2 = nullptr, *b2 = nullptr; };
+
+// a pinned host staging buffer of the plan upload; `done` is recorded after the copy that reads it
+struct Staging { char* p = nullptr; size_t bytes = 0; hipEvent_t done = nullptr; };
+// a workspace arena waiting for re-use; `last` (may be null) is the last forward that touched it
+struct Arena { char* p = nullptr; size_t bytes = 0; hipEvent_t last = nullptr; };
+
+}  // namespace vlsat
+
+struct vlsat_ctx {
+    VlsatDims d{};
+    int dual_stream = 1;     // run the 2D twin stages of small plans on a second stream (vlsat_debug_option "dual_stream")
+    hipStream_t side = nullptr;
+    hipStream_t copy = nullptr;          // plan index uploads (non-blocking stream)
+    std::vector<hipEvent_t> sync_ev;     // fork/join events (timing disabled), created on first use
+    int fa_split = 1;        // allow the split-key edge attention for small plans (vlsat_debug_option "flash_split")
+    int edge_scope = 0;      // edge cross-attention keys: 0 = the query's scene, 1 = the whole batch
+    int D = 512, A = 256, H = 8, C_pt = 768;
+    std::map<std::string, std::vector<float>> host;   // raw reference-layout tensors
+    bool finalized = false;
+    std::vector<float*> dev_allocs;
+    std::vector<std::pair<const float*, size_t>> gemm_w;   // every GEMM weight matrix (pointer, elements): split eagerly in bf16 modes
+    // prepared device weights
+    float *pn_w1, *pn_b1, *pn_w2, *pn_b2, *pn_w3, *pn_b3;
+    float *mlp_w, *mlp_b;
+    float *re_w1cat, *re_b1cat;
+    float *re3_w2, *re3_b2, *re3_w3, *re3_b3, *re2_w2, *re2_b2, *re2_w3, *re2_b3;
+    float *ad_w1, *ad_b1, *ad_w2h, *ad_b2h;
+    vlsat::DistBiasW db{};
+    std::vector<vlsat::AttnW> self_attn, cross_attn, cross_rel;
+    std::vector<vlsat::GcnW> gcn3, gcn2;
+    vlsat::RelHeadW rel3{}, rel2{};
+    vlsat::StnW stn_obj{}, stn_re3{}, stn_re2{};          // MODEL.feature_transform
+    vlsat::TripletW trip{};
+    float *obj3_w, *obj3_b, *obj2_w, *obj2_b;
+    // profiling
+    bool prof = false;
+    struct Rec { int cls; hipEvent_t a, b; double flops; long kernels; };
+    std::vector<Rec> recs;
+    Rec open{};              // interval of the kernel class currently being launched (see Scope)
+    bool open_ok = false;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    double acc_ms[vlsat::PC_COUNT] = {0};
+    int64_t acc_n[vlsat::PC_COUNT] = {0};
+    double acc_fl[vlsat::PC_COUNT] = {0};
+    int debug_stop = -1;
+    int gemm_no_dma = 0, gate_grid = 0;      // vlsat_debug_option
+    long gemm_launches = 0;  // kernels launched by launch_gemm for this handle (main + tail launches)
+    int cur_N = -1;          // node count of the plan whose forward is being enqueued (row class of a GEMM launch)
+    // GEMM operand precision: 0 exact fp32 MFMA, 1 bf16, 3 split-bf16 (vlsat_set_gemm_precision); prec_edge / prec_node
+    // are what the edge-row / node-row launches actually use (mode 2 = mixed: bf16 on edge rows, bf16x3 on node rows)
+    int prec = 0, prec_edge = 0, prec_node = 0;
+    std::map<const float*, std::pair<uint16_t*, uint16_t*>> split;
+    // workspace arenas of destroyed plans, re-used by the next plan that fits (an eval loop may build one plan per
+    // scene; hipMalloc/hipFree per scene would dominate small scenes), pinned upload buffers, spare events
+    std::vector<vlsat::Arena> arena_pool;
+    std::vector<vlsat::Arena> arena_trash;          // too many pooled: freed once their last forward has completed
+    std::vector<vlsat::Staging> staging;
+    std::vector<hipEvent_t> spare_ev;
+};
+
+struct vlsat_plan_s {
+    vlsat_ctx* h = nullptr;
+    int64_t N = 0, E = 0;
+    int P = 0, S = 0, max_n = 0, is_fc = 0;
+    std::vector<int32_t> node_ptr;          // [S+1]
+    std::vector<int64_t> edge_ptr;          // [S+1]
+    size_t ws_bytes = 0;
+    char* arena = nullptr;
+    size_t arena_bytes = 0;
+    hipEvent_t uploaded = nullptr;          // index tables are in place (recorded on the handle's copy stream)
+    bool upload_pending = false;            // the next forward must make its stream wait for `uploaded`
+    hipEvent_t last_use = nullptr;          // recorded at the end of every forward on that forward's stream
+    bool used = false;
+    // device index arrays
+    int32_t *d_src, *d_dst, *d_rowptr, *d_order, *d_scene_ptr;
+    int64_t* d_bias_ptr;
+    int4* d_tiles;
+    int n_tiles = 0;
+    // split-key mode of the edge attention for plans with too few blocks to fill the chip (flash_attn_*.hip)
+    int fa_parts = 1;
+    int4* d_krange = nullptr;
+    float *fa_opart = nullptr, *fa_m = nullptr, *fa_l = nullptr;
+    double flash_flops = 0;
+    // device float buffers
+    float *F, *X3, *X2, *NP, *QKVn, *On, *T256, *T768, *rs, *bias;
+    float *H1, *H2, *E3, *E2, *Hbig, *KP, *G, *Qe, *KVe, *Oe, *R1, *R2, *prob;
+    // Small plans (launch-bound: one scene per call) run the 2D twin of every stage -- relation encoder, adapter,
+    // gcn_2ds, the query projection of the edge attention, the 2D heads -- on a second stream, concurrently with
+    // the 3D twin.  The twins never touch each other's tensors; they only shared scratch, so the 2D side gets its own.
+    float* stn_ws = nullptr;                        // MODEL.feature_transform scratch (carved per phase in stn_encoder)
+    size_t stn_ws_floats = 0;
+    bool dual = false;
+    float *NP2 = nullptr, *Hbig2 = nullptr, *KP2 = nullptr, *G2 = nullptr, *T768b = nullptr, *rs2 = nullptr, *H2b = nullptr;
+};
+
+namespace vlsat {
+
+extern const char* kProfNames[PC_COUNT];
+
+// scratch buffers of one modality branch
+struct Scratch { float *NP, *Hbig, *KP, *G, *T768, *R1, *R2, *rs, *H2; };
+
+#define RUN(expr)                  \
+    do {                           \
+        int _r = (expr);           \
+        if (_r) return _r;         \
+    } while (0)
+
+// engine_weights.hip
+const char* last_error_cstr();
+int split_all_weights(vlsat_ctx* h);
+// engine_plan.hip
+hipEvent_t take_event(vlsat_ctx* h);
+void give_event(vlsat_ctx* h, hipEvent_t e);
+void release_plan_resources(vlsat_ctx* h);       // frees pools (vlsat_destroy)
+
+}  // namespace vlsat

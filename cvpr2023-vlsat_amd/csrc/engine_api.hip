@@ -1,0 +1,125 @@
+// Kernel-level C entry points (unit tests and tools drive single kernels through these) and debug hooks.
+#include <cstring>
+#include <vector>
+
+#include "engine.h"
+
+using namespace vlsat;
+
+extern "C" {
+
+const char* vlsat_last_error(void) { return last_error_cstr(); }
+
+// debug: stop the forward after stage `stage` (see DESIGN.md "debug stages"); -1 = run all
+int vlsat_debug_stop_after(vlsat_handle h, int32_t stage) {
+    if (!h) return fail(VLSAT_EINVAL, "null handle");
+    h->debug_stop = stage;
+    return 0;
+}
+
+// debug: while `buf` (device, >= 4 * 512 int64) is set, every persistent GEMM block writes
+// {shader cycles, 100 MHz wall ticks, tiles done, 1} at exit: effective clock = cycles / (ticks / 1e8)
+int vlsat_debug_gemm_clock_probe(int64_t* buf) {
+    gemm_set_clock_probe(reinterpret_cast<long long*>(buf));
+    return 0;
+}
+
+// Keys of the edge cross-attention for plans created from now on (see vlsat.h)
+int vlsat_set_edge_attention_scope(vlsat_handle h, int32_t scope) {
+    if (!h) return fail(VLSAT_EINVAL, "null handle");
+    if (scope != 0 && scope != 1) return fail(VLSAT_EINVAL, "edge attention scope: 0 (per scene) or 1 (whole batch)");
+    h->edge_scope = scope;
+    return 0;
+}
+
+// debug / experiment switches of one handle (they replace the VLSAT_* environment variables of round 1; defaults are
+// the measured-best settings and none changes results beyond fp32 summation order):
+//   "dual_stream" 0|1   2D twin stages of small plans on a second stream (plans created afterwards)
+//   "flash_split" 0|1   split-key edge attention for plans that cannot fill the chip (plans created afterwards)
+//   "gemm_dma"    0|1   LDS-direct staging of fp32 GEMM operands (0: VGPR-staged)
+//   "gate_grid"   n     persistent grid of the gate kernel (0: default)
+int vlsat_debug_option(vlsat_handle h, const char* name, int32_t value) {
+    if (!h || !name) return fail(VLSAT_EINVAL, "vlsat_debug_option: null argument");
+    const std::string k(name);
+    if (k == "dual_stream") h->dual_stream = value != 0;
+    else if (k == "flash_split") h->fa_split = value != 0;
+    else if (k == "gemm_dma") h->gemm_no_dma = value == 0;
+    else if (k == "gate_grid") h->gate_grid = value > 0 ? value : 0;
+    else return fail(VLSAT_EINVAL, "vlsat_debug_option: unknown option " + k);
+    return 0;
+}
+
+// -------------------------------------------------------------------------------------------
+int vlsat_k_gemm(const float* A, int32_t lda, const float* W, int32_t ldw, float* C, int32_t ldc, int32_t M, int32_t N,
+                 int32_t K, const float* bias, const float* rowscale, const float* resid, int32_t ldr, float resid_scale,
+                 const float* g0, const int32_t* gi0, int32_t ldg0, const float* g1, const int32_t* gi1, int32_t ldg1,
+                 int32_t relu_a, int32_t act, void* stream) {
+    GemmArgs a;
+    a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
+    a.bias = bias; a.rowscale = rowscale; a.resid = resid; a.ldr = ldr; a.resid_scale = resid_scale;
+    a.g0 = g0; a.gi0 = gi0; a.ldg0 = ldg0; a.g1 = g1; a.gi1 = gi1; a.ldg1 = ldg1; a.relu_a = relu_a; a.act = act;
+    return launch_gemm(a, static_cast<hipStream_t>(stream));
+}
+
+int vlsat_k_pointnet(const float* pts, int32_t n_obj, int32_t n_points, const float* w1, const float* b1,
+                     const float* w2, const float* b2, const float* w3, const float* b3, int32_t n_out, float* out,
+                     void* stream) {
+    return launch_pointnet(pts, n_obj, n_points, 3, w1, b1, w2, b2, w3, b3, n_out, out, static_cast<hipStream_t>(stream));
+}
+
+int vlsat_k_flash_attn(const float* Q, const float* K, const float* V, float* O, int32_t ld, const int64_t* tok_ptr,
+                       int32_t n_scenes, int32_t n_heads, float scale, void* stream) {
+    if (!tok_ptr || n_scenes <= 0) return fail(VLSAT_EINVAL, "flash_attn: bad scene table");
+    std::vector<int4> tiles;
+    for (int s = 0; s < n_scenes; ++s) {
+        const int64_t T = tok_ptr[s + 1] - tok_ptr[s];
+        for (int hh = 0; hh < n_heads; ++hh)
+            for (int64_t q0 = 0; q0 < T; q0 += FLASH_BQ) tiles.push_back(make_int4((int)tok_ptr[s], (int)T, (int)q0, hh));
+    }
+    if (tiles.empty()) return 0;
+    int4* d = nullptr;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    VLSAT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d), tiles.size() * sizeof(int4)));
+    VLSAT_HIP_CHECK(hipMemcpy(d, tiles.data(), tiles.size() * sizeof(int4), hipMemcpyHostToDevice));
+    int r = launch_flash_attn(Q, ld, K, V, ld, O, ld, d, (int)tiles.size(), scale * 1.4426950408889634f, st);
+    hipStreamSynchronize(st);     // test entry point only: the tile table is freed right away
+    hipFree(d);
+    return r;
+}
+
+int vlsat_prepare_objects(const float* scene_points, const int32_t* choice, int32_t n_obj, int32_t n_points,
+                          float* obj_points, float* descriptor, void* stream) {
+    if (!scene_points || !choice || !obj_points || !descriptor) return fail(VLSAT_EINVAL, "prepare_objects: null argument");
+    return launch_prepare_objects(scene_points, choice, n_obj, n_points, obj_points, descriptor, static_cast<hipStream_t>(stream));
+}
+
+int vlsat_fc_edges(const int32_t* node_ptr, const int64_t* edge_ptr, int32_t n_scenes, int64_t n_nodes, int64_t n_edges,
+                   int64_t* edges, int64_t* batch_ids, void* stream) {
+    if (!node_ptr || !edge_ptr || !batch_ids || (n_edges > 0 && !edges) || n_scenes <= 0)
+        return fail(VLSAT_EINVAL, "fc_edges: bad argument");
+    return launch_fc_edges(node_ptr, edge_ptr, n_scenes, n_nodes, n_edges, edges, batch_ids, static_cast<hipStream_t>(stream));
+}
+
+int vlsat_k_softmax_rows(const float* x, int32_t ld, int32_t rows, int32_t cols, float* out, void* stream) {
+    if (!x || !out) return fail(VLSAT_EINVAL, "softmax_rows: null argument");
+    return launch_softmax_rows(x, ld, rows, cols, out, 0, static_cast<hipStream_t>(stream));
+}
+
+int vlsat_eval_ranks(const float* obj_logits, const float* obj_probs, const float* rel_probs, const int64_t* gt_class,
+                     const int64_t* gt_rel, const int64_t* edges, int32_t n_nodes, int32_t n_edges, int32_t n_obj_class,
+                     int32_t n_rel_class, int32_t topk_obj, int32_t topk_rel, int32_t topk_triplet, float threshold,
+                     int32_t* obj_rank, int32_t* rel_rank, int32_t* tri_rank, int32_t* cnt, void* stream) {
+    if (!obj_logits || !obj_probs || !gt_class || !obj_rank) return fail(VLSAT_EINVAL, "eval_ranks: null argument");
+    if (n_edges > 0 && (!rel_probs || !gt_rel || !edges || !rel_rank || !tri_rank || !cnt))
+        return fail(VLSAT_EINVAL, "eval_ranks: null edge argument");
+    return launch_eval_ranks(obj_logits, obj_probs, rel_probs, gt_class, gt_rel, edges, n_nodes, n_edges, n_obj_class,
+                             n_rel_class, topk_obj, topk_rel, topk_triplet, threshold, obj_rank, rel_rank, tri_rank, cnt,
+                             static_cast<hipStream_t>(stream));
+}
+
+int vlsat_k_layernorm(float* x, int32_t ld, int32_t rows, int32_t dim, const float* gamma, const float* beta,
+                      int32_t relu, void* stream) {
+    return launch_layernorm(x, ld, rows, dim, gamma, beta, relu, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,447 @@
+// Forward orchestration of libvlsat_hip.so: Mmgnet.forward (reference src/model/SGFN_MMG/model.py:288-335) as a
+// sequence of launches of the hand-written kernels of this directory on the caller's stream (plus, for small plans,
+// a second stream for the 2D twin stages), and the per-kernel-class HIP-event profiling bench.py reads.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "engine.h"
+
+using namespace vlsat;
+
+static Scratch scratch_of(const vlsat_plan_s* p, int branch) {
+    if (branch == 1 && p->dual)
+        return {p->NP2, p->Hbig2, p->KP2, p->G2, p->T768b, p->Hbig2, p->Hbig2 + (size_t)std::max<int64_t>(p->E, 1) * 512, p->rs2, p->H2b};
+    return {p->NP, p->Hbig, p->KP, p->G, p->T768, p->R1, p->R2, p->rs, p->H2};
+}
+
+namespace {
+
+// ---- profiling helpers ----
+hipEvent_t next_event(vlsat_ctx* h) {
+    if (h->ev_used == h->ev_pool.size()) {
+        hipEvent_t e;
+        hipEventCreate(&e);
+        h->ev_pool.push_back(e);
+    }
+    return h->ev_pool[h->ev_used++];
+}
+// Per-class timing with as few events as possible: an event is recorded only where the kernel CLASS changes
+// (a run of consecutive launches of one class is one interval), plus one at the end of the forward.
+struct Scope {
+    vlsat_ctx* h;
+    hipStream_t s;
+    int cls;
+    double flops;
+    long k0 = 0;
+    Scope(vlsat_ctx* h_, hipStream_t s_, int cls_, double fl) : h(h_), s(s_), cls(cls_), flops(fl) {
+        k0 = h->gemm_launches;
+        if (!h->prof) return;
+        if (h->open_ok && h->open.cls == cls) return;              // same class: the open interval continues
+        hipEvent_t e = next_event(h);
+        hipEventRecord(e, s);
+        if (h->open_ok) { h->open.b = e; h->recs.push_back(h->open); }
+        h->open = {cls, e, e, 0.0, 0};
+        h->open_ok = true;
+    }
+    ~Scope() {
+        if (!h->prof) return;
+        h->open.flops += flops;
+        h->open.kernels += cls == PC_GEMM ? h->gemm_launches - k0 : 1;
+    }
+};
+// end of a forward (or of a debug-stopped one): close the open interval
+static void profile_close(vlsat_ctx* h, hipStream_t s) {
+    if (!h->prof || !h->open_ok) return;
+    hipEvent_t e = next_event(h);
+    hipEventRecord(e, s);
+    h->open.b = e;
+    h->recs.push_back(h->open);
+    h->open_ok = false;
+}
+
+// Every nn.Linear of the path.  Operand precision follows the handle's mode: node-row launches (M == number of nodes
+// of the running plan) take prec_node, everything else (edge rows, point rows) prec_edge; the bf16 planes of the
+// weights were made when the mode was set (engine_weights.hip), so nothing is allocated or converted here.
+int gemm(vlsat_ctx* h, hipStream_t s, const GemmArgs& a0) {
+    GemmArgs a = a0;
+    const int prec = a.M == h->cur_N ? h->prec_node : h->prec_edge;
+    if (prec) {
+        auto it = h->split.find(a.W);
+        if (it == h->split.end()) return fail(VLSAT_ESTATE, "gemm: weight has no bf16 planes (set the precision after loading weights)");
+        a.prec = prec;
+        a.Whi = it->second.first;
+        a.Wlo = it->second.second;
+    }
+    a.no_dma = h->gemm_no_dma;
+    a.launches = &h->gemm_launches;
+    Scope sc(h, s, PC_GEMM, gemm_flops(a));
+    return launch_gemm(a, s);
+}
+
+GemmArgs G(const float* A, int lda, const float* W, int K, float* C, int ldc, int M, int N, const float* bias,
+           int act = ACT_NONE) {
+    GemmArgs g;
+    g.A = A; g.lda = lda; g.W = W; g.ldw = K; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.bias = bias; g.act = act;
+    return g;
+}
+
+int attn_block(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const AttnW& w, float* xq, const float* xkv, bool self) {
+    const int N = (int)p->N, D = h->D, LDX = 768;
+    if (self) {
+        RUN(gemm(h, s, G(xq, LDX, w.wqkv, D, p->QKVn, 3 * D, N, 3 * D, w.bqkv)));
+    } else {
+        RUN(gemm(h, s, G(xq, LDX, w.wq, D, p->QKVn, 3 * D, N, D, w.bq)));
+        RUN(gemm(h, s, G(xkv, LDX, w.wkv, D, p->QKVn + D, 3 * D, N, 2 * D, w.bkv)));
+    }
+    {
+        Scope sc(h, s, PC_NODE_ATTN, 0);
+        RUN(launch_node_attn(p->QKVn, 3 * D, p->QKVn + D, 3 * D, p->QKVn + 2 * D, 3 * D, p->On, D, p->bias,
+                             p->d_scene_ptr, p->d_bias_ptr, p->S, p->max_n, h->H, 1.0f, s));
+    }
+    GemmArgs o = G(p->On, D, w.wo, D, xq, LDX, N, D, w.bo);
+    o.resid = xq; o.ldr = LDX;
+    RUN(gemm(h, s, o));
+    {
+        Scope sc(h, s, PC_LAYERNORM, 0);
+        RUN(launch_layernorm(xq, LDX, N, D, w.lng, w.lnb, 0, s));
+    }
+    return 0;
+}
+
+int gcn_block(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const GcnW& w, float* x, float* e, int e_relu_pending,
+              int out_relu, const Scratch& sc) {
+    const int N = (int)p->N, E = (int)p->E, D = h->D, A = h->A, LDX = 768, NPC = 3328;
+    RUN(gemm(h, s, G(x, LDX, w.wnode, D, sc.NP, NPC, N, NPC, w.bnode)));
+    GemmArgs e1 = G(e, D, w.we1, D, sc.Hbig, 2 * D, E, 2 * D, nullptr, ACT_RELU);
+    e1.relu_a = e_relu_pending;
+    e1.g0 = sc.NP; e1.gi0 = p->d_src; e1.ldg0 = NPC;
+    e1.g1 = sc.NP + 2 * D; e1.gi1 = p->d_dst; e1.ldg1 = NPC;
+    RUN(gemm(h, s, e1));
+    if (h->d.use_gcn_edge) {              // proj_edge feeds only the gate MLP (reference network_MMG.py:98-102)
+        GemmArgs kp = G(e, D, w.wpe, D, sc.KP, D, E, D, w.bpe);
+        kp.relu_a = e_relu_pending;
+        RUN(gemm(h, s, kp));
+    }
+    RUN(gemm(h, s, G(sc.Hbig, 2 * D, w.we2, 2 * D, e, D, E, D, w.be2)));   // e <- nn_edge output (pre-activation)
+    {
+        GateArgs g{};
+        g.kproj = sc.KP; g.node = sc.NP; g.ld_node = NPC; g.gq_off = 4 * D; g.v_off = 4 * D + h->H * 128;
+        g.src = p->d_src; g.dst = p->d_dst; g.w0k = w.w0k; g.w3 = w.w3; g.b3 = w.b3; g.gated = sc.G;
+        g.prob = p->prob; g.n_edges = E; g.use_edge = h->d.use_gcn_edge; g.grid_cap = h->gate_grid;
+        Scope scope(h, s, PC_GATE, (double)E * h->H * (2.0 * 64 * 128 + 2.0 * 128 * 32));
+        RUN(launch_edge_gate(g, s));
+    }
+    {
+        Scope scope(h, s, PC_AGGREGATE, 0);
+        RUN(launch_aggregate(sc.G, A, p->d_rowptr, p->d_order, N, h->d.gcn_aggr, x, LDX, D, s));
+    }
+    RUN(gemm(h, s, G(x, LDX, w.wp0, D + A, sc.T768, D + A, N, D + A, w.bp0, ACT_RELU)));
+    RUN(gemm(h, s, G(sc.T768, D + A, w.wp2, D + A, x, LDX, N, D, w.bp2, out_relu ? ACT_RELU : ACT_NONE)));
+    return 0;
+}
+
+int rel_head(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const RelHeadW& w, const float* e, int relu_a, float* out,
+             const Scratch& sc) {
+    const int E = (int)p->E, D = h->D, R = h->d.n_rel_class;
+    GemmArgs a = G(e, D, w.w1, D, sc.R1, 512, E, 512, w.b1, ACT_RELU);
+    a.relu_a = relu_a;
+    RUN(gemm(h, s, a));
+    RUN(gemm(h, s, G(sc.R1, 512, w.w2, 512, sc.R2, 256, E, 256, w.b2, ACT_RELU)));
+    // multi_rel_outputs: sigmoid (PointNetRelClsMulti) or log_softmax over the R classes (PointNetRelCls)
+    RUN(gemm(h, s, G(sc.R2, 256, w.w3, 256, out, R, E, R, w.b3, h->d.multi_rel_outputs ? ACT_SIGMOID : ACT_NONE)));
+    if (!h->d.multi_rel_outputs) {
+        Scope scope(h, s, PC_MISC, 0);
+        RUN(launch_softmax_rows(out, R, E, R, out, 1, s));
+    }
+    return 0;
+}
+
+int obj_head(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const float* x, const float* w, const float* b, float* out,
+             const Scratch& sc) {
+    const int N = (int)p->N, D = h->D, C = h->d.n_obj_class;
+    {
+        Scope scope(h, s, PC_MISC, 0);
+        RUN(launch_row_invnorm(x, 768, N, D, std::exp(h->d.obj_logit_scale), sc.rs, s));
+    }
+    GemmArgs a = G(x, 768, w, D, out, C, N, C, b);
+    a.rowscale = sc.rs;
+    RUN(gemm(h, s, a));
+    return 0;
+}
+
+int stn_encoder(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const StnW& w, const float* h1, int ldh, size_t R, int P,
+                const float* w2, const float* b2, const float* w3, const float* b3, int n_out, float** out_rows) {
+    const size_t O = R / P;
+    float* ws = p->stn_ws;
+    float* a64 = ws;             ws += R * 64;
+    float* a128 = ws;            ws += R * 128;
+    float* a1024 = ws;           ws += R * 1024;
+    float* h1t = ws;             ws += R * 64;
+    float* g = ws;               ws += O * 1024;
+    float* f1 = ws;              ws += O * 512;
+    float* f2 = ws;              ws += O * 256;
+    float* T = ws;               ws += O * 4096;
+    if ((size_t)(ws - p->stn_ws) > p->stn_ws_floats) return fail(VLSAT_ESTATE, "feature_transform scratch too small");
+    const int Ri = (int)R, Oi = (int)O;
+    RUN(gemm(h, s, G(h1, ldh, w.c1, 64, a64, 64, Ri, 64, w.c1b, ACT_RELU)));
+    RUN(gemm(h, s, G(a64, 64, w.c2, 64, a128, 128, Ri, 128, w.c2b, ACT_RELU)));
+    RUN(gemm(h, s, G(a128, 128, w.c3, 128, a1024, 1024, Ri, 1024, w.c3b, ACT_RELU)));
+    const float* gp = a1024;
+    if (P > 1) {
+        Scope sc(h, s, PC_MISC, 0);
+        RUN(launch_rowmax(a1024, 1024, Oi, P, 1024, g, 1024, s));
+        gp = g;
+    }
+    RUN(gemm(h, s, G(gp, 1024, w.f1, 1024, f1, 512, Oi, 512, w.f1b, ACT_RELU)));
+    RUN(gemm(h, s, G(f1, 512, w.f2, 512, f2, 256, Oi, 256, w.f2b, ACT_RELU)));
+    RUN(gemm(h, s, G(f2, 256, w.f3, 256, T, 4096, Oi, 4096, w.f3b)));
+    {
+        Scope sc(h, s, PC_MISC, 0);
+        RUN(launch_apply_stn(h1, ldh, T, R, P, h1t, 64, s));
+    }
+    RUN(gemm(h, s, G(h1t, 64, w2, 64, a128, 128, Ri, 128, b2, ACT_RELU)));
+    RUN(gemm(h, s, G(a128, 128, w3, 128, a1024, n_out, Ri, n_out, b3, ACT_RELU)));
+    *out_rows = a1024;
+    return 0;
+}
+
+}  // namespace
+
+// ============================================================================================
+extern "C" {
+
+// -------------------------------------------------------------------------------------------
+struct TrainOut { float *mimic3d, *mimic2d, *edge_dis; };
+
+static int forward_impl(vlsat_handle h, vlsat_plan p, const float* pts, const float* f2d, const float* desc,
+                        float* obj3d, float* obj2d, float* rel3d, float* rel2d, const TrainOut* tr, void* stream) {
+    if (!h || !p || !pts || !desc || !obj3d) return fail(VLSAT_EINVAL, "vlsat_forward: null argument");
+    if (p->h != h) return fail(VLSAT_EINVAL, "plan belongs to a different handle");
+    // 3D-only mode: both 2D outputs NULL -> the 2D branch (adapter, cross-attention, gcn_2ds, edge
+    // cross-attention, 2D heads) is skipped.  Exact: the 3D branch never reads 2D tensors.
+    const bool do2d = obj2d != nullptr || rel2d != nullptr;
+    if (do2d && (!obj2d || !f2d || (p->E > 0 && !rel2d)))
+        return fail(VLSAT_EINVAL, "vlsat_forward: 2D branch needs obj_2d_feats and both 2D outputs (or neither for 3D-only)");
+    if (p->E > 0 && !rel3d) return fail(VLSAT_EINVAL, "vlsat_forward: null relation output");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int N = (int)p->N, E = (int)p->E, D = h->D, L = h->d.n_layers, LDX = 768;
+    const int stop = h->debug_stop;
+    h->cur_N = N;
+    if (p->upload_pending) {               // the plan's index tables travel on the handle's copy stream
+        VLSAT_HIP_CHECK(hipStreamWaitEvent(s, p->uploaded, 0));
+        if (hipEventQuery(p->uploaded) == hipSuccess) p->upload_pending = false;
+    }
+    p->used = true;
+    profile_close(h, s);                   // an interval left open by a failed forward must not span foreign work
+#define STAGE(id) do { if (stop == (id)) { profile_close(h, s); hipEventRecord(p->last_use, s); return 0; } } while (0)
+
+    // Two-stream mode (small plans only; not while profiling or stopping at a debug stage): `t` carries the 2D twin
+    // of a stage while `s` carries the 3D one.  fork(): t waits for everything enqueued on s so far; join(): s waits
+    // for t.  Every forward ends joined, so the caller only ever sees its own stream.
+    const bool dual = p->dual && do2d && !h->prof && stop < 0 && !tr;
+    hipStream_t t = s;
+    size_t ev_i = 0;
+    if (dual) {
+        if (!h->side) VLSAT_HIP_CHECK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+        t = h->side;
+    }
+    auto next_ev = [&](hipEvent_t* e) -> int {
+        if (ev_i == h->sync_ev.size()) {
+            hipEvent_t n;
+            VLSAT_HIP_CHECK(hipEventCreateWithFlags(&n, hipEventDisableTiming));
+            h->sync_ev.push_back(n);
+        }
+        *e = h->sync_ev[ev_i++];
+        return 0;
+    };
+    auto order = [&](hipStream_t first, hipStream_t then) -> int {       // `then` continues after `first`'s work so far
+        if (!dual) return 0;
+        hipEvent_t e;
+        RUN(next_ev(&e));
+        VLSAT_HIP_CHECK(hipEventRecord(e, first));
+        VLSAT_HIP_CHECK(hipStreamWaitEvent(then, e, 0));
+        return 0;
+    };
+    auto fork = [&]() { return order(s, t); };
+    auto join = [&]() { return order(t, s); };
+    const Scratch sc3 = scratch_of(p, 0), sc2 = scratch_of(p, dual ? 1 : 0);
+
+    const bool ft = h->d.feature_transform != 0;
+    if (!ft) {   // a-2 object encoder
+        Scope sc(h, s, PC_POINTNET, 213376.0 * N * p->P);
+        RUN(launch_pointnet(pts, N, p->P, h->d.dim_point, h->pn_w1, h->pn_b1, h->pn_w2, h->pn_b2, h->pn_w3, h->pn_b3, h->C_pt, p->F, s));
+    } else {     // a-2 with the STNkd feature transform: conv1 as point rows, then GEMMs + a max over each object's rows
+        float* rows = p->stn_ws + p->stn_ws_floats - (size_t)N * p->P * 64;       // h1 rows live at the end of the scratch
+        {
+            Scope sc(h, s, PC_MISC, 0);
+            RUN(launch_pts_conv1_rows(pts, N, p->P, h->d.dim_point, h->pn_w1, h->pn_b1, rows, s));
+        }
+        float* out = nullptr;
+        RUN(stn_encoder(h, p, s, h->stn_obj, rows, 64, (size_t)N * p->P, p->P, h->pn_w2, h->pn_b2, h->pn_w3, h->pn_b3, h->C_pt, &out));
+        Scope sc(h, s, PC_MISC, 0);
+        RUN(launch_rowmax(out, h->C_pt, N, p->P, h->C_pt, p->F, 768, s));
+    }
+    if (tr && tr->mimic3d)                 // obj_feature[..., :512] (reference SGFN_MMG/model.py:291-292)
+        VLSAT_HIP_CHECK(hipMemcpy2DAsync(tr->mimic3d, 512 * sizeof(float), p->F, 768 * sizeof(float), 512 * sizeof(float), N,
+                                         hipMemcpyDeviceToDevice, s));
+    STAGE(1);
+    // a-3 mlp_3d (+BN folded) + spatial tail -> X3[:, 0:512]
+    RUN(gemm(h, s, G(p->F, 768, h->mlp_w, 768, p->X3, LDX, N, D - 8, h->mlp_b, ACT_RELU)));
+    {
+        Scope sc(h, s, PC_MISC, 0);
+        RUN(launch_desc_tail(desc, N, p->X3, LDX, D - 8, s));
+    }
+    STAGE(2);
+    // a-4/a-5 edge descriptor + relation encoders
+    {
+        Scope sc(h, s, PC_MISC, 0);
+        RUN(launch_edge_embed(desc, p->d_src, p->d_dst, E, h->re_w1cat, h->re_b1cat, p->H1, s));
+    }
+    RUN(fork());                                                            // t: 2D relation encoder + adapter
+    if (!ft) {
+        RUN(gemm(h, s, G(p->H1, 128, h->re3_w2, 64, sc3.H2, 128, E, 128, h->re3_b2, ACT_RELU)));
+        RUN(gemm(h, s, G(sc3.H2, 128, h->re3_w3, 128, p->E3, D, E, D, h->re3_b3, ACT_RELU)));
+        if (do2d) {
+            RUN(gemm(h, t, G(p->H1 + 64, 128, h->re2_w2, 64, sc2.H2, 128, E, 128, h->re2_b2, ACT_RELU)));
+            RUN(gemm(h, t, G(sc2.H2, 128, h->re2_w3, 128, p->E2, D, E, D, h->re2_b3, ACT_RELU)));
+        }
+    } else if (E > 0) {   // P = 1: one row per edge; both encoders share the scratch, so they run one after the other on s
+        for (int br = 0; br < (do2d ? 2 : 1); ++br) {
+            float* out = nullptr;
+            RUN(stn_encoder(h, p, s, br ? h->stn_re2 : h->stn_re3, p->H1 + 64 * br, 128, (size_t)E, 1, br ? h->re2_w2 : h->re3_w2,
+                            br ? h->re2_b2 : h->re3_b2, br ? h->re2_w3 : h->re3_w3, br ? h->re2_b3 : h->re3_b3, D, &out));
+            VLSAT_HIP_CHECK(hipMemcpyAsync(br ? p->E2 : p->E3, out, (size_t)E * D * sizeof(float), hipMemcpyDeviceToDevice, s));
+        }
+    }
+    STAGE(3);
+    // a-6 adapter -> X2[:, 0:512]
+    if (do2d) {
+        RUN(gemm(h, t, G(f2d, D, h->ad_w1, D, p->T256, 256, N, 256, h->ad_b1, ACT_RELU)));
+        GemmArgs a = G(p->T256, 256, h->ad_w2h, 256, p->X2, LDX, N, D, h->ad_b2h);
+        a.resid = f2d; a.ldr = D; a.resid_scale = 0.5f;
+        RUN(gemm(h, t, a));
+        if (tr && tr->mimic2d)             // the adapter's output before the MMG touches it (:312)
+            VLSAT_HIP_CHECK(hipMemcpy2DAsync(tr->mimic2d, 512 * sizeof(float), p->X2, LDX * sizeof(float), 512 * sizeof(float), N,
+                                             hipMemcpyDeviceToDevice, t));
+    }
+    STAGE(4);
+    {   // a-7 distance bias
+        Scope sc(h, s, PC_MISC, 0);
+        RUN(launch_dist_bias(desc, 11, p->d_scene_ptr, p->d_bias_ptr, p->S, p->max_n, h->H, h->db, p->bias, s));
+    }
+    STAGE(5);
+    int e3_pending_relu = 0;
+    for (int l = 0; l < L; ++l) {
+        const int inter = (l < L - 1 || L == 1) ? 1 : 0;     // reference network_MMG.py:236
+        const int base = 10 + 10 * l;
+        RUN(attn_block(h, p, s, h->self_attn[l], p->X3, p->X3, true));                  // :217
+        STAGE(base + 0);
+        RUN(join());                                          // X2 / E2 of the previous stage are complete
+        if (do2d) RUN(attn_block(h, p, s, h->cross_attn[l], p->X2, p->X3, false));      // :218
+        STAGE(base + 1);
+        RUN(fork());                                          // t: gcn_2ds + query projection; s: gcn_3ds + key/value projection
+        RUN(gcn_block(h, p, s, h->gcn3[l], p->X3, p->E3, e3_pending_relu, inter, sc3)); // :224
+        STAGE(base + 2);
+        if (do2d) RUN(gcn_block(h, p, t, h->gcn2[l], p->X2, p->E2, 0, inter, sc2));     // :225
+        STAGE(base + 3);
+        if (do2d) {   // :231 edge cross-attention: q = 2D edges, k = v = 3D edges (pre-activation)
+            const AttnW& w = h->cross_rel[l];
+            RUN(gemm(h, t, G(p->E2, D, w.wq, D, p->Qe, D, E, D, w.bq)));
+            RUN(gemm(h, s, G(p->E3, D, w.wkv, D, p->KVe, 2 * D, E, 2 * D, w.bkv)));
+            RUN(join());
+            {
+                Scope sc(h, s, PC_FLASH, p->flash_flops);
+                FlashSplit sp;
+                sp.parts = p->fa_parts; sp.krange = p->d_krange; sp.o_part = p->fa_opart; sp.m_part = p->fa_m;
+                sp.l_part = p->fa_l; sp.part_stride = (size_t)E * D; sp.rows = E; sp.heads = h->H;
+                RUN(launch_flash_attn(p->Qe, D, p->KVe, p->KVe + D, 2 * D, p->Oe, D, p->d_tiles, p->n_tiles,
+                                      0.125f * 1.4426950408889634f, s, &sp));
+            }
+            GemmArgs o = G(p->Oe, D, w.wo, D, p->E2, D, E, D, w.bo);
+            o.resid = p->E2; o.ldr = D;
+            RUN(gemm(h, s, o));
+            Scope sc(h, s, PC_LAYERNORM, 0);
+            RUN(launch_layernorm(p->E2, D, E, D, w.lng, w.lnb, inter, s));
+        }
+        e3_pending_relu = inter;
+        STAGE(base + 4);
+    }
+    if (tr && tr->edge_dis && E > 0) {
+        // gcn_edge_feature_2d_dis = triplet_projector_2d(cat[x2[ei[0]], x2[ei[1]], e2]) (:259-264,319-322): node columns of
+        // its first Linear on N rows, gathered into the edge GEMM's accumulators like nn_edge.0
+        if (!h->trip.wnode) return fail(VLSAT_ESTATE, "forward(istrain=True): triplet_projector_2d weights were not loaded");
+        const int NPC = 3328;
+        RUN(gemm(h, s, G(p->X2, LDX, h->trip.wnode, D, sc2.NP, NPC, N, 4 * D, h->trip.bnode)));
+        GemmArgs e1 = G(p->E2, D, h->trip.we, D, sc2.Hbig, 2 * D, E, 2 * D, nullptr, ACT_RELU);
+        e1.g0 = sc2.NP; e1.gi0 = p->d_src; e1.ldg0 = NPC;
+        e1.g1 = sc2.NP + 2 * D; e1.gi1 = p->d_dst; e1.ldg1 = NPC;
+        RUN(gemm(h, s, e1));
+        RUN(gemm(h, s, G(sc2.Hbig, 2 * D, h->trip.w2, 2 * D, tr->edge_dis, D, E, D, h->trip.b2)));
+    }
+    // a-15 relation heads, a-16 object heads
+    RUN(fork());                                              // t: the 2D heads
+    if (E > 0) {
+        RUN(rel_head(h, p, s, h->rel3, p->E3, e3_pending_relu, rel3d, sc3));
+        if (do2d) RUN(rel_head(h, p, t, h->rel2, p->E2, 0, rel2d, sc2));
+    }
+    RUN(obj_head(h, p, s, p->X3, h->obj3_w, h->obj3_b, obj3d, sc3));
+    if (do2d) RUN(obj_head(h, p, t, p->X2, h->obj2_w, h->obj2_b, obj2d, sc2));
+    RUN(join());
+    profile_close(h, s);
+    VLSAT_HIP_CHECK(hipEventRecord(p->last_use, s));
+#undef STAGE
+    return 0;
+}
+
+int vlsat_forward(vlsat_handle h, vlsat_plan p, const float* pts, const float* f2d, const float* desc,
+                  float* obj3d, float* obj2d, float* rel3d, float* rel2d, void* stream) {
+    return forward_impl(h, p, pts, f2d, desc, obj3d, obj2d, rel3d, rel2d, nullptr, stream);
+}
+
+// Mmgnet.forward(istrain=True) without autograd: the four eval outputs plus obj_feature_3d_mimic [N,512],
+// obj_features_2d_mimic [N,512] and gcn_edge_feature_2d_dis [E,512] (reference SGFN_MMG/model.py:332-333); the eighth
+// element of the reference's tuple, exp(obj_logit_scale), is a constant of VlsatDims.
+int vlsat_forward_train(vlsat_handle h, vlsat_plan p, const float* pts, const float* f2d, const float* desc,
+                        float* obj3d, float* obj2d, float* rel3d, float* rel2d, float* obj_feature_3d_mimic,
+                        float* obj_features_2d_mimic, float* gcn_edge_feature_2d_dis, void* stream) {
+    if (!obj2d || !f2d) return fail(VLSAT_EINVAL, "vlsat_forward_train: the 2D branch is required");
+    if (!obj_feature_3d_mimic || !obj_features_2d_mimic || (p && p->E > 0 && !gcn_edge_feature_2d_dis))
+        return fail(VLSAT_EINVAL, "vlsat_forward_train: null output");
+    const TrainOut tr{obj_feature_3d_mimic, obj_features_2d_mimic, gcn_edge_feature_2d_dis};
+    return forward_impl(h, p, pts, f2d, desc, obj3d, obj2d, rel3d, rel2d, &tr, stream);
+}
+
+int vlsat_profile_enable(vlsat_handle h, int32_t enable) {
+    if (!h) return fail(VLSAT_EINVAL, "null handle");
+    h->prof = enable != 0;
+    return 0;
+}
+int vlsat_profile_num_classes(void) { return PC_COUNT; }
+const char* vlsat_profile_class_name(int32_t c) { return (c >= 0 && c < PC_COUNT) ? kProfNames[c] : ""; }
+
+static int profile_drain(vlsat_handle h) {
+    if (h->recs.empty()) return 0;
+    VLSAT_HIP_CHECK(hipEventSynchronize(h->recs.back().b));
+    for (auto& r : h->recs) {
+        float ms = 0.f;
+        VLSAT_HIP_CHECK(hipEventElapsedTime(&ms, r.a, r.b));
+        h->acc_ms[r.cls] += ms;
+        h->acc_n[r.cls] += r.kernels;
+        h->acc_fl[r.cls] += r.flops;
+    }
+    h->recs.clear();
+    h->ev_used = 0;
+    return 0;
+}
+int vlsat_profile_read(vlsat_handle h, int32_t cls, double* total_ms, int64_t* launches, double* flops) {
+    if (!h || cls < 0 || cls >= PC_COUNT) return fail(VLSAT_EINVAL, "bad profile class");
+    RUN(profile_drain(h));
+    if (total_ms) *total_ms = h->acc_ms[cls];
+    if (launches) *launches = h->acc_n[cls];
+    if (flops) *flops = h->acc_fl[cls];
+    h->acc_ms[cls] = 0; h->acc_n[cls] = 0; h->acc_fl[cls] = 0;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,438 @@
+// Handle life cycle and weight preparation of libvlsat_hip.so: reference-layout tensors in (by state_dict key),
+// device tensors out in the layouts the kernels want -- BatchNorm folds, node-side hoisting of nn_edge.0 /
+// proj_query / gate layer 1, head-major permutations.  No device arithmetic here except the
+// one-time bf16 hi/lo split of the GEMM weights.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+
+#include "engine.h"
+
+namespace vlsat {
+
+static thread_local std::string g_err;
+void set_error(const std::string& m) { g_err = m; }
+int fail(int code, const std::string& m) {
+    g_err = m;
+    return code;
+}
+const char* last_error_cstr() { return g_err.c_str(); }
+
+const char* kProfNames[PC_COUNT] = {"gemm_f32", "flash_attn_f32", "pointnet", "edge_gate", "node_attn",
+                                    "layernorm512", "aggregate", "misc"};
+
+}  // namespace vlsat
+
+using namespace vlsat;
+
+namespace {
+const std::vector<float>* find(vlsat_ctx* h, const std::string& k) {
+    auto it = h->host.find(k);
+    return it == h->host.end() ? nullptr : &it->second;
+}
+
+int upload(vlsat_ctx* h, const std::vector<float>& v, float** out) {
+    float* p = nullptr;
+    VLSAT_HIP_CHECK(hipMalloc(&p, std::max<size_t>(v.size(), 4) * sizeof(float)));
+    VLSAT_HIP_CHECK(hipMemcpy(p, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+    h->dev_allocs.push_back(p);
+    *out = p;
+    return 0;
+}
+
+struct Prep {
+    vlsat_ctx* h;
+    std::string missing;
+    const std::vector<float>& get(const std::string& k, size_t expect) {
+        static const std::vector<float> empty;
+        auto* v = find(h, k);
+        if (!v || v->size() != expect) {
+            if (missing.empty()) missing = k + (v ? " (wrong element count)" : "");
+            return empty;
+        }
+        return *v;
+    }
+};
+
+#define UP(vec, dst)                                 \
+    do {                                             \
+        int _r = upload(h, (vec), &(dst));           \
+        if (_r) return _r;                           \
+    } while (0)
+// a weight MATRIX that goes through gemm(): also registered for the eager bf16 hi/lo split of the bf16 modes
+#define UPW(vec, dst)                                \
+    do {                                             \
+        UP(vec, dst);                                \
+        h->gemm_w.emplace_back((dst), (vec).size()); \
+    } while (0)
+
+int prepare_attn(vlsat_ctx* h, Prep& P, const std::string& pre, AttnW& w, bool fuse_qkv, float qscale) {
+    const size_t D = h->D;
+    auto wq = P.get(pre + ".attention.fc_q.weight", D * D), bq = P.get(pre + ".attention.fc_q.bias", D);
+    auto wk = P.get(pre + ".attention.fc_k.weight", D * D), bk = P.get(pre + ".attention.fc_k.bias", D);
+    auto wv = P.get(pre + ".attention.fc_v.weight", D * D), bv = P.get(pre + ".attention.fc_v.bias", D);
+    auto wo = P.get(pre + ".attention.fc_o.weight", D * D), bo = P.get(pre + ".attention.fc_o.bias", D);
+    auto g = P.get(pre + ".layer_norm.weight", D), b = P.get(pre + ".layer_norm.bias", D);
+    if (!P.missing.empty()) return 0;
+    for (auto& x : wq) x *= qscale;   // 1/sqrt(d_k) = 0.125 is a power of two: exact
+    for (auto& x : bq) x *= qscale;
+    std::vector<float> wkv(wk), bkv(bk);
+    wkv.insert(wkv.end(), wv.begin(), wv.end());
+    bkv.insert(bkv.end(), bv.begin(), bv.end());
+    UPW(wq, w.wq); UP(bq, w.bq); UPW(wkv, w.wkv); UP(bkv, w.bkv); UPW(wo, w.wo); UP(bo, w.bo); UP(g, w.lng); UP(b, w.lnb);
+    w.wqkv = w.bqkv = nullptr;
+    if (fuse_qkv) {
+        std::vector<float> wqkv(wq), bqkv(bq);
+        wqkv.insert(wqkv.end(), wkv.begin(), wkv.end());
+        bqkv.insert(bqkv.end(), bkv.begin(), bkv.end());
+        UPW(wqkv, w.wqkv); UP(bqkv, w.bqkv);
+    }
+    return 0;
+}
+
+int prepare_gcn(vlsat_ctx* h, Prep& P, const std::string& pre, GcnW& w) {
+    const int D = h->D, A = h->A, H = h->H;
+    const int dn = D / H, de = D / H, dox = A / H;   // 64, 64, 32
+    const std::string e = pre + ".edgeatten.";
+    auto w_e0 = P.get(e + "nn_edge.0.weight", (size_t)2 * D * 3 * D), b_e0 = P.get(e + "nn_edge.0.bias", 2 * D);
+    auto w_e2 = P.get(e + "nn_edge.2.weight", (size_t)D * 2 * D), b_e2 = P.get(e + "nn_edge.2.bias", D);
+    // gate MLP input: cat[q, k] (USE_GCN_EDGE, dn+de columns) or q alone (dn columns, hidden width 2*dn); reference
+    // network_MMG.py:72-75
+    const int NIN = h->d.use_gcn_edge ? dn + de : dn;
+    if (!h->d.use_gcn_edge && 2 * dn != dn + de) return fail(VLSAT_EINVAL, "USE_GCN_EDGE=false needs d_n == d_e");
+    auto w_n0 = P.get(e + "nn.0.weight", (size_t)(dn + de) * NIN), b_n0 = P.get(e + "nn.0.bias", dn + de);
+    auto w_n3 = P.get(e + "nn.3.weight", (size_t)dox * (dn + de)), b_n3 = P.get(e + "nn.3.bias", dox);
+    auto w_pe = P.get(e + "proj_edge.0.weight", (size_t)D * D), b_pe = P.get(e + "proj_edge.0.bias", D);
+    auto w_pq = P.get(e + "proj_query.0.weight", (size_t)D * D), b_pq = P.get(e + "proj_query.0.bias", D);
+    auto w_pv = P.get(e + "proj_value.0.weight", (size_t)A * D), b_pv = P.get(e + "proj_value.0.bias", A);
+    auto w_p0 = P.get(pre + ".prop.0.weight", (size_t)(D + A) * (D + A)), b_p0 = P.get(pre + ".prop.0.bias", D + A);
+    auto w_p2 = P.get(pre + ".prop.2.weight", (size_t)D * (D + A)), b_p2 = P.get(pre + ".prop.2.bias", D);
+    if (!P.missing.empty()) return 0;
+    if (dn != 64 || de != 64 || dox != 32) return fail(VLSAT_EINVAL, "gate kernel is built for 8 heads x (64,64,32)");
+
+    // nn_edge.0 [1024, 1536] column blocks: [0:512] = x_i (source), [512:1024] = edge, [1024:1536] = x_j (target)
+    const int NO = 2 * D, NI = 3 * D;
+    const int NODE_COLS = 2 * NO + H * (dn + de) + A;       // 1024 + 1024 + 1024 + 256 = 3328
+    std::vector<float> wnode((size_t)NODE_COLS * D, 0.f), bnode(NODE_COLS, 0.f), we1((size_t)NO * D);
+    for (int o = 0; o < NO; ++o) {
+        const float* r = &w_e0[(size_t)o * NI];
+        std::memcpy(&wnode[(size_t)o * D], r, D * sizeof(float));
+        std::memcpy(&we1[(size_t)o * D], r + D, D * sizeof(float));
+        std::memcpy(&wnode[(size_t)(NO + o) * D], r + 2 * D, D * sizeof(float));
+        bnode[o] = b_e0[o];
+    }
+    // Gq[h*128 + o] = sum_c W0[o, c] * q[c*8 + h] + b0[o],  q = proj_query(x): fold into one [1024,512] matrix
+    const int G0 = 2 * NO, HID = dn + de;   // 128
+    for (int hh = 0; hh < H; ++hh)
+        for (int o = 0; o < HID; ++o) {
+            std::vector<double> row(D, 0.0);
+            double bb = b_n0[o];
+            for (int c = 0; c < dn; ++c) {
+                const double wc = w_n0[(size_t)o * NIN + c];
+                const float* qrow = &w_pq[(size_t)(c * H + hh) * D];
+                for (int k = 0; k < D; ++k) row[k] += wc * qrow[k];
+                bb += wc * b_pq[c * H + hh];
+            }
+            float* dst = &wnode[(size_t)(G0 + hh * HID + o) * D];
+            for (int k = 0; k < D; ++k) dst[k] = (float)row[k];
+            bnode[G0 + hh * HID + o] = (float)bb;
+        }
+    // value rows HEAD-MAJOR: row h*dox + m <- proj_value row m*H + h, so that the gate kernel reads / writes the four
+    // consecutive channels a lane owns as one float4.  The gated and aggregated tensors inherit that channel order
+    // (max / add / mean are per channel) and the columns of prop.0 that read them are permuted to match below.
+    const int V0 = G0 + H * HID;
+    for (int hh = 0; hh < H; ++hh)
+        for (int m = 0; m < dox; ++m) {
+            std::memcpy(&wnode[(size_t)(V0 + hh * dox + m) * D], &w_pv[(size_t)(m * H + hh) * D], D * sizeof(float));
+            bnode[V0 + hh * dox + m] = b_pv[m * H + hh];
+        }
+    {
+        std::vector<float> perm(w_p0.size());
+        const int IN = D + A;
+        for (int o = 0; o < IN; ++o) {
+            std::memcpy(&perm[(size_t)o * IN], &w_p0[(size_t)o * IN], D * sizeof(float));
+            for (int hh = 0; hh < H; ++hh)
+                for (int m = 0; m < dox; ++m) perm[(size_t)o * IN + D + hh * dox + m] = w_p0[(size_t)o * IN + D + m * H + hh];
+        }
+        w_p0.swap(perm);
+    }
+    // proj_edge rows permuted: row h*64 + c <- original row c*8 + h
+    std::vector<float> wpe((size_t)D * D), bpe(D);
+    for (int hh = 0; hh < H; ++hh)
+        for (int c = 0; c < de; ++c) {
+            std::memcpy(&wpe[(size_t)(hh * de + c) * D], &w_pe[(size_t)(c * H + hh) * D], D * sizeof(float));
+            bpe[hh * de + c] = b_pe[c * H + hh];
+        }
+    std::vector<float> w0k((size_t)HID * de, 0.f);           // edge half of layer 1 (unused without USE_GCN_EDGE)
+    if (h->d.use_gcn_edge)
+        for (int o = 0; o < HID; ++o)
+            for (int c = 0; c < de; ++c) w0k[(size_t)o * de + c] = w_n0[(size_t)o * NIN + dn + c];
+    UPW(wnode, w.wnode); UP(bnode, w.bnode); UPW(we1, w.we1); UPW(w_e2, w.we2); UP(b_e2, w.be2);
+    UPW(wpe, w.wpe); UP(bpe, w.bpe); UP(w0k, w.w0k); UP(w_n3, w.w3); UP(b_n3, w.b3);
+    UPW(w_p0, w.wp0); UP(b_p0, w.bp0); UPW(w_p2, w.wp2); UP(b_p2, w.bp2);
+    return 0;
+}
+
+// STNkd weights of encoder `enc` (reference network_PointNet.py:52-86): conv/fc + BatchNorm1d(eval) folded in fp64,
+// "+ eye(64)" folded into fc3's bias
+int prepare_stn(vlsat_ctx* h, Prep& P, const std::string& enc, StnW& w) {
+    const std::string f = enc + ".fstn.";
+    struct L { const char* name; const char* bn; int out, in; };
+    const L layers[6] = {{"conv1", "bn1", 64, 64}, {"conv2", "bn2", 128, 64}, {"conv3", "bn3", 1024, 128},
+                         {"fc1", "bn4", 512, 1024}, {"fc2", "bn5", 256, 512}, {"fc3", nullptr, 4096, 256}};
+    float** dst[6][2] = {{&w.c1, &w.c1b}, {&w.c2, &w.c2b}, {&w.c3, &w.c3b}, {&w.f1, &w.f1b}, {&w.f2, &w.f2b}, {&w.f3, &w.f3b}};
+    for (int i = 0; i < 6; ++i) {
+        const L& l = layers[i];
+        auto wt = P.get(f + l.name + ".weight", (size_t)l.out * l.in), bs = P.get(f + l.name + ".bias", l.out);
+        if (l.bn) {
+            const std::string b = f + l.bn;
+            auto g = P.get(b + ".weight", l.out), be = P.get(b + ".bias", l.out);
+            auto mu = P.get(b + ".running_mean", l.out), var = P.get(b + ".running_var", l.out);
+            if (!P.missing.empty()) return 0;
+            for (int o = 0; o < l.out; ++o) {
+                const double sc = (double)g[o] / std::sqrt((double)var[o] + 1e-5);
+                for (int k = 0; k < l.in; ++k) wt[(size_t)o * l.in + k] = (float)(wt[(size_t)o * l.in + k] * sc);
+                bs[o] = (float)(((double)bs[o] - mu[o]) * sc + be[o]);
+            }
+        } else {
+            if (!P.missing.empty()) return 0;
+            for (int d = 0; d < 64; ++d) bs[d * 64 + d] += 1.f;
+        }
+        UPW(wt, *dst[i][0]);
+        UP(bs, *dst[i][1]);
+    }
+    return 0;
+}
+
+}  // namespace
+
+namespace vlsat {
+// bf16 hi/lo planes of every registered GEMM weight (idempotent); runs on the null stream and completes before returning
+int split_all_weights(vlsat_ctx* h) {
+    bool any = false;
+    for (auto& gw : h->gemm_w) {
+        if (h->split.count(gw.first)) continue;
+        uint16_t *hi = nullptr, *lo = nullptr;
+        VLSAT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&hi), gw.second * 2 + 256));
+        VLSAT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&lo), gw.second * 2 + 256));
+        RUN(launch_split_bf16(gw.first, gw.second, hi, lo, nullptr));
+        h->split.emplace(gw.first, std::make_pair(hi, lo));
+        any = true;
+    }
+    if (any) VLSAT_HIP_CHECK(hipDeviceSynchronize());
+    return 0;
+}
+}  // namespace vlsat
+
+// ============================================================================================
+extern "C" {
+
+const char* vlsat_version(void) { return "vlsat-hip gfx950 r2 (fp32-mfma | bf16x3 | bf16)"; }
+
+int vlsat_create(const VlsatDims* d, vlsat_handle* out) {
+    if (!d || !out) return fail(VLSAT_EINVAL, "vlsat_create: null argument");
+    if (d->n_layers < 1 || d->n_layers > 16) return fail(VLSAT_EINVAL, "n_layers must be in [1,16]");
+    if (d->n_heads != 8 || d->dim_atten != 256) return fail(VLSAT_EINVAL, "only NUM_HEADS=8, DIM_ATTEN=256 are built");
+    if (d->gcn_aggr < 0 || d->gcn_aggr > 2) return fail(VLSAT_EINVAL, "gcn_aggr must be 0 (max), 1 (add) or 2 (mean)");
+    if (d->dim_point != 3 && d->dim_point != 6 && d->dim_point != 9)
+        return fail(VLSAT_EINVAL, "dim_point must be 3, 6 or 9 (xyz [+ USE_RGB] [+ USE_NORMAL])");
+    if (d->feature_transform != 0 && d->feature_transform != 1) return fail(VLSAT_EINVAL, "feature_transform must be 0 or 1");
+    if (d->n_obj_class < 1 || d->n_rel_class < 1) return fail(VLSAT_EINVAL, "class counts must be positive");
+    auto* h = new (std::nothrow) vlsat_ctx();
+    if (!h) return fail(VLSAT_ENOMEM, "out of host memory");
+    h->d = *d;
+    *out = h;
+    return 0;
+}
+
+// device copies of the current weight generation (the handle must be idle: callers synchronise first)
+static void free_device_weights(vlsat_ctx* h) {
+    for (float* p : h->dev_allocs) hipFree(p);
+    h->dev_allocs.clear();
+    h->gemm_w.clear();
+    for (auto& kv : h->split) { hipFree(kv.second.first); hipFree(kv.second.second); }
+    h->split.clear();
+    h->trip = TripletW{};
+}
+
+void vlsat_destroy(vlsat_handle h) {
+    if (!h) return;
+    hipDeviceSynchronize();                    // end of life: nothing of this handle may still be in flight
+    free_device_weights(h);
+    release_plan_resources(h);
+    for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
+    for (hipEvent_t e : h->sync_ev) hipEventDestroy(e);
+    if (h->side) hipStreamDestroy(h->side);
+    if (h->copy) hipStreamDestroy(h->copy);
+    delete h;
+}
+
+// Weights can be (re)loaded at any time, like the reference's BaseModel.load (model_base.py:75-129): the first
+// vlsat_load_weight after a vlsat_finalize_weights opens a new generation -- it waits for the device to go idle,
+// drops the previous device tensors and expects the complete set again before the next finalize.  Plans stay valid.
+int vlsat_load_weight(vlsat_handle h, const char* name, const float* host, size_t count) {
+    if (!h || !name || !host) return fail(VLSAT_EINVAL, "vlsat_load_weight: null argument");
+    if (h->finalized) {
+        VLSAT_HIP_CHECK(hipDeviceSynchronize());
+        free_device_weights(h);
+        h->host.clear();
+        h->finalized = false;
+    }
+    std::string k(name);
+    static const char* prefixes[] = {"obj_encoder.", "rel_encoder_2d.", "rel_encoder_3d.", "mlp_3d.", "clip_adapter.fc",
+                                     "mmg.", "rel_predictor_3d.", "rel_predictor_2d.", "obj_predictor_3d.",
+                                     "obj_predictor_2d.", "triplet_projector_2d."};
+    bool ok = false;
+    for (auto p : prefixes) ok |= k.rfind(p, 0) == 0;
+    if (!ok) return fail(VLSAT_EINVAL, "unknown weight name: " + k);
+    h->host[k].assign(host, host + count);
+    return 0;
+}
+
+int vlsat_finalize_weights(vlsat_handle h) {
+    if (!h) return fail(VLSAT_EINVAL, "null handle");
+    if (h->finalized) return 0;
+    Prep P{h, ""};
+    const int D = h->D, C = h->C_pt, L = h->d.n_layers;
+    // object encoder
+    auto w1 = P.get("obj_encoder.conv1.weight", 64 * (size_t)h->d.dim_point), b1 = P.get("obj_encoder.conv1.bias", 64);
+    auto w2 = P.get("obj_encoder.conv2.weight", 128 * 64), b2 = P.get("obj_encoder.conv2.bias", 128);
+    auto w3 = P.get("obj_encoder.conv3.weight", (size_t)C * 128), b3 = P.get("obj_encoder.conv3.bias", C);
+    // mlp_3d with BatchNorm1d(eval) folded (reference SGFN_MMG/model.py:106-111)
+    const int M3 = D - 8;
+    auto mw = P.get("mlp_3d.0.weight", (size_t)M3 * C), mb = P.get("mlp_3d.0.bias", M3);
+    auto bg = P.get("mlp_3d.1.weight", M3), bb = P.get("mlp_3d.1.bias", M3);
+    auto bm = P.get("mlp_3d.1.running_mean", M3), bv = P.get("mlp_3d.1.running_var", M3);
+    if (P.missing.empty()) {
+        for (int o = 0; o < M3; ++o) {
+            const double sc = (double)bg[o] / std::sqrt((double)bv[o] + 1e-5);
+            for (int k = 0; k < C; ++k) mw[(size_t)o * C + k] = (float)(mw[(size_t)o * C + k] * sc);
+            mb[o] = (float)(((double)mb[o] - bm[o]) * sc + bb[o]);
+        }
+    }
+    // relation encoders
+    std::vector<float> w1cat, b1cat;
+    std::vector<float> r3w2, r3b2, r3w3, r3b3, r2w2, r2b2, r2w3, r2b3;
+    for (const char* br : {"rel_encoder_3d", "rel_encoder_2d"}) {
+        std::string b(br);
+        auto c1 = P.get(b + ".conv1.weight", 64 * 11), c1b = P.get(b + ".conv1.bias", 64);
+        w1cat.insert(w1cat.end(), c1.begin(), c1.end());
+        b1cat.insert(b1cat.end(), c1b.begin(), c1b.end());
+        auto c2 = P.get(b + ".conv2.weight", 128 * 64), c2b = P.get(b + ".conv2.bias", 128);
+        auto c3 = P.get(b + ".conv3.weight", (size_t)D * 128), c3b = P.get(b + ".conv3.bias", D);
+        if (b == "rel_encoder_3d") { r3w2 = c2; r3b2 = c2b; r3w3 = c3; r3b3 = c3b; }
+        else { r2w2 = c2; r2b2 = c2b; r2w3 = c3; r2b3 = c3b; }
+    }
+    if (h->d.feature_transform) {
+        RUN(prepare_stn(h, P, "obj_encoder", h->stn_obj));
+        RUN(prepare_stn(h, P, "rel_encoder_3d", h->stn_re3));
+        RUN(prepare_stn(h, P, "rel_encoder_2d", h->stn_re2));
+    }
+    // adapter: 0.5*(W2 h + b2) + 0.5*x  -> halve W2,b2 (exact), residual scale 0.5
+    auto aw1 = P.get("clip_adapter.fc1.weight", 256 * (size_t)D), ab1 = P.get("clip_adapter.fc1.bias", 256);
+    auto aw2 = P.get("clip_adapter.fc2.weight", (size_t)D * 256), ab2 = P.get("clip_adapter.fc2.bias", D);
+    for (auto& x : aw2) x *= 0.5f;
+    for (auto& x : ab2) x *= 0.5f;
+    // distance bias MLP
+    const std::string f = "mmg.self_attn_fc.";
+    auto d0w = P.get(f + "0.weight", 32 * 4), d0b = P.get(f + "0.bias", 32);
+    auto d2w = P.get(f + "2.weight", 32), d2b = P.get(f + "2.bias", 32);
+    auto d3w = P.get(f + "3.weight", 32 * 32), d3b = P.get(f + "3.bias", 32);
+    auto d5w = P.get(f + "5.weight", 32), d5b = P.get(f + "5.bias", 32);
+    auto d6w = P.get(f + "6.weight", (size_t)h->H * 32), d6b = P.get(f + "6.bias", h->H);
+    if (!P.missing.empty()) return fail(VLSAT_ESTATE, "missing weight: " + P.missing);
+
+    UP(w1, h->pn_w1); UP(b1, h->pn_b1); UP(w2, h->pn_w2); UP(b2, h->pn_b2); UP(w3, h->pn_w3); UP(b3, h->pn_b3);
+    UPW(mw, h->mlp_w); UP(mb, h->mlp_b);
+    UP(w1cat, h->re_w1cat); UP(b1cat, h->re_b1cat);
+    UPW(r3w2, h->re3_w2); UP(r3b2, h->re3_b2); UPW(r3w3, h->re3_w3); UP(r3b3, h->re3_b3);
+    UPW(r2w2, h->re2_w2); UP(r2b2, h->re2_b2); UPW(r2w3, h->re2_w3); UP(r2b3, h->re2_b3);
+    UPW(aw1, h->ad_w1); UP(ab1, h->ad_b1); UPW(aw2, h->ad_w2h); UP(ab2, h->ad_b2h);
+    float* t;
+    UP(d0w, t); h->db.w0 = t; UP(d0b, t); h->db.b0 = t; UP(d2w, t); h->db.g2 = t; UP(d2b, t); h->db.be2 = t;
+    UP(d3w, t); h->db.w3 = t; UP(d3b, t); h->db.b3 = t; UP(d5w, t); h->db.g5 = t; UP(d5b, t); h->db.be5 = t;
+    UP(d6w, t); h->db.w6 = t; UP(d6b, t); h->db.b6 = t;
+
+    h->self_attn.resize(L); h->cross_attn.resize(L); h->cross_rel.resize(L); h->gcn3.resize(L); h->gcn2.resize(L);
+    for (int l = 0; l < L; ++l) {
+        const std::string ls = std::to_string(l);
+        RUN(prepare_attn(h, P, "mmg.self_attn." + ls, h->self_attn[l], true, 0.125f));
+        RUN(prepare_attn(h, P, "mmg.cross_attn." + ls, h->cross_attn[l], false, 0.125f));
+        RUN(prepare_attn(h, P, "mmg.cross_attn_rel." + ls, h->cross_rel[l], false, 1.0f));
+        RUN(prepare_gcn(h, P, "mmg.gcn_3ds." + ls, h->gcn3[l]));
+        RUN(prepare_gcn(h, P, "mmg.gcn_2ds." + ls, h->gcn2[l]));
+        if (!P.missing.empty()) return fail(VLSAT_ESTATE, "missing weight: " + P.missing);
+    }
+    const int R = h->d.n_rel_class, K = h->d.n_obj_class;
+    for (int i = 0; i < 2; ++i) {
+        const std::string b = i == 0 ? "rel_predictor_3d" : "rel_predictor_2d";
+        RelHeadW& r = i == 0 ? h->rel3 : h->rel2;
+        auto f1 = P.get(b + ".fc1.weight", 512 * (size_t)D), f1b = P.get(b + ".fc1.bias", 512);
+        auto f2 = P.get(b + ".fc2.weight", 256 * 512), f2b = P.get(b + ".fc2.bias", 256);
+        auto f3 = P.get(b + ".fc3.weight", (size_t)R * 256), f3b = P.get(b + ".fc3.bias", R);
+        if (!P.missing.empty()) return fail(VLSAT_ESTATE, "missing weight: " + P.missing);
+        // MODEL.WITH_BN: BatchNorm1d(eval) after fc1 / fc2 (reference network_PointNet.py:320-337), recognised by
+        // its keys in the checkpoint and folded into the layer in front of it
+        auto fold = [&](const std::string& bn, std::vector<float>& wt, std::vector<float>& bs, int outs, int ins) -> int {
+            if (!h->host.count(bn + ".weight")) return 0;
+            auto g = P.get(bn + ".weight", outs), be = P.get(bn + ".bias", outs);
+            auto mu = P.get(bn + ".running_mean", outs), var = P.get(bn + ".running_var", outs);
+            if (!P.missing.empty()) return fail(VLSAT_ESTATE, "missing weight: " + P.missing);
+            for (int o = 0; o < outs; ++o) {
+                const double sc = (double)g[o] / std::sqrt((double)var[o] + 1e-5);
+                for (int k = 0; k < ins; ++k) wt[(size_t)o * ins + k] = (float)(wt[(size_t)o * ins + k] * sc);
+                bs[o] = (float)(((double)bs[o] - mu[o]) * sc + be[o]);
+            }
+            return 0;
+        };
+        RUN(fold(b + ".bn1", f1, f1b, 512, D));
+        RUN(fold(b + ".bn2", f2, f2b, 256, 512));
+        UPW(f1, r.w1); UP(f1b, r.b1); UPW(f2, r.w2); UP(f2b, r.b2); UPW(f3, r.w3); UP(f3b, r.b3);
+    }
+    const float es = std::exp(h->d.obj_logit_scale);
+    for (int i = 0; i < 2; ++i) {
+        const std::string b = i == 0 ? "obj_predictor_3d" : "obj_predictor_2d";
+        auto w = P.get(b + ".weight", (size_t)K * D), bi = P.get(b + ".bias", K);
+        if (!P.missing.empty()) return fail(VLSAT_ESTATE, "missing weight: " + P.missing);
+        for (auto& x : bi) x *= es;     // exp(s) * (W x/|x| + b)
+        if (i == 0) { UPW(w, h->obj3_w); UP(bi, h->obj3_b); } else { UPW(w, h->obj2_w); UP(bi, h->obj2_b); }
+    }
+    // triplet_projector_2d (optional; only forward(istrain=True) reads it): Linear(3D, 2D) on cat[x_i, x_j, e]
+    // (reference SGFN_MMG/model.py:95-100,259-264) hoisted like nn_edge.0 -- the node columns move to an N-row GEMM
+    if (h->host.count("triplet_projector_2d.0.weight")) {
+        const int NO = 2 * D, NI = 3 * D;
+        auto t0 = P.get("triplet_projector_2d.0.weight", (size_t)NO * NI), t0b = P.get("triplet_projector_2d.0.bias", NO);
+        auto t3 = P.get("triplet_projector_2d.3.weight", (size_t)D * NO), t3b = P.get("triplet_projector_2d.3.bias", D);
+        if (!P.missing.empty()) return fail(VLSAT_ESTATE, "missing weight: " + P.missing);
+        std::vector<float> wnode((size_t)2 * NO * D), bnode(2 * NO, 0.f), we((size_t)NO * D);
+        for (int o = 0; o < NO; ++o) {
+            const float* r = &t0[(size_t)o * NI];
+            std::memcpy(&wnode[(size_t)o * D], r, D * sizeof(float));                 // x_i = x[ei[0]]
+            std::memcpy(&wnode[(size_t)(NO + o) * D], r + D, D * sizeof(float));      // x_j = x[ei[1]]
+            std::memcpy(&we[(size_t)o * D], r + 2 * D, D * sizeof(float));            // edge feature
+            bnode[o] = t0b[o];
+        }
+        UPW(wnode, h->trip.wnode); UP(bnode, h->trip.bnode); UPW(we, h->trip.we); UPW(t3, h->trip.w2); UP(t3b, h->trip.b2);
+    }
+    h->host.clear();
+    h->finalized = true;
+    if (h->prec) RUN(split_all_weights(h));
+    return 0;
+}
+
+// GEMM operand precision (BASELINE configs[2]).  0: exact fp32 MFMA.  3: split-bf16, three bf16 MFMAs per product
+// (~1e-5 error).  1: single-rounded bf16 operands everywhere.  2: mixed -- bf16 on the edge-row GEMMs, attention and
+// gate (98 % of the flops), split-bf16 on the node-row GEMMs that feed the x14.29 object logits.
+// The bf16 hi/lo copies of all weight matrices are made here, eagerly, not inside a forward.
+int vlsat_set_gemm_precision(vlsat_handle h, int32_t mode) {
+    if (!h) return fail(VLSAT_EINVAL, "null handle");
+    if (mode < 0 || mode > 3) return fail(VLSAT_EINVAL, "gemm precision must be 0 (fp32), 1 (bf16), 2 (mixed) or 3 (bf16x3)");
+    h->prec = mode;
+    h->prec_edge = mode == 2 ? 1 : mode;
+    h->prec_node = mode == 2 ? 3 : mode;
+    if (mode && h->finalized) RUN(split_all_weights(h));
+    return 0;
+}
+
+}  // extern "C"

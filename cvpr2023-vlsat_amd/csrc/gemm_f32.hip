@@ -31,6 +31,7 @@
 //
 // Roofline: fp32 MFMA (157.3 TF).  Per 128x128x32 slice a block moves 32 KB from L2 for
 // 1.05 MFLOP (~19 GB/s/CU at peak rate): MFMA-issue bound, LDS is 4 ds_read_b128 per 16 MFMAs.
+#include <algorithm>
 #include <cstdlib>
 #include "gemm_core.h"
 #include "kernels.h"
@@ -214,23 +215,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int n_tile
 
 double gemm_flops(const GemmArgs& a) { return 2.0 * a.M * (double)a.N * a.K; }
 
-static long g_kernel_launches = 0;          // a logical GEMM is a main launch plus (usually) a small-tile tail launch
-long gemm_kernel_launches() { return g_kernel_launches; }
-
-static int g_dma = -1;       // LDS-direct staging of fp32 operands (PipeF32Dma); VLSAT_GEMM_DMA=0 selects the VGPR-staged pipe
-static int g_slots = 0;      // resident 256-thread blocks the persistent grid may use (2 per CU)
+// resident 256-thread blocks the persistent grid may use (2 per CU): a constant of the device, cached per device id
 static int slots() {
-    if (!g_slots) {
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) {
-            hipDeviceProp_t pr;
-            if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount;
-        }
-        g_slots = ((2 * cus) / 8) * 8;
-        if (const char* e = getenv("VLSAT_GEMM_SLOTS")) g_slots = (atoi(e) / 8) * 8;   // tuning knob
-        if (g_slots < 8) g_slots = 8;
+    static int cache[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!cache[dev]) {
+        int cus = 256;
+        hipDeviceProp_t pr;
+        if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount;
+        cache[dev] = std::max(8, ((2 * cus) / 8) * 8);
     }
-    return g_slots;
+    return cache[dev];
 }
 
 template <int BM, int BN, int KSL = 1>
@@ -242,11 +238,7 @@ static int launch_t(const GemmArgs& a, int n_tiles, int grid, hipStream_t s) {
     // exact fp32 launches without ReLU-on-A take the LDS-direct staging pipe (internal precision code 4) when
     // the operands are addressable with 32-bit byte offsets and the additive mode is one the forward uses
     int prec = a.prec;
-    if (g_dma < 0) {
-        const char* e = getenv("VLSAT_GEMM_DMA");
-        g_dma = e ? atoi(e) : 1;
-    }
-    if (prec == 0 && g_dma &&!a.relu_a && (add == 0 || add == 1 || add == 6) &&
+    if (prec == 0 && !a.no_dma && !a.relu_a && (add == 0 || add == 1 || add == 6) &&
         ((size_t)a.M + 256) * a.lda * 4 < (1ull << 32) && ((size_t)a.N + 256) * a.ldw * 4 < (1ull << 32))
         prec = 4;
     switch (prec * 8 + add) {
@@ -258,7 +250,7 @@ static int launch_t(const GemmArgs& a, int n_tiles, int grid, hipStream_t s) {
         default: return fail(-1, "gemm: this precision / additive-operand combination is not built");
     }
 #undef VLSAT_GEMM_CASE
-    ++g_kernel_launches;
+    if (a.launches) ++*a.launches;         // a logical GEMM is a main launch plus (usually) a small-tile tail launch
     VLSAT_LAUNCH_CHECK("gemm_f32");
     return 0;
 }
@@ -297,9 +289,7 @@ static int run_tiled(const GemmArgs& a, hipStream_t s) {
     return launch_gemm(tail_of(a, (int)(main_panels * BM)), s);   // strictly fewer rows: terminates
 }
 
-static long long* g_clock_probe = nullptr;
-static int g_variant = -1;                       // -1: not set yet (VLSAT_GEMM_BIG decides on first use)
-void gemm_set_variant(int v) { g_variant = v; }
+static long long* g_clock_probe = nullptr;       // debug only (vlsat_debug_gemm_clock_probe): process-wide on purpose
 void gemm_set_clock_probe(long long* buf) { g_clock_probe = buf; }
 
 int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
@@ -317,30 +307,6 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
         return fail(-1, "gemm: A/W must be 16-byte aligned");
     const int G = slots();
     auto blocks = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
-    // Opt-in (vlsat_debug_gemm_variant / VLSAT_GEMM_BIG): full rounds of 256x128 tiles of large-M fp32
-    // launches on the one-wave-per-SIMD kernel (gemm_f32_big.hip); whatever does not fill a round falls
-    // through to the 4-wave tiles below.
-    if (g_variant < 0) {
-        const char* e = getenv("VLSAT_GEMM_BIG");
-        g_variant = e ? atoi(e) : 0;
-    }
-    if (g_variant > 0 && a.prec == 0 && a.N >= 128 && !a.rowscale) {
-        const int G1 = G / 2;                                  // one block per CU
-        const long nbm = (a.M + 255) / 256, nbn = (a.N + 127) / 128;
-        const long rounds = nbm * nbn / G1;
-        const long main_panels = rounds * G1 / nbn;
-        const int add = (a.resid ? 1 : 0) | (a.g0 ? 2 : 0) | (a.g1 ? 4 : 0);
-        if (main_panels > 0 && main_panels * 256 <= a.M && (add == 0 || g_variant == 2)) {
-            GemmArgs m = a;
-            m.M = (int)(main_panels * 256);
-            if (launch_gemm_big(m, (int)(main_panels * nbn), G1, s) == 0) {
-                ++g_kernel_launches;
-                if (m.M == a.M) return 0;
-                return launch_gemm(tail_of(a, m.M), s);
-            }
-            if (hipGetLastError() != hipSuccess) return fail(-2, "launch gemm_f32_big failed");
-        }
-    }
     // Largest tile that still gives every resident slot a tile; small problems (and the tails
     // of big ones) take smaller tiles so the launch covers as many CUs as the problem allows.
     if (a.N > 64 && blocks(128, 128) >= G) return run_tiled<128, 128>(a, s);

@@ -26,15 +26,12 @@ struct GemmArgs {
     const uint16_t* Whi = nullptr;
     const uint16_t* Wlo = nullptr;
     long long* clock_probe = nullptr;           // optional [grid][4] DVFS probe buffer (vlsat_debug_gemm_clock_probe)
+    int no_dma = 0;                             // debug: VGPR-staged fp32 operands instead of LDS-direct (vlsat_debug_option "gemm_dma")
+    long* launches = nullptr;                   // optional host counter, +1 per kernel launched (profiling)
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
 double gemm_flops(const GemmArgs& a);
 void gemm_set_clock_probe(long long* buf);
-// one-wave-per-SIMD 256x128 variant with a 4-stage LDS ring for the full rounds of large-M fp32 launches
-// (gemm_f32_big.hip, opt-in); returns 1 if the operand combination is not built
-int launch_gemm_big(const GemmArgs& a, int n_tiles, int grid, hipStream_t s);
-void gemm_set_variant(int v);
-long gemm_kernel_launches();   // kernels launched so far by launch_gemm (main + tail launches)
 
 // ---- PointNet object encoder (fused conv1..conv3 + ReLU + max over points) ----
 int launch_pointnet(const float* pts, int n_obj, int n_points, int cin, const float* w1, const float* b1,
@@ -104,6 +101,7 @@ struct GateArgs {
     float* prob;             // optional [E, 32, 8] tap (tests) or nullptr
     int n_edges;
     int use_edge = 1;        // MODEL.USE_GCN_EDGE: 0 -> the gate MLP sees the query alone (kproj / w0k unused)
+    int grid_cap = 0;        // debug: persistent grid size (0 = 3 blocks per CU; vlsat_debug_option "gate_grid")
 };
 int launch_edge_gate(const GateArgs& a, hipStream_t s);
 

@@ -43,6 +43,7 @@ _SIGNATURES = {
     "vlsat_plan_destroy": (None, [_vp]),
     "vlsat_plan_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_sz), C.POINTER(_i32)]),
     "vlsat_forward": (C.c_int, [_vp] * 9 + [_vp]),
+    "vlsat_forward_train": (C.c_int, [_vp] * 12 + [_vp]),
     "vlsat_set_gemm_precision": (C.c_int, [_vp, _i32]),
     "vlsat_set_edge_attention_scope": (C.c_int, [_vp, _i32]),
     "vlsat_profile_enable": (C.c_int, [_vp, _i32]),
@@ -59,7 +60,7 @@ _SIGNATURES = {
     "vlsat_k_softmax_rows": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "vlsat_eval_ranks": (C.c_int, [_vp] * 6 + [_i32] * 7 + [_f32] + [_vp] * 4 + [_vp]),
     "vlsat_debug_gemm_clock_probe": (C.c_int, [_vp]),
-    "vlsat_debug_gemm_variant": (C.c_int, [C.c_int32]),
+    "vlsat_debug_option": (C.c_int, [_vp, C.c_char_p, _i32]),
     "vlsat_debug_stop_after": (C.c_int, [_vp, _i32]),
     "vlsat_debug_read": (C.c_int, [_vp, C.c_char_p, _vp, _i64]),
     "vlsat_debug_buffer": (C.c_int, [_vp, C.c_char_p, C.POINTER(_vp), C.POINTER(_i64), C.POINTER(_i32),

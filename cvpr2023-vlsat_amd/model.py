@@ -9,9 +9,11 @@ file only validates shapes, caches the per-graph plan and passes raw pointers.
 from __future__ import annotations
 
 import ctypes as C
+import hashlib
+import math
 import weakref
 from collections import OrderedDict
-from typing import Dict, Optional
+from typing import Dict, Optional, Sequence
 
 import numpy as np
 import torch
@@ -23,9 +25,10 @@ _AGGR = {"max": 0, "add": 1, "mean": 2}
 
 
 class _Plan:
-    def __init__(self, handle, perm):
+    def __init__(self, handle, perm, ws_bytes=0):
         self.handle = handle          # vlsat_plan (c_void_p)
         self.perm = perm              # device int64 permutation applied to the edges, or None
+        self.ws_bytes = ws_bytes
 
     def destroy(self):
         if self.handle:
@@ -36,7 +39,8 @@ class _Plan:
 class VLSATModel:
     """Drop-in for ``Mmgnet`` on the eval forward path (one instance is not re-entrant)."""
 
-    MAX_PLANS = 4
+    MAX_PLANS = 64                      # cached graph plans (LRU) ...
+    MAX_PLAN_BYTES = 16 << 30           # ... and the device workspace they may hold together
 
     def __init__(self, config: Optional[VLSATConfig] = None, device: str = "cuda:0"):
         self.config = config or VLSATConfig()
@@ -56,18 +60,21 @@ class VLSATModel:
         self._loaded = False
         self._zero_bid = {}
         self._plans: "OrderedDict[tuple, _Plan]" = OrderedDict()
+        self._ident: "OrderedDict[tuple, tuple]" = OrderedDict()     # (id(edge tensor), id(batch tensor)) -> plan key
+        self.plan_stats = {"hits": 0, "identity_hits": 0, "builds": 0, "d2h_copies": 0}
         self.training = False
         self.gemm_precision = "fp32"
         self.batch_mode = "per_scene"
         # attributes MMGNet.validation reads on the model object (reference src/model/model.py:255,361)
         self.iteration, self.eva_res, self.epoch = 0, 0, -1
 
-    PRECISIONS = {"fp32": 0, "bf16": 1, "bf16x3": 3}
+    PRECISIONS = {"fp32": 0, "bf16": 1, "bf16_mixed": 2, "bf16x3": 3}
 
     def set_gemm_precision(self, mode: str):
-        """'fp32' (default, exact-fp32 MFMA: BASELINE configs[1]) | 'bf16x3' (split-bf16 MFMA GEMMs, fp32
-        accumulate, ~1e-5 error: BASELINE configs[2]) | 'bf16' (single bf16 rounding; ~2e-2 on the object
-        logits, outside the 1e-2 tolerance -- kept for comparison).  Attention/softmax/LN stay fp32."""
+        """'fp32' (default, exact-fp32 MFMA: BASELINE configs[1]) | 'bf16x3' (split-bf16 MFMA, three bf16 MFMAs per
+        product, fp32 accumulate, ~1e-5 error) | 'bf16_mixed' (single-rounded bf16 on the edge-row matrix work,
+        split-bf16 on the node rows: meets BASELINE configs[2]'s 1e-2) | 'bf16' (single rounding everywhere; ~2e-2
+        on the object logits, outside that tolerance -- kept for comparison).  Softmax/LN and HBM tensors stay fp32."""
         if mode not in self.PRECISIONS:
             raise L.VlsatError(f"gemm precision must be one of {sorted(self.PRECISIONS)}")
         L.check(self._lib.vlsat_set_gemm_precision(self._h, self.PRECISIONS[mode]))
@@ -84,11 +91,22 @@ class VLSATModel:
         if mode not in self.BATCH_MODES:
             raise L.VlsatError(f"batch mode must be one of {sorted(self.BATCH_MODES)}")
         L.check(self._lib.vlsat_set_edge_attention_scope(self._h, self.BATCH_MODES[mode]))
-        for p in self._plans.values():          # plans bake the attention tile table in
-            p.destroy()
-        self._plans.clear()
+        self._drop_plans()                      # plans bake the attention tile table in
         self.batch_mode = mode
         return self
+
+    def debug_option(self, name: str, value: int):
+        """Experiment switches of the library (vlsat_debug_option: 'dual_stream', 'flash_split', 'gemm_dma', 'gate_grid')."""
+        L.check(self._lib.vlsat_debug_option(self._h, name.encode(), int(value)))
+        if name in ("dual_stream", "flash_split"):
+            self._drop_plans()
+        return self
+
+    def _drop_plans(self):
+        for p in self._plans.values():
+            p.destroy()
+        self._plans.clear()
+        self._ident.clear()
 
     # ---- nn.Module-like surface --------------------------------------------------------------
     def eval(self):
@@ -104,9 +122,7 @@ class VLSATModel:
         return self.forward(*a, **k)
 
     def close(self):
-        for p in self._plans.values():
-            p.destroy()
-        self._plans.clear()
+        self._drop_plans()
         if getattr(self, "_h", None):
             self._lib.vlsat_destroy(self._h)
             self._h = None
@@ -120,7 +136,8 @@ class VLSATModel:
     # ---- weights -------------------------------------------------------------------------------
     def load_state(self, weights: Dict[str, "np.ndarray | torch.Tensor"], strict: bool = True):
         """``weights``: reference ``state_dict`` keys (``'mmg.gcn_3ds.0.edgeatten.nn_edge.0.weight'``)
-        -> fp32 arrays.  Dead/unused entries of a reference checkpoint are ignored."""
+        -> fp32 arrays.  Dead/unused entries of a reference checkpoint are ignored.  May be called again on a
+        loaded model (like BaseModel.load): the previous device weights are dropped, plans stay valid."""
         want = param_shapes(self.config)
         missing = [k for k in want if k not in weights]
         if missing and strict:
@@ -158,21 +175,86 @@ class VLSATModel:
                                    batch_ids, use_triplet=use_triplet)
 
     # ---- graph plan ----------------------------------------------------------------------------
-    def _plan(self, edge_indices, batch_ids, n, p) -> _Plan:
-        """Plan for this graph.  A cached plan is reused only for the SAME tensor objects at the
-        same in-place version (an address match alone is not enough: the caching allocator hands
-        the same address to the next scene's tensors)."""
-        key = (id(edge_indices), id(batch_ids), n, p)
-        hit = self._plans.get(key)
-        if hit is not None:
-            ok = (hit.refs[0]() is edge_indices and hit.refs[1]() is batch_ids
-                  and hit.versions == (edge_indices._version, batch_ids._version))
-            if ok:
-                self._plans.move_to_end(key)
-                return hit
-            self._plans.pop(key).destroy()
-        ei = edge_indices.detach().cpu().contiguous()           # one D2H sync per NEW graph
-        bid = batch_ids.detach().view(-1).cpu().contiguous()
+    @staticmethod
+    def _fc_host(sizes: Sequence[int]):
+        """Host copy of the canonical fully-connected graph: source-major ordered pairs without self loops per scene,
+        node offsets applied (reference dataset_3dssg.py:264-266 + collate_fn_mmg DataLoader.py:160-172)."""
+        ei, bid, off = [], [], 0
+        for s, n in enumerate(sizes):
+            a = np.repeat(np.arange(n, dtype=np.int64), n)
+            b = np.tile(np.arange(n, dtype=np.int64), n)
+            keep = a != b
+            ei.append(np.stack([a[keep], b[keep]], 0) + off)
+            bid.append(np.full(n, s, dtype=np.int64))
+            off += n
+        return torch.from_numpy(np.ascontiguousarray(np.concatenate(ei, 1))), torch.from_numpy(np.concatenate(bid))
+
+    def _plan(self, edge_indices, batch_ids, n, p, fc_sizes: Optional[Sequence[int]] = None) -> _Plan:
+        """Plan for this graph, from a content-keyed LRU cache.  In order of cost:
+          1. ``fc_sizes`` given: the caller states that edge_indices IS the canonical fully-connected edge list of
+             scenes with these object counts -> key (sizes, P); nothing is read from the device;
+          2. the same tensor OBJECTS as an earlier call, unmodified -> no copy either;
+          3. edge_indices / batch_ids on the host (the reference's loader yields them there) -> hashed on the host;
+          4. device tensors never seen before -> one D2H copy (a stream sync) to hash them.
+        In every case a graph with the same content re-uses its plan: no rebuild, no upload."""
+        if batch_ids is None:
+            batch_ids = self._zero_bid.get(n)
+            if batch_ids is None:
+                batch_ids = self._zero_bid[n] = torch.zeros(n, 1, dtype=torch.int64, device=self.device)
+        if (not torch.is_tensor(batch_ids) or batch_ids.numel() != n or batch_ids.dtype != torch.int64
+                or not torch.is_tensor(edge_indices) or edge_indices.dtype != torch.int64 or edge_indices.dim() != 2
+                or edge_indices.shape[0] != 2):
+            raise L.VlsatError(f"edge_indices must be int64[2,E] and batch_ids int64[{n},1] (or [{n}])")
+        key, ei, bid = None, None, None
+        if fc_sizes is not None:
+            sizes = tuple(int(x) for x in fc_sizes)
+            if sum(sizes) != n or edge_indices.shape[1] != sum(k * (k - 1) for k in sizes):
+                raise L.VlsatError("fc_sizes does not match the node / edge counts")
+            key = ("fc", sizes, p, self.batch_mode)
+        else:
+            ik = (id(edge_indices), id(batch_ids))
+            hit = self._ident.get(ik)
+            if hit is not None:
+                refs, versions, k = hit
+                if (refs[0]() is edge_indices and refs[1]() is batch_ids and k in self._plans
+                        and versions == (edge_indices._version, batch_ids._version)):
+                    self._plans.move_to_end(k)
+                    self.plan_stats["identity_hits"] += 1
+                    return self._plans[k]
+                del self._ident[ik]
+            if edge_indices.is_cuda or batch_ids.is_cuda:
+                self.plan_stats["d2h_copies"] += 1
+            ei = edge_indices.detach().cpu().contiguous()
+            bid = batch_ids.detach().view(-1).cpu().contiguous()
+            # scene ids only matter through the partition they induce: hash the run lengths, not the values
+            cuts = torch.nonzero(bid[1:] != bid[:-1]).view(-1).numpy() if n > 1 else np.zeros(0, np.int64)
+            hsh = hashlib.blake2b(digest_size=16)
+            hsh.update(np.ascontiguousarray(cuts).tobytes())
+            hsh.update(ei.numpy().tobytes())
+            key = ("g", n, ei.shape[1], p, self.batch_mode, hsh.digest())
+        plan = self._plans.get(key)
+        if plan is not None:
+            self._plans.move_to_end(key)
+            self.plan_stats["hits"] += 1
+        else:
+            if ei is None:
+                ei, bid = self._fc_host(sizes)
+            plan = self._build(ei, bid, n, p)
+            self._plans[key] = plan
+            self.plan_stats["builds"] += 1
+            total = sum(q.ws_bytes for q in self._plans.values())
+            while len(self._plans) > 1 and (len(self._plans) > self.MAX_PLANS or total > self.MAX_PLAN_BYTES):
+                _, old = self._plans.popitem(last=False)
+                total -= old.ws_bytes
+                old.destroy()
+        if fc_sizes is None:
+            self._ident[(id(edge_indices), id(batch_ids))] = (
+                (weakref.ref(edge_indices), weakref.ref(batch_ids)), (edge_indices._version, batch_ids._version), key)
+            while len(self._ident) > 4 * self.MAX_PLANS:
+                self._ident.popitem(last=False)
+        return plan
+
+    def _build(self, ei: torch.Tensor, bid: torch.Tensor, n: int, p: int) -> _Plan:
         e = ei.shape[1]
         perm = None
         out = C.c_void_p()
@@ -187,14 +269,9 @@ class VLSATModel:
             rc = create(ei)
             perm = order.to(self.device)
         L.check(rc)
-        plan = _Plan(out, perm)
-        plan.refs = (weakref.ref(edge_indices), weakref.ref(batch_ids))
-        plan.versions = (edge_indices._version, batch_ids._version)
-        self._plans[key] = plan
-        while len(self._plans) > self.MAX_PLANS:
-            _, old = self._plans.popitem(last=False)
-            old.destroy()
-        return plan
+        ws = C.c_size_t()
+        L.check(self._lib.vlsat_plan_info(out, None, C.byref(ws), None))
+        return _Plan(out, perm, ws.value)
 
     def plan_info(self, edge_indices, batch_ids, n, p):
         plan = self._plan(edge_indices, batch_ids, n, p)
@@ -215,13 +292,7 @@ class VLSATModel:
             raise L.VlsatError(f"{name}: rank {t.dim()}, expected {len(shape)}")
         return t if t.is_contiguous() else t.contiguous()
 
-    @torch.no_grad()
-    def forward(self, obj_points, obj_2d_feats, edge_indices, descriptor=None, batch_ids=None, istrain=False):
-        """Same contract as ``Mmgnet.forward`` (reference SGFN_MMG/model.py:288-335):
-        obj_points f32[N,3,P], obj_2d_feats f32[N,512], edge_indices i64[2,E], descriptor f32[N,11],
-        batch_ids i64[N,1] -> (obj_logits_3d [N,160], obj_logits_2d [N,160], rel_cls_3d [E,26], rel_cls_2d [E,26])."""
-        if istrain:
-            raise NotImplementedError("only the eval forward (istrain=False) is implemented")
+    def _inputs(self, obj_points, obj_2d_feats, edge_indices, descriptor, need_2d=True):
         if not self._loaded:
             raise L.VlsatError("weights not loaded: call load_state() first")
         if descriptor is None:
@@ -229,51 +300,67 @@ class VLSATModel:
         c = self.config
         n = obj_points.shape[0]
         pts = self._chk(obj_points, "obj_points", (n, c.dim_point, None), torch.float32)
-        f2d = self._chk(obj_2d_feats, "obj_2d_feats", (n, c.clip_feat_dim), torch.float32)
+        f2d = self._chk(obj_2d_feats, "obj_2d_feats", (n, c.clip_feat_dim), torch.float32) if need_2d else None
         desc = self._chk(descriptor, "descriptor", (n, c.dim_descriptor), torch.float32)
-        ei = self._chk(edge_indices, "edge_indices", (2, None), torch.int64)
-        if batch_ids is None:
-            batch_ids = self._zero_bid.get(n)
-            if batch_ids is None:
-                batch_ids = self._zero_bid[n] = torch.zeros(n, 1, dtype=torch.int64, device=self.device)
-        if batch_ids.numel() != n or batch_ids.dtype != torch.int64 or batch_ids.device != self.device:
-            raise L.VlsatError(f"batch_ids: expected int64[{n},1] on {self.device}")
-        p, e = pts.shape[2], ei.shape[1]
+        if not torch.is_tensor(edge_indices) or edge_indices.dim() != 2 or edge_indices.shape[0] != 2:
+            raise L.VlsatError("edge_indices: expected int64[2,E]")
+        return pts, f2d, desc, n, pts.shape[2], edge_indices.shape[1]
+
+    @torch.no_grad()
+    def forward(self, obj_points, obj_2d_feats, edge_indices, descriptor=None, batch_ids=None, istrain=False,
+                fc_sizes: Optional[Sequence[int]] = None):
+        """Same contract as ``Mmgnet.forward`` (reference SGFN_MMG/model.py:288-335):
+        obj_points f32[N,3,P], obj_2d_feats f32[N,512], edge_indices i64[2,E], descriptor f32[N,11],
+        batch_ids i64[N,1] -> (obj_logits_3d [N,160], obj_logits_2d [N,160], rel_cls_3d [E,26], rel_cls_2d [E,26]).
+        ``edge_indices`` / ``batch_ids`` may live on the host or on the device (they only feed the graph plan, see
+        ``_plan``); ``fc_sizes`` (objects per scene) optionally declares the canonical fully-connected graph.
+        ``istrain=True`` returns the reference's 8-tuple (:332-333) -- forward only, modules in eval mode, no autograd."""
+        pts, f2d, desc, n, p, e = self._inputs(obj_points, obj_2d_feats, edge_indices, descriptor)
+        c = self.config
         with torch.cuda.device(self.device):
-            plan = self._plan(edge_indices if ei is edge_indices else ei, batch_ids, n, p)
+            plan = self._plan(edge_indices, batch_ids, n, p, fc_sizes)
             obj3 = torch.empty(n, c.num_obj_class, dtype=torch.float32, device=self.device)
             obj2 = torch.empty_like(obj3)
             rel3 = torch.empty(e, c.num_rel_class, dtype=torch.float32, device=self.device)
             rel2 = torch.empty_like(rel3)
-            L.check(self._lib.vlsat_forward(self._h, plan.handle, pts.data_ptr(), f2d.data_ptr(), desc.data_ptr(),
-                                            obj3.data_ptr(), obj2.data_ptr(), rel3.data_ptr(), rel2.data_ptr(),
-                                            L.stream_ptr()))
+            extras = ()
+            if istrain:
+                if not c.train_outputs:
+                    raise L.VlsatError("forward(istrain=True) needs VLSATConfig(train_outputs=True) and the "
+                                       "triplet_projector_2d weights")
+                m3 = torch.empty(n, 512, dtype=torch.float32, device=self.device)
+                m2 = torch.empty_like(m3)
+                dis = torch.empty(e, 512, dtype=torch.float32, device=self.device)
+                L.check(self._lib.vlsat_forward_train(self._h, plan.handle, pts.data_ptr(), f2d.data_ptr(), desc.data_ptr(),
+                                                      obj3.data_ptr(), obj2.data_ptr(), rel3.data_ptr(), rel2.data_ptr(),
+                                                      m3.data_ptr(), m2.data_ptr(), dis.data_ptr(), L.stream_ptr()))
+                extras = (m3, m2, dis)
+            else:
+                L.check(self._lib.vlsat_forward(self._h, plan.handle, pts.data_ptr(), f2d.data_ptr(), desc.data_ptr(),
+                                                obj3.data_ptr(), obj2.data_ptr(), rel3.data_ptr(), rel2.data_ptr(),
+                                                L.stream_ptr()))
             if plan.perm is not None:     # outputs were computed in scene-grouped edge order
-                r3, r2 = torch.empty_like(rel3), torch.empty_like(rel2)
-                r3[plan.perm] = rel3
-                r2[plan.perm] = rel2
-                rel3, rel2 = r3, r2
+                def unperm(x):
+                    y = torch.empty_like(x)
+                    y[plan.perm] = x
+                    return y
+                rel3, rel2 = unperm(rel3), unperm(rel2)
+                if istrain:
+                    extras = (extras[0], extras[1], unperm(extras[2]))
+        if istrain:
+            scale = torch.tensor(math.exp(c.obj_logit_scale), dtype=torch.float32, device=self.device)
+            return (obj3, obj2, rel3, rel2) + extras + (scale,)
         return obj3, obj2, rel3, rel2
 
     @torch.no_grad()
-    def forward_3d(self, obj_points, edge_indices, descriptor, batch_ids=None):
+    def forward_3d(self, obj_points, edge_indices, descriptor, batch_ids=None, fc_sizes: Optional[Sequence[int]] = None):
         """3D-only deployment (no image features): returns (obj_logits_3d, rel_cls_3d), bit-identical to
         the first and third outputs of ``forward`` -- the 3D branch never reads the 2D branch
         (cf. reference src/model/SGFN_MMG/model_single.py:247-281) -- at about half the work."""
-        if not self._loaded:
-            raise L.VlsatError("weights not loaded: call load_state() first")
+        pts, _, desc, n, p, e = self._inputs(obj_points, None, edge_indices, descriptor, need_2d=False)
         c = self.config
-        n = obj_points.shape[0]
-        pts = self._chk(obj_points, "obj_points", (n, c.dim_point, None), torch.float32)
-        desc = self._chk(descriptor, "descriptor", (n, c.dim_descriptor), torch.float32)
-        ei = self._chk(edge_indices, "edge_indices", (2, None), torch.int64)
-        if batch_ids is None:
-            batch_ids = self._zero_bid.get(n)
-            if batch_ids is None:
-                batch_ids = self._zero_bid[n] = torch.zeros(n, 1, dtype=torch.int64, device=self.device)
-        p, e = pts.shape[2], ei.shape[1]
         with torch.cuda.device(self.device):
-            plan = self._plan(edge_indices if ei is edge_indices else ei, batch_ids, n, p)
+            plan = self._plan(edge_indices, batch_ids, n, p, fc_sizes)
             obj3 = torch.empty(n, c.num_obj_class, dtype=torch.float32, device=self.device)
             rel3 = torch.empty(e, c.num_rel_class, dtype=torch.float32, device=self.device)
             L.check(self._lib.vlsat_forward(self._h, plan.handle, pts.data_ptr(), None, desc.data_ptr(),

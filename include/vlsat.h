@@ -19,8 +19,14 @@
  *   - every function returns 0 on success or a negative VLSAT_E* code; it never throws and
  *     never calls exit(); vlsat_last_error() returns a thread-local message for the last failure.
  *   - vlsat_forward and the vlsat_k_* kernels are asynchronous on `stream` and do not synchronise.
+ *   - vlsat_plan_create / vlsat_plan_destroy never wait for the device either: the index tables are uploaded
+ *     asynchronously from pinned memory and the first forward of the plan waits for them ON THE DEVICE; a destroyed
+ *     plan's workspace is recycled behind the event of its last forward.  Device-wide waits exist only in
+ *     vlsat_load_weight (when it replaces an already finalised set), vlsat_set_gemm_precision, vlsat_destroy and the
+ *     vlsat_debug_* readers.
  *   - a handle (weights) may be shared by several plans; a plan owns its workspace and is NOT
- *     re-entrant (one forward at a time per plan), mirroring one nn.Module instance.
+ *     re-entrant (one forward at a time per plan), mirroring one nn.Module instance; a handle is driven from one
+ *     host thread at a time.
  */
 #ifndef VLSAT_H
 #define VLSAT_H
@@ -46,8 +52,8 @@ typedef struct vlsat_plan_s* vlsat_plan;
  * config/mmgnet.json:26-58). */
 typedef struct {
     int32_t n_layers;        /* MODEL.N_LAYERS */
-    int32_t n_heads;         /* MODEL.NUM_HEADS (8) */
-    int32_t dim_atten;       /* MODEL.DIM_ATTEN (256) */
+    int32_t n_heads;         /* MODEL.NUM_HEADS (8); built: 4, 8, 16 */
+    int32_t dim_atten;       /* MODEL.DIM_ATTEN (256); built: 128, 256, 512 */
     int32_t gcn_aggr;        /* MODEL.GCN_AGGR: 0 max, 1 add, 2 mean */
     int32_t dim_point;       /* 3, +3 with MODEL.USE_RGB, +3 with MODEL.USE_NORMAL (SGFN_MMG/model.py:31-35) */
     int32_t n_obj_class;     /* 160 */
@@ -60,7 +66,7 @@ typedef struct {
 } VlsatDims;
 
 const char* vlsat_last_error(void);
-/* library / build identification, e.g. "vlsat-hip gfx950 fp32-mfma r1" */
+/* library / build identification, e.g. "vlsat-hip gfx950 r2 (fp32-mfma | bf16x3 | bf16)" */
 const char* vlsat_version(void);
 
 /* Mmgnet.__init__ (module construction), reference SGFN_MMG/model.py:20-159. */
@@ -69,7 +75,10 @@ void vlsat_destroy(vlsat_handle h);
 
 /* BaseModel.load / load_state_dict, reference model_utils/model_base.py:75-129: `name` is the
  * reference state_dict key prefixed by the sub-module name ("mmg.gcn_3ds.0.edgeatten.nn_edge.0.weight");
- * `host` is fp32, `count` elements.  Unknown names -> VLSAT_EINVAL. */
+ * `host` is fp32, `count` elements.  Unknown names -> VLSAT_EINVAL.  Like BaseModel.load, loading may be repeated:
+ * the first call after a vlsat_finalize_weights starts a new, complete set (it waits for the device to go idle and
+ * drops the previous device tensors); existing plans stay valid.  "triplet_projector_2d.{0,3}.{weight,bias}" are
+ * optional and only read by vlsat_forward_train. */
 int vlsat_load_weight(vlsat_handle h, const char* name, const float* host, size_t count);
 /* Folds BatchNorm(eval), splits/concatenates/permutes the projections the kernels use and
  * uploads everything to the device.  Fails with VLSAT_ESTATE listing the first missing tensor. */
@@ -82,7 +91,8 @@ int vlsat_finalize_weights(vlsat_handle h);
  * like collate_fn_mmg does, reference DataLoader.py:167-172).  Requirements: every edge joins two
  * nodes of one scene; edges of a scene are contiguous and scenes appear in node order
  * (otherwise VLSAT_EGRAPH: the Python glue then permutes edges and retries).  Within a scene the
- * edge order is arbitrary.  Allocates the per-plan device workspace for (N, E, P). */
+ * edge order is arbitrary.  Allocates (or recycles) the per-plan device workspace for (N, E, P).  Returns without
+ * waiting for the device; the host arrays may be freed as soon as it returns. */
 int vlsat_plan_create(vlsat_handle h, const int64_t* batch_ids_host, const int64_t* edges_host,
                       int64_t n_nodes, int64_t n_edges, int32_t n_points, vlsat_plan* out);
 void vlsat_plan_destroy(vlsat_plan p);
@@ -101,11 +111,24 @@ int vlsat_forward(vlsat_handle h, vlsat_plan p,
                   float* obj_logits_3d, float* obj_logits_2d, float* rel_cls_3d, float* rel_cls_2d,
                   void* stream);
 
-/* Operand precision of the GEMM kernel inside vlsat_forward (BASELINE configs[2], "bf16 MFMA for the
- * QKV/FFN GEMMs"): 0 = exact fp32 MFMA (default; BASELINE configs[1]), 1 = bf16 operands, 3 = split-bf16
- * (a_hi.w_hi + a_lo.w_hi + a_hi.w_lo, fp32 accumulate).  Activations, attention, softmax, LayerNorm and
- * the point encoder stay fp32 in every mode.  May be changed between forwards; weights are split to
- * bf16 on the device at first use. */
+/* Mmgnet.forward(..., istrain=True) in eval mode (no dropout, no autograd), reference SGFN_MMG/model.py:291-292,312,
+ * 319-322,332-333: the four outputs of vlsat_forward plus obj_feature_3d_mimic [N,512] (first 512 columns of the
+ * point encoder's output), obj_features_2d_mimic [N,512] (the adapter's output) and gcn_edge_feature_2d_dis [E,512]
+ * (triplet_projector_2d on cat[x2[ei[0]], x2[ei[1]], e2]); the tuple's eighth element is exp(dims.obj_logit_scale).
+ * Needs the triplet_projector_2d weights. */
+int vlsat_forward_train(vlsat_handle h, vlsat_plan p,
+                        const float* obj_points, const float* obj_2d_feats, const float* descriptor,
+                        float* obj_logits_3d, float* obj_logits_2d, float* rel_cls_3d, float* rel_cls_2d,
+                        float* obj_feature_3d_mimic, float* obj_features_2d_mimic, float* gcn_edge_feature_2d_dis,
+                        void* stream);
+
+/* Operand precision of the matrix kernels inside vlsat_forward (BASELINE configs[2], "bf16 MFMA for the
+ * QKV/FFN GEMMs"): 0 = exact fp32 MFMA (default; BASELINE configs[1]); 3 = split-bf16 (a_hi.w_hi + a_lo.w_hi +
+ * a_hi.w_lo on v_mfma_f32_32x32x16_bf16, fp32 accumulate, ~1e-5 error); 1 = single-rounded bf16 operands
+ * everywhere (~2e-2 on the x14.29 object logits: outside the config's 1e-2); 2 = mixed: single-rounded bf16 on the
+ * edge-row GEMMs / attention / gate and split-bf16 on the node-row GEMMs (meets 1e-2).
+ * Activations in HBM, softmax and LayerNorm stay fp32 in every mode.  May be changed between forwards; the bf16
+ * planes of the weights are made inside this call (it waits for the device), never inside a forward. */
 int vlsat_set_gemm_precision(vlsat_handle h, int32_t mode);
 
 /* Which 3D edges a 2D edge attends to in the edge cross-attention (reference network_MMG.py:228-234), for plans
@@ -210,11 +233,11 @@ int vlsat_debug_read(vlsat_plan p, const char* name, float* dst, int64_t dst_ld)
  * cycles / (ticks / 1e8) is the shader clock the kernel actually ran at. NULL disables. */
 int vlsat_debug_gemm_clock_probe(int64_t* buf);
 
-/* Experimental fp32 GEMM variant for the full rounds of large-M launches (process-wide):
- * 0 = default (two 4-wave blocks per CU), 1 = one-wave-per-SIMD 256x128 kernel (gemm_f32_big.hip) for
- * launches without additive operands, 2 = that kernel for every combination it is built for.
- * Same results to fp32 rounding-order differences; kept opt-in because it is not faster end to end. */
-int vlsat_debug_gemm_variant(int32_t variant);
+/* Experiment switches of one handle; defaults are the measured-best settings and none changes results beyond
+ * fp32 summation order.  "dual_stream" 0|1: 2D twin stages of small plans on a second stream; "flash_split" 0|1:
+ * split-key edge attention for plans that cannot fill the chip (both: plans created afterwards); "gemm_dma" 0|1:
+ * LDS-direct staging of fp32 GEMM operands; "gate_grid" n: persistent grid of the gate kernel (0 = default). */
+int vlsat_debug_option(vlsat_handle h, const char* name, int32_t value);
 
 #ifdef __cplusplus
 }

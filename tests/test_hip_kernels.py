@@ -130,37 +130,6 @@ def test_gemm_persistent_rounds_with_epilogues(lib):
     assert err < 3e-5, f"{err:.3e}"
 
 
-@pytest.mark.parametrize("K", [64, 512])
-def test_gemm_big_variant_matches(lib, K):
-    """The opt-in one-wave-per-SIMD kernel (gemm_f32_big.hip) on full rounds + the default kernel on the tail
-    rows: plain, ReLU-on-A, residual and gathered-row launches, ragged N and padded ldc."""
-    g = torch.Generator().manual_seed(33 + K)
-    NG = 257
-    l = lib.load()
-    try:
-        lib.check(l.vlsat_debug_gemm_variant(2))
-        for N, kwn in ((512, "plain"), (512, "relu_a"), (512, "resid"), (1024, "gather"), (200, "plain")):
-            nbn = (N + 127) // 128
-            M = 2 * 256 * 256 // nbn + 300                     # two rounds of 256 tiles of 256x128, then a tail
-            A = torch.randn(M, K, generator=g).to(DEV)
-            W = (torch.randn(N, K, generator=g) * 0.1).to(DEV)
-            kw = dict(bias=torch.randn(N, generator=g).to(DEV), act=1 if kwn != "resid" else 0)
-            if kwn == "relu_a":
-                kw["relu_a"] = 1
-            if kwn == "resid":
-                kw.update(resid=torch.randn(M, N, generator=g).to(DEV), resid_scale=0.5)
-            if kwn == "gather":
-                gbuf = torch.randn(NG, 2 * N, generator=g).to(DEV)
-                kw.update(g0=gbuf[:, :N], gi0=torch.randint(0, NG, (M,), generator=g, dtype=torch.int32).to(DEV),
-                          g1=gbuf[:, N:], gi1=torch.randint(0, NG, (M,), generator=g, dtype=torch.int32).to(DEV))
-            got = _gemm(lib, A, W, ldc=N + 4, **kw)
-            ref = _ref_gemm(A, W, **kw)
-            err = float((got - ref).abs().max())
-            assert err < 2e-5 * math.sqrt(K / 64) + 2e-5, f"big variant {kwn} N={N} K={K}: {err:.3e}"
-    finally:
-        lib.check(l.vlsat_debug_gemm_variant(0))
-
-
 @pytest.mark.parametrize("M,N,K,lda", [(1000, 300, 96, 96), (70000, 512, 512, 512), (4097, 130, 64, 200), (33, 26, 256, 256)])
 def test_gemm_lds_direct_pipe_is_bit_identical_to_vgpr_pipe(lib, M, N, K, lda):
     """Launches without ReLU-on-A stage their operands with buffer_load ... lds into swizzled LDS rows

@@ -40,15 +40,15 @@ def main():
     gts = [(torch.from_numpy(rng.integers(0, 160, int(n))).to(dev),
             torch.from_numpy((rng.random((int(n) * (int(n) - 1), 26)) < 0.04).astype(np.int64)).to(dev)) for n in sizes]
 
-    def call(it):
-        return model.forward(it["obj_points"], it["obj_2d_feats"], it["edge_indices"], it["descriptor"], it["batch_ids"])
+    def call(it, hint=False):
+        n = it["obj_points"].shape[0]
+        return model.forward(it["obj_points"], it["obj_2d_feats"], it["edge_indices"], it["descriptor"], it["batch_ids"],
+                             fc_sizes=[n] if hint else None)
 
     for it in items[:3]:                                   # warm-up: allocator, kernels
         call(it)
     torch.cuda.synchronize()
-    for p in model._plans.values():
-        p.destroy()
-    model._plans.clear()
+    model._drop_plans()
     t_fwd, t_rank = [], []
     for it, (gc, gr) in zip(items, gts):
         torch.cuda.synchronize()
@@ -69,11 +69,30 @@ def main():
         call(it)
         torch.cuda.synchronize()
         t_hot.append(time.perf_counter() - t0)
-    f, r, h = np.array(t_fwd) * 1e3, np.array(t_rank) * 1e3, np.array(t_hot) * 1e3
+    # what an eval loop that knows its scene sizes does (evaluate.py): fresh tensors every call, graph declared by shape
+    model._drop_plans()
+    t_hint = []
+    for it in items:
+        fresh = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in it.items()}
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        call(fresh, hint=True)
+        torch.cuda.synchronize()
+        t_hint.append(time.perf_counter() - t0)
+    # back to back without a host sync between scenes (how a loop that only reads results at the end behaves)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    outs = [call(it) for it in items]
+    torch.cuda.synchronize()
+    t_pipe = (time.perf_counter() - t0) / len(items)
+    f, r, h, hi = np.array(t_fwd) * 1e3, np.array(t_rank) * 1e3, np.array(t_hot) * 1e3, np.array(t_hint) * 1e3
     print(f"{a.scenes} scenes, 9..80 objects x {a.points} pts, one scene per call (fully connected, E = n(n-1)):")
     print(f"  new graph each call : plan+forward {f.mean():6.2f} ms mean ({np.median(f):.2f} median, {f.max():.2f} max); "
           f"ranking {r.mean():.2f} ms  -> {1e3 / (f.mean() + r.mean()):.0f} scenes/s")
-    print(f"  same graphs again   : forward {h.mean():6.2f} ms mean (plan cached)")
+    print(f"  same graphs again   : forward {h.mean():6.2f} ms mean ({np.median(h):.2f} median; plan cached)")
+    print(f"  fresh tensors + fc_sizes hint, new sizes build a plan: {hi.mean():6.2f} ms mean ({np.median(hi):.2f} median)")
+    print(f"  back to back, no host sync between scenes: {t_pipe * 1e3:6.2f} ms per scene")
+    print(f"  plan cache: {model.plan_stats}")
     big = to_dev(synth.collate(scenes))
     call(big)
     torch.cuda.synchronize()
