@@ -44,6 +44,19 @@ __device__ __forceinline__ int xcd_remap(int b, int nblk) {
     return base + idx;
 }
 
+// Split-pair format of the bf16 modes (one 32-bit word per element, same footprint and addressing as fp32):
+// upper half = bf16 hi = rne(x), lower half = bf16 lo = rne(x - hi); x ~= hi + lo to 2^-17 relative.
+__device__ __forceinline__ float pack_split(float x) {
+    const __bf16 h = (__bf16)x;                                        // v_cvt_pk_bf16_f32 (round to nearest even)
+    const __bf16 l = (__bf16)(x - (float)h);
+    const unsigned hb = __builtin_bit_cast(unsigned short, h), lb = __builtin_bit_cast(unsigned short, l);
+    return __uint_as_float((hb << 16) | lb);
+}
+__device__ __forceinline__ float unpack_split(float w) {
+    const unsigned u = __float_as_uint(w);
+    return __uint_as_float(u & 0xffff0000u) + __uint_as_float(u << 16);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -82,6 +82,8 @@ struct vlsat_ctx {
     double acc_fl[vlsat::PC_COUNT] = {0};
     int debug_stop = -1;
     int gemm_no_dma = 0, gate_grid = 0;      // vlsat_debug_option
+    int split_fmt = 1;                       // bf16 modes: edge tensors between matrix kernels in the split-pair format
+    int flash_bf16 = 1, flash_tr = 1;        // bf16 modes: attention on the bf16 matrix cores / V operand by LDS transpose read
     long gemm_launches = 0;  // kernels launched by launch_gemm for this handle (main + tail launches)
     int cur_N = -1;          // node count of the plan whose forward is being enqueued (row class of a GEMM launch)
     // GEMM operand precision: 0 exact fp32 MFMA, 1 bf16, 3 split-bf16 (vlsat_set_gemm_precision); prec_edge / prec_node

@@ -38,6 +38,9 @@ int vlsat_set_edge_attention_scope(vlsat_handle h, int32_t scope) {
 //   "flash_split" 0|1   split-key edge attention for plans that cannot fill the chip (plans created afterwards)
 //   "gemm_dma"    0|1   LDS-direct staging of fp32 GEMM operands (0: VGPR-staged)
 //   "gate_grid"   n     persistent grid of the gate kernel (0: default)
+//   "split_fmt"   0|1   bf16 modes: edge tensors between matrix kernels as bf16 hi/lo pairs (0: plain fp32, split on read)
+//   "flash_bf16"  0|1   bf16 modes: edge attention on the bf16 matrix cores (0: keep the fp32 kernel)
+//   "flash_tr"    0|1   bf16 attention: V operand by ds_read_b64_tr_b16 (0: ds_read_u16 gather)
 int vlsat_debug_option(vlsat_handle h, const char* name, int32_t value) {
     if (!h || !name) return fail(VLSAT_EINVAL, "vlsat_debug_option: null argument");
     const std::string k(name);
@@ -45,6 +48,9 @@ int vlsat_debug_option(vlsat_handle h, const char* name, int32_t value) {
     else if (k == "flash_split") h->fa_split = value != 0;
     else if (k == "gemm_dma") h->gemm_no_dma = value == 0;
     else if (k == "gate_grid") h->gate_grid = value > 0 ? value : 0;
+    else if (k == "split_fmt") h->split_fmt = value != 0;
+    else if (k == "flash_bf16") h->flash_bf16 = value != 0;
+    else if (k == "flash_tr") h->flash_tr = value != 0;
     else return fail(VLSAT_EINVAL, "vlsat_debug_option: unknown option " + k);
     return 0;
 }
@@ -59,6 +65,52 @@ int vlsat_k_gemm(const float* A, int32_t lda, const float* W, int32_t ldw, float
     a.bias = bias; a.rowscale = rowscale; a.resid = resid; a.ldr = ldr; a.resid_scale = resid_scale;
     a.g0 = g0; a.gi0 = gi0; a.ldg0 = ldg0; a.g1 = g1; a.gi1 = gi1; a.ldg1 = ldg1; a.relu_a = relu_a; a.act = act;
     return launch_gemm(a, static_cast<hipStream_t>(stream));
+}
+
+// w[i] -> bf16 hi[i] + bf16 lo[i]: the planes the bf16 GEMM modes read (asynchronous on `stream`)
+int vlsat_k_split_bf16(const float* w, size_t n, uint16_t* hi, uint16_t* lo, void* stream) {
+    if (!w || !hi || !lo) return fail(VLSAT_EINVAL, "split_bf16: null argument");
+    return launch_split_bf16(w, n, hi, lo, static_cast<hipStream_t>(stream));
+}
+
+// vlsat_k_gemm on the bf16 matrix cores with caller-provided weight planes (asynchronous): prec 1 = bf16, 3 = split-bf16;
+// no_dma = 1 selects the VGPR-staged operand pipe of round 1, prefetch = slices of look-ahead of the A prefetch (0 = off)
+int vlsat_k_gemm_planes(const float* A, int32_t lda, const float* W, const uint16_t* Whi, const uint16_t* Wlo, int32_t ldw,
+                        float* C, int32_t ldc, int32_t M, int32_t N, int32_t K, const float* bias,
+                        const float* resid, int32_t ldr, float resid_scale,
+                        const float* g0, const int32_t* gi0, int32_t ldg0, const float* g1, const int32_t* gi1, int32_t ldg1,
+                        int32_t relu_a, int32_t act, int32_t prec, int32_t no_dma, int32_t prefetch, int32_t fmt, float c_scale,
+                        void* stream) {
+    if (prec != 1 && prec != 3) return fail(VLSAT_EINVAL, "gemm_planes: prec must be 1 or 3");
+    GemmArgs a;
+    a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
+    a.bias = bias; a.resid = resid; a.ldr = ldr; a.resid_scale = resid_scale;
+    a.g0 = g0; a.gi0 = gi0; a.ldg0 = ldg0; a.g1 = g1; a.gi1 = gi1; a.ldg1 = ldg1; a.relu_a = relu_a; a.act = act;
+    a.prec = prec; a.Whi = Whi; a.Wlo = Wlo; a.no_dma = no_dma; a.prefetch = prefetch;
+    a.a_split = fmt & 1; a.r_split = (fmt >> 1) & 1; a.c_split = (fmt >> 2) & 1; a.c_scale = c_scale;
+    a.k_rotate = (fmt >> 3) & 1;               // (bit 3: k rotation, bit 4: no ring kernel -- benchmarking)
+    a.no_ring = (fmt >> 4) & 1;
+    return launch_gemm(a, static_cast<hipStream_t>(stream));
+}
+
+// test entry point: splits a dense W [N,K] on the spot (allocates, synchronises) and runs vlsat_k_gemm_planes
+int vlsat_k_gemm_bf16(const float* A, int32_t lda, const float* W, int32_t ldw, float* C, int32_t ldc, int32_t M, int32_t N,
+                      int32_t K, const float* bias, const float* resid, int32_t ldr, float resid_scale,
+                      const float* g0, const int32_t* gi0, int32_t ldg0, const float* g1, const int32_t* gi1, int32_t ldg1,
+                      int32_t relu_a, int32_t act, int32_t prec, int32_t no_dma, void* stream) {
+    if (ldw != K) return fail(VLSAT_EINVAL, "gemm_bf16: W must be dense [N,K] (the planes are made from it)");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t n = (size_t)N * K;
+    uint16_t *hi = nullptr, *lo = nullptr;
+    VLSAT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&hi), n * 2 + 256));
+    VLSAT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&lo), n * 2 + 256));
+    int r = launch_split_bf16(W, n, hi, lo, st);
+    if (!r) r = vlsat_k_gemm_planes(A, lda, W, hi, lo, ldw, C, ldc, M, N, K, bias, resid, ldr, resid_scale, g0, gi0, ldg0, g1, gi1,
+                                    ldg1, relu_a, act, prec, no_dma, -1, 0, 1.f, stream);
+    hipStreamSynchronize(st);
+    hipFree(hi);
+    hipFree(lo);
+    return r;
 }
 
 int vlsat_k_pointnet(const float* pts, int32_t n_obj, int32_t n_points, const float* w1, const float* b1,
@@ -82,6 +134,27 @@ int vlsat_k_flash_attn(const float* Q, const float* K, const float* V, float* O,
     VLSAT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d), tiles.size() * sizeof(int4)));
     VLSAT_HIP_CHECK(hipMemcpy(d, tiles.data(), tiles.size() * sizeof(int4), hipMemcpyHostToDevice));
     int r = launch_flash_attn(Q, ld, K, V, ld, O, ld, d, (int)tiles.size(), scale * 1.4426950408889634f, st);
+    hipStreamSynchronize(st);     // test entry point only: the tile table is freed right away
+    hipFree(d);
+    return r;
+}
+
+int vlsat_k_flash_attn_bf16(const float* Q, const float* K, const float* V, float* O, int32_t ld, const int64_t* tok_ptr,
+                            int32_t n_scenes, int32_t n_heads, float scale, int32_t terms, int32_t use_tr, void* stream) {
+    if (!tok_ptr || n_scenes <= 0) return fail(VLSAT_EINVAL, "flash_attn: bad scene table");
+    std::vector<int4> tiles;
+    for (int s = 0; s < n_scenes; ++s) {
+        const int64_t T = tok_ptr[s + 1] - tok_ptr[s];
+        for (int hh = 0; hh < n_heads; ++hh)
+            for (int64_t q0 = 0; q0 < T; q0 += FLASH_BQ) tiles.push_back(make_int4((int)tok_ptr[s], (int)T, (int)q0, hh));
+    }
+    if (tiles.empty()) return 0;
+    int4* d = nullptr;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    VLSAT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d), tiles.size() * sizeof(int4)));
+    VLSAT_HIP_CHECK(hipMemcpy(d, tiles.data(), tiles.size() * sizeof(int4), hipMemcpyHostToDevice));
+    int r = launch_flash_attn_bf16(Q, ld, K, V, ld, O, ld, d, (int)tiles.size(), scale * 1.4426950408889634f, terms, use_tr != 0,
+                                   use_tr == 2, st);
     hipStreamSynchronize(st);     // test entry point only: the tile table is freed right away
     hipFree(d);
     return r;

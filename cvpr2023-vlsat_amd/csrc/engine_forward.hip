@@ -17,6 +17,15 @@ static Scratch scratch_of(const vlsat_plan_s* p, int branch) {
 
 namespace {
 
+// bf16 modes keep the edge-row tensors that only feed matrix kernels (E3, E2, Hbig, the relation-head hiddens, Q / K|V / O
+// of the edge attention) in the split-pair format (common.h pack_split): producers pack in their epilogues, consumers
+// separate hi / lo with two v_perm_b32 instead of re-splitting fp32 on every fragment read.  Not with
+// MODEL.feature_transform (its encoder chain keeps fp32 rows) and not when a debug option disabled one of the kernels
+// that understand the format.
+static bool split_fmt(const vlsat_ctx* h) {
+    return h->prec_edge != 0 && h->split_fmt && h->flash_bf16 && h->flash_tr && !h->gemm_no_dma && !h->d.feature_transform;
+}
+
 // ---- profiling helpers ----
 hipEvent_t next_event(vlsat_ctx* h) {
     if (h->ev_used == h->ev_pool.size()) {
@@ -113,17 +122,22 @@ int gcn_block(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const GcnW& w, float
               int out_relu, const Scratch& sc) {
     const int N = (int)p->N, E = (int)p->E, D = h->D, A = h->A, LDX = 768, NPC = 3328;
     RUN(gemm(h, s, G(x, LDX, w.wnode, D, sc.NP, NPC, N, NPC, w.bnode)));
+    const int S = split_fmt(h);
     GemmArgs e1 = G(e, D, w.we1, D, sc.Hbig, 2 * D, E, 2 * D, nullptr, ACT_RELU);
     e1.relu_a = e_relu_pending;
+    e1.a_split = S; e1.c_split = S;
     e1.g0 = sc.NP; e1.gi0 = p->d_src; e1.ldg0 = NPC;
     e1.g1 = sc.NP + 2 * D; e1.gi1 = p->d_dst; e1.ldg1 = NPC;
     RUN(gemm(h, s, e1));
     if (h->d.use_gcn_edge) {              // proj_edge feeds only the gate MLP (reference network_MMG.py:98-102)
         GemmArgs kp = G(e, D, w.wpe, D, sc.KP, D, E, D, w.bpe);
         kp.relu_a = e_relu_pending;
+        kp.a_split = S;                   // (its output feeds the fp32 gate kernel: plain fp32)
         RUN(gemm(h, s, kp));
     }
-    RUN(gemm(h, s, G(sc.Hbig, 2 * D, w.we2, 2 * D, e, D, E, D, w.be2)));   // e <- nn_edge output (pre-activation)
+    GemmArgs e2 = G(sc.Hbig, 2 * D, w.we2, 2 * D, e, D, E, D, w.be2);       // e <- nn_edge output (pre-activation)
+    e2.a_split = S; e2.c_split = S;
+    RUN(gemm(h, s, e2));
     {
         GateArgs g{};
         g.kproj = sc.KP; g.node = sc.NP; g.ld_node = NPC; g.gq_off = 4 * D; g.v_off = 4 * D + h->H * 128;
@@ -144,12 +158,18 @@ int gcn_block(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const GcnW& w, float
 int rel_head(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const RelHeadW& w, const float* e, int relu_a, float* out,
              const Scratch& sc) {
     const int E = (int)p->E, D = h->D, R = h->d.n_rel_class;
+    const int S = split_fmt(h);
     GemmArgs a = G(e, D, w.w1, D, sc.R1, 512, E, 512, w.b1, ACT_RELU);
     a.relu_a = relu_a;
+    a.a_split = S; a.c_split = S;
     RUN(gemm(h, s, a));
-    RUN(gemm(h, s, G(sc.R1, 512, w.w2, 512, sc.R2, 256, E, 256, w.b2, ACT_RELU)));
+    GemmArgs b = G(sc.R1, 512, w.w2, 512, sc.R2, 256, E, 256, w.b2, ACT_RELU);
+    b.a_split = S; b.c_split = S;
+    RUN(gemm(h, s, b));
     // multi_rel_outputs: sigmoid (PointNetRelClsMulti) or log_softmax over the R classes (PointNetRelCls)
-    RUN(gemm(h, s, G(sc.R2, 256, w.w3, 256, out, R, E, R, w.b3, h->d.multi_rel_outputs ? ACT_SIGMOID : ACT_NONE)));
+    GemmArgs c = G(sc.R2, 256, w.w3, 256, out, R, E, R, w.b3, h->d.multi_rel_outputs ? ACT_SIGMOID : ACT_NONE);
+    c.a_split = S;
+    RUN(gemm(h, s, c));
     if (!h->d.multi_rel_outputs) {
         Scope scope(h, s, PC_MISC, 0);
         RUN(launch_softmax_rows(out, R, E, R, out, 1, s));
@@ -266,6 +286,7 @@ static int forward_impl(vlsat_handle h, vlsat_plan p, const float* pts, const fl
     auto fork = [&]() { return order(s, t); };
     auto join = [&]() { return order(t, s); };
     const Scratch sc3 = scratch_of(p, 0), sc2 = scratch_of(p, dual ? 1 : 0);
+    const int S = split_fmt(h);            // edge tensors in the split-pair format (bf16 modes)
 
     const bool ft = h->d.feature_transform != 0;
     if (!ft) {   // a-2 object encoder
@@ -300,11 +321,14 @@ static int forward_impl(vlsat_handle h, vlsat_plan p, const float* pts, const fl
     }
     RUN(fork());                                                            // t: 2D relation encoder + adapter
     if (!ft) {
-        RUN(gemm(h, s, G(p->H1, 128, h->re3_w2, 64, sc3.H2, 128, E, 128, h->re3_b2, ACT_RELU)));
-        RUN(gemm(h, s, G(sc3.H2, 128, h->re3_w3, 128, p->E3, D, E, D, h->re3_b3, ACT_RELU)));
-        if (do2d) {
-            RUN(gemm(h, t, G(p->H1 + 64, 128, h->re2_w2, 64, sc2.H2, 128, E, 128, h->re2_b2, ACT_RELU)));
-            RUN(gemm(h, t, G(sc2.H2, 128, h->re2_w3, 128, p->E2, D, E, D, h->re2_b3, ACT_RELU)));
+        for (int br = 0; br < (do2d ? 2 : 1); ++br) {          // conv2 / conv3 of rel_encoder_3d (on s) and rel_encoder_2d (on t)
+            const Scratch& sc = br ? sc2 : sc3;
+            GemmArgs c2 = G(p->H1 + 64 * br, 128, br ? h->re2_w2 : h->re3_w2, 64, sc.H2, 128, E, 128, br ? h->re2_b2 : h->re3_b2, ACT_RELU);
+            c2.c_split = S;
+            RUN(gemm(h, br ? t : s, c2));
+            GemmArgs c3 = G(sc.H2, 128, br ? h->re2_w3 : h->re3_w3, 128, br ? p->E2 : p->E3, D, E, D, br ? h->re2_b3 : h->re3_b3, ACT_RELU);
+            c3.a_split = S; c3.c_split = S;
+            RUN(gemm(h, br ? t : s, c3));
         }
     } else if (E > 0) {   // P = 1: one row per edge; both encoders share the scratch, so they run one after the other on s
         for (int br = 0; br < (do2d ? 2 : 1); ++br) {
@@ -347,22 +371,35 @@ static int forward_impl(vlsat_handle h, vlsat_plan p, const float* pts, const fl
         STAGE(base + 3);
         if (do2d) {   // :231 edge cross-attention: q = 2D edges, k = v = 3D edges (pre-activation)
             const AttnW& w = h->cross_rel[l];
-            RUN(gemm(h, t, G(p->E2, D, w.wq, D, p->Qe, D, E, D, w.bq)));
-            RUN(gemm(h, s, G(p->E3, D, w.wkv, D, p->KVe, 2 * D, E, 2 * D, w.bkv)));
+            const float sc2e = 0.125f * 1.4426950408889634f;           // 1/sqrt(d_k) * log2(e): the attention works in exp2
+            GemmArgs gq = G(p->E2, D, w.wq, D, p->Qe, D, E, D, w.bq);
+            gq.a_split = S; gq.c_split = S;
+            if (S) gq.c_scale = sc2e;                                  // the split-format attention takes Q pre-scaled
+            RUN(gemm(h, t, gq));
+            GemmArgs gkv = G(p->E3, D, w.wkv, D, p->KVe, 2 * D, E, 2 * D, w.bkv);
+            gkv.a_split = S; gkv.c_split = S;
+            RUN(gemm(h, s, gkv));
             RUN(join());
             {
                 Scope sc(h, s, PC_FLASH, p->flash_flops);
                 FlashSplit sp;
                 sp.parts = p->fa_parts; sp.krange = p->d_krange; sp.o_part = p->fa_opart; sp.m_part = p->fa_m;
                 sp.l_part = p->fa_l; sp.part_stride = (size_t)E * D; sp.rows = E; sp.heads = h->H;
-                RUN(launch_flash_attn(p->Qe, D, p->KVe, p->KVe + D, 2 * D, p->Oe, D, p->d_tiles, p->n_tiles,
-                                      0.125f * 1.4426950408889634f, s, &sp));
+                if (h->prec_edge && h->flash_bf16)
+                    RUN(launch_flash_attn_bf16(p->Qe, D, p->KVe, p->KVe + D, 2 * D, p->Oe, D, p->d_tiles, p->n_tiles, sc2e,
+                                               h->prec_edge == 3 ? 3 : 1, h->flash_tr, S, s, &sp));
+                else
+                    RUN(launch_flash_attn(p->Qe, D, p->KVe, p->KVe + D, 2 * D, p->Oe, D, p->d_tiles, p->n_tiles, sc2e, s, &sp));
             }
-            GemmArgs o = G(p->Oe, D, w.wo, D, p->E2, D, E, D, w.bo);
+            // out-projection + residual, then LayerNorm (+ inter-layer ReLU).  Split format: the GEMM reads O and the
+            // residual as hi/lo pairs and writes plain fp32 into the (now dead) Q buffer; the LayerNorm packs E2 again.
+            float* pre_ln = S ? p->Qe : p->E2;
+            GemmArgs o = G(p->Oe, D, w.wo, D, pre_ln, D, E, D, w.bo);
             o.resid = p->E2; o.ldr = D;
+            o.a_split = S; o.r_split = S;
             RUN(gemm(h, s, o));
             Scope sc(h, s, PC_LAYERNORM, 0);
-            RUN(launch_layernorm(p->E2, D, E, D, w.lng, w.lnb, inter, s));
+            RUN(launch_layernorm_to(pre_ln, D, p->E2, D, E, D, w.lng, w.lnb, inter, S, s));
         }
         e3_pending_relu = inter;
         STAGE(base + 4);
@@ -376,8 +413,11 @@ static int forward_impl(vlsat_handle h, vlsat_plan p, const float* pts, const fl
         GemmArgs e1 = G(p->E2, D, h->trip.we, D, sc2.Hbig, 2 * D, E, 2 * D, nullptr, ACT_RELU);
         e1.g0 = sc2.NP; e1.gi0 = p->d_src; e1.ldg0 = NPC;
         e1.g1 = sc2.NP + 2 * D; e1.gi1 = p->d_dst; e1.ldg1 = NPC;
+        e1.a_split = S; e1.c_split = S;
         RUN(gemm(h, s, e1));
-        RUN(gemm(h, s, G(sc2.Hbig, 2 * D, h->trip.w2, 2 * D, tr->edge_dis, D, E, D, h->trip.b2)));
+        GemmArgs e2 = G(sc2.Hbig, 2 * D, h->trip.w2, 2 * D, tr->edge_dis, D, E, D, h->trip.b2);
+        e2.a_split = S;
+        RUN(gemm(h, s, e2));
     }
     // a-15 relation heads, a-16 object heads
     RUN(fork());                                              // t: the 2D heads

@@ -1,0 +1,320 @@
+// Edge cross-attention core on the bf16 matrix cores (BASELINE configs[2]): the same flash-style kernel as
+// flash_attn_f32.hip -- reference transformer/attention.py:60-76 as called from network_MMG.py:231, scores never
+// leave registers -- with QK^T and PV on v_mfma_f32_32x32x16_bf16 (16x the fp32-MFMA rate) and fp32 softmax.
+//
+// TERMS = 3 (split-bf16, ~1e-5): every operand x is carried as bf16 hi + bf16 lo (x ~= hi + lo to 2^-17) and each
+// product is three MFMAs  a_lo.b_hi + a_hi.b_lo + a_hi.b_hi  (small terms first), fp32 accumulate.
+// TERMS = 1 (single rounding): hi parts only.
+//
+// Q, K, V arrive as fp32 (the projection GEMMs' outputs) and are split while staging: Q once per block into registers
+// (pre-multiplied by scale*log2 e), K/V per key tile into LDS planes.
+//   block   = 128 queries (4 waves x 32), key tiles of 64, double-buffered LDS, one barrier per tile;
+//   S^T     = K_tile . Q^T  : A = K rows from LDS (ds_read_b128: 8 consecutive d, row pitch 144 B = conflict-free),
+//             B = Q from registers; "swapped" product so a lane owns ONE query column: the softmax row reductions
+//             are in-lane plus one lane^32 shuffle;
+//   O^T    += V^T . P^T     : B = P straight from the S registers -- the k-slot (half hi, element e) of step j is key
+//             32(j>>1) + 16(j&1) + 8(e>>2) + 4 hi + (e&3), i.e. exactly the keys registers 8(j&1)+e already hold, so P
+//             needs no cross-lane movement; A = V^T[d][those keys] read from the ROW-major V tile with the gfx950
+//             LDS transpose read ds_read_b64_tr_b16 (two reads of 4 keys x 16 d per operand).  The V image is
+//             4 sub-tiles [64 keys][16 d] (32-byte rows) 2176 B apart, so the two 16-lane groups of a half-wave land
+//             on disjoint bank halves (semantics and bank behaviour: tools/tr_read_probe.hip).
+//   TR = false keeps a gather fallback for the V operand (eight ds_read_u16 per operand) -- the reference
+//   implementation the transpose-read path is tested against.
+// Split keys (plans that cannot fill the chip) and the output transpose through LDS are as in flash_attn_f32.hip.
+// Roofline: bf16 MFMA, 2.5 PF / TERMS; algorithmic work 4*T^2*64 flop per (scene, head).
+#include "gemm_core.h"
+#include "kernels.h"
+
+namespace vlsat {
+
+namespace {
+
+constexpr int FB_KV = 64;              // keys per tile
+constexpr int FB_D = 64;               // head dim
+constexpr int FB_KPITCH = 144;         // bytes per key row of a K plane (128 + 16: conflict-free ds_read_b128)
+constexpr int FB_KPLANE = FB_KV * FB_KPITCH;                  // 9216
+constexpr int FB_VSUB = FB_KV * 32 + 128;                     // 2176: one [64 keys][16 d] sub-tile + half a bank row
+constexpr int FB_VPLANE = 4 * FB_VSUB;                        // 8704
+constexpr int FB_OPITCH = 68;          // floats per query row of the output transpose
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split4(const f32x4& x, bf16x4& hi, bf16x4& lo) {
+    hi = __builtin_convertvector(x, bf16x4);
+    lo = __builtin_convertvector(x - __builtin_convertvector(hi, f32x4), bf16x4);
+}
+// four elements of an operand tensor -> bf16 hi / lo.  IO_S: the tensor is in the split-pair format (common.h
+// pack_split; written by the projection GEMMs' epilogues in the bf16 modes), so this is two v_perm_b32 per plane
+template <bool IO_S>
+__device__ __forceinline__ void planes4(const f32x4& x, bf16x4& hi, bf16x4& lo) {
+    if (IO_S) {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        const u32x4 w = __builtin_bit_cast(u32x4, x);
+        u32x2 h, l;
+        h[0] = __builtin_amdgcn_perm(w[1], w[0], 0x07060302u); h[1] = __builtin_amdgcn_perm(w[3], w[2], 0x07060302u);
+        l[0] = __builtin_amdgcn_perm(w[1], w[0], 0x05040100u); l[1] = __builtin_amdgcn_perm(w[3], w[2], 0x05040100u);
+        hi = __builtin_bit_cast(bf16x4, h);
+        lo = __builtin_bit_cast(bf16x4, l);
+    } else {
+        split4(x, hi, lo);
+    }
+}
+
+// IO_S: Q, K, V arrive and O leaves in the split-pair format; Q is then already multiplied by scale * log2 e
+template <int TERMS, bool TR, bool IO_S>
+__global__ __launch_bounds__(256, 2) void flash_attn_bf16_kernel(
+    const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
+    float* __restrict__ O, int ldq, int ldkv, int ldo, const int4* __restrict__ tiles, int n_tiles,
+    float scale_log2e, FlashSplit sp) {
+    constexpr int PL = TERMS == 1 ? 1 : 2;
+    constexpr int BUF = PL * (FB_KPLANE + FB_VPLANE);
+    constexpr int SMEM = 2 * BUF > 4 * 32 * FB_OPITCH * 4 ? 2 * BUF : 4 * 32 * FB_OPITCH * 4;
+    __shared__ __attribute__((aligned(16))) char smem[SMEM];
+
+    const int tile_id = xcd_remap(blockIdx.x, n_tiles);
+    const int4 t = tiles[tile_id];
+    const int row_base = t.x, n_tok = t.y, q0 = t.z, head = t.w;
+    const int n_kv_tiles = (n_tok + FB_KV - 1) / FB_KV;
+    // split mode: sp.krange[tile] = {first 32-key tile, end 32-key tile, part, -} (units of 32 keys, see engine_plan.hip)
+    const int4 kr = sp.parts > 1 ? sp.krange[tile_id] : make_int4(0, 2 * n_kv_tiles, 0, 0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, hi = lane >> 5;
+    const size_t col0 = (size_t)head * FB_D;
+
+    const bool wave_active = q0 + wave * 32 < n_tok;
+    int qrow = q0 + wave * 32 + li;
+    if (qrow >= n_tok) qrow = n_tok - 1;      // clamped rows are computed but never stored
+    // ---- this lane's query: d = 16 ks + 8 hi + e, pre-scaled, split into bf16 hi / lo ----
+    bf16x8 qh[4], ql[4];
+    {
+        const float* qp = Q + (size_t)(row_base + qrow) * ldq + col0 + 8 * hi;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            f32x4 x0 = *reinterpret_cast<const f32x4*>(qp + 16 * ks), x1 = *reinterpret_cast<const f32x4*>(qp + 16 * ks + 4);
+            if (!IO_S) {
+                x0 *= scale_log2e;
+                x1 *= scale_log2e;
+            }
+            bf16x4 h0, l0, h1, l1;
+            planes4<IO_S>(x0, h0, l0);
+            planes4<IO_S>(x1, h1, l1);
+            qh[ks] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+            ql[ks] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+    }
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+
+    // ---- staging: K rows (tid>>4) + 16 i, four d per thread; V: wave-instruction = 4 keys x all 64 d, so that a
+    //      16-lane write group fills 4 consecutive 32-byte rows of ONE sub-tile (conflict-free ds_write_b64) ----
+    const int krow = tid >> 4, kc4 = (tid & 15) * 4;
+    const int vkey = 4 * wave + ((lane >> 2) & 3), vsub = lane >> 4, vc4 = vsub * 16 + (lane & 3) * 4;
+    f32x4 rk[4], rv[4];
+    auto load_tile = [&](int kv0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int r = kv0 + krow + 16 * i;
+            r = r < n_tok ? r : n_tok - 1;
+            rk[i] = *reinterpret_cast<const f32x4*>(K + (size_t)(row_base + r) * ldkv + col0 + kc4);
+            int rv_ = kv0 + vkey + 16 * i;
+            rv_ = rv_ < n_tok ? rv_ : n_tok - 1;
+            rv[i] = *reinterpret_cast<const f32x4*>(V + (size_t)(row_base + rv_) * ldkv + col0 + vc4);
+        }
+    };
+    auto store_tile = [&](char* buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bf16x4 h, l;
+            planes4<IO_S>(rk[i], h, l);
+            char* kp = buf + (krow + 16 * i) * FB_KPITCH + kc4 * 2;
+            *reinterpret_cast<bf16x4*>(kp) = h;
+            if (PL == 2) *reinterpret_cast<bf16x4*>(kp + FB_KPLANE) = l;
+            planes4<IO_S>(rv[i], h, l);
+            char* vp = buf + PL * FB_KPLANE + vsub * FB_VSUB + (vkey + 16 * i) * 32 + (lane & 3) * 8;
+            *reinterpret_cast<bf16x4*>(vp) = h;
+            if (PL == 2) *reinterpret_cast<bf16x4*>(vp + FB_VPLANE) = l;
+        }
+    };
+
+    // key range of this block in 64-key tiles (the split table counts 32-key tiles; a part boundary inside a 64-key
+    // tile is handled by masking, below)
+    const int kt0 = kr.x >> 1, kt1 = (kr.y + 1) >> 1;
+    const int key_lo = kr.x * 32, key_hi = kr.y * 32 < n_tok ? kr.y * 32 : n_tok;       // keys [key_lo, key_hi) belong to this block
+    if (kt0 < kt1) {
+        load_tile(kt0 * FB_KV);
+        store_tile(smem + (kt0 & 1) * BUF);
+    }
+    __syncthreads();
+
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const char* sK = smem + (kt & 1) * BUF;
+        const char* sV = sK + PL * FB_KPLANE;
+        const bool more = kt + 1 < kt1;
+        if (more) load_tile((kt + 1) * FB_KV);
+
+        if (wave_active) {
+            // ---- S^T[key][query] = sum_d K[key][d] * Q[query][d], two blocks of 32 keys ----
+            f32x16 s[2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+                const char* kp = sK + (32 * kb + li) * FB_KPITCH + 16 * hi;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const bf16x8 kh = *reinterpret_cast<const bf16x8*>(kp + 32 * ks);
+                    if (PL == 2) {
+                        const bf16x8 kl = *reinterpret_cast<const bf16x8*>(kp + FB_KPLANE + 32 * ks);
+                        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[ks], s[kb], 0, 0, 0);
+                        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[ks], s[kb], 0, 0, 0);
+                    }
+                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[ks], s[kb], 0, 0, 0);
+                }
+            }
+            // keys outside [key_lo, key_hi): beyond the scene's tokens (last tile) or another part's (split mode)
+            const int kv0 = kt * FB_KV;
+            if (kv0 < key_lo || kv0 + FB_KV > key_hi) {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = kv0 + 32 * kb + crow32(r, hi);
+                        if (key < key_lo || key >= key_hi) s[kb][r] = -INFINITY;
+                    }
+            }
+            // ---- online softmax for this lane's query ----
+            float mx = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s[0][r], s[1][r]));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run, mx);
+            // (a part whose first tile is fully masked for this query keeps m = -inf; exp2(-inf - -inf) must not be NaN)
+            const float m_use = m_new == -INFINITY ? 0.f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+            float rs = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    s[kb][r] = __builtin_amdgcn_exp2f(s[kb][r] - m_use);
+                    rs += s[kb][r];
+                }
+            rs += __shfl_xor(rs, 32);
+            l_run = l_run * alpha + rs;
+            m_run = m_new;
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+            }
+            // ---- O^T[d][query] += sum_key V[key][d] * P[key][query] ----
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int kb = j >> 1, half = j & 1;
+                f32x4 p0, p1;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { p0[c] = s[kb][8 * half + c]; p1[c] = s[kb][8 * half + 4 + c]; }
+                bf16x4 h0, l0, h1, l1;
+                split4(p0, h0, l0);
+                split4(p1, h1, l1);
+                const bf16x8 ph = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+                const bf16x8 pl = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+                const int k0 = 32 * kb + 16 * half + 4 * hi;          // first key of this lane half's k-slots (then +8)
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    bf16x8 vf[PL];
+#pragma unroll
+                    for (int pln = 0; pln < PL; ++pln) {
+                        const char* vb = sV + pln * FB_VPLANE + (2 * db + ((lane >> 4) & 1)) * FB_VSUB;
+                        if (TR) {
+                            const char* a = vb + (k0 + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;
+                            const s16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                (s16x4 __attribute__((address_space(3)))*)(a));
+                            const s16x4 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                (s16x4 __attribute__((address_space(3)))*)(a + 8 * 32));
+                            const bf16x4 b0 = __builtin_bit_cast(bf16x4, x0), b1 = __builtin_bit_cast(bf16x4, x1);
+                            vf[pln] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+                        } else {
+                            const unsigned short* g = reinterpret_cast<const unsigned short*>(vb) + (lane & 15);
+                            typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+                            u16x8 u;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) u[e] = g[(k0 + 8 * (e >> 2) + (e & 3)) * 16];
+                            vf[pln] = __builtin_bit_cast(bf16x8, u);
+                        }
+                    }
+                    f32x16& o = db ? o1 : o0;
+                    if (PL == 2) {
+                        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[PL - 1], ph, o, 0, 0, 0);
+                        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pl, o, 0, 0, 0);
+                    }
+                    o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], ph, o, 0, 0, 0);
+                }
+            }
+        }   // wave_active
+        if (more) store_tile(smem + ((kt + 1) & 1) * BUF);
+        __syncthreads();
+    }
+
+    // ---- normalise (or, in split mode, keep un-normalised and record m, l), transpose through LDS
+    //      (wave-private [32 q][68]), coalesced store ----
+    const bool split = sp.parts > 1;
+    const float inv_l = split ? 1.f : 1.f / l_run;
+    if (split) {
+        O = sp.o_part + (size_t)kr.z * sp.part_stride;
+        const int qr = q0 + wave * 32 + li;
+        if (hi == 0 && qr < n_tok) {
+            const size_t i = ((size_t)kr.z * sp.rows + row_base + qr) * sp.heads + head;
+            sp.m_part[i] = m_run;
+            sp.l_part[i] = l_run;
+        }
+    }
+    float* so = reinterpret_cast<float*>(smem) + wave * (32 * FB_OPITCH);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float a = o0[r] * inv_l, b = o1[r] * inv_l;
+        so[li * FB_OPITCH + crow32(r, hi)] = (IO_S && !split) ? pack_split(a) : a;       // (split-key partials stay fp32: the merge packs)
+        so[li * FB_OPITCH + 32 + crow32(r, hi)] = (IO_S && !split) ? pack_split(b) : b;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = lane + 64 * i;             // 512 float4 = 32 rows x 16
+        const int r = idx >> 4, c4 = (idx & 15) * 4;
+        const int qr = q0 + wave * 32 + r;
+        if (qr < n_tok)
+            *reinterpret_cast<f32x4*>(O + (size_t)(row_base + qr) * ldo + col0 + c4) =
+                *reinterpret_cast<const f32x4*>(so + r * FB_OPITCH + c4);
+    }
+}
+
+}  // namespace
+
+int launch_flash_attn_bf16(const float* Q, int ldq, const float* K, const float* V, int ldkv, float* O, int ldo,
+                           const int4* tiles, int n_tiles, float scale_log2e, int terms, int use_tr, int io_split,
+                           hipStream_t s, const FlashSplit* split) {
+    if (n_tiles <= 0) return 0;
+    if ((ldq | ldkv | ldo) & 3) return fail(-1, "flash_attn: leading dims must be multiples of 4");
+    if (terms != 1 && terms != 3) return fail(-1, "flash_attn_bf16: terms must be 1 or 3");
+    FlashSplit sp{};
+    if (split && split->parts > 1) {
+        sp = *split;
+        if (!sp.krange || !sp.o_part || !sp.m_part || !sp.l_part || sp.heads * FB_D > ldo)
+            return fail(-1, "flash_attn: incomplete split-key workspace");
+    }
+#define VLSAT_FA(T, R, S) hipLaunchKernelGGL((flash_attn_bf16_kernel<T, R, S>), dim3(n_tiles), dim3(256), 0, s, Q, K, V, O, ldq, ldkv, ldo, tiles, n_tiles, scale_log2e, sp)
+    if (io_split) {
+        if (!use_tr) return fail(-1, "flash_attn_bf16: the split-pair format is built for the transpose-read path only");
+        if (terms == 3) VLSAT_FA(3, true, true); else VLSAT_FA(1, true, true);
+    } else if (terms == 3) { if (use_tr) VLSAT_FA(3, true, false); else VLSAT_FA(3, false, false); }
+    else                   { if (use_tr) VLSAT_FA(1, true, false); else VLSAT_FA(1, false, false); }
+#undef VLSAT_FA
+    VLSAT_LAUNCH_CHECK("flash_attn_bf16");
+    if (sp.parts > 1) return launch_flash_merge(O, ldo, sp, s, io_split);
+    return 0;
+}
+
+}  // namespace vlsat

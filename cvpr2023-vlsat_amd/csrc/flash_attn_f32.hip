@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_f32_kernel(
 }
 
 // O[row, h*64 + d] = sum_p 2^(m_p - m) O_p[row, h*64 + d] / sum_p 2^(m_p - m) l_p,  m = max_p m_p  (per row, head)
-__global__ __launch_bounds__(256) void flash_merge_kernel(float* __restrict__ O, int ldo, FlashSplit sp) {
+__global__ __launch_bounds__(256) void flash_merge_kernel(float* __restrict__ O, int ldo, FlashSplit sp, int out_split) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;       // one float4 of one row
     const int per_row = sp.heads * (FA_D / 4);
     const size_t row = idx / per_row;
@@ -214,7 +214,10 @@ __global__ __launch_bounds__(256) void flash_merge_kernel(float* __restrict__ O,
     }
     const float inv = 1.f / den;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) acc[c] *= inv;
+    for (int c = 0; c < 4; ++c) {
+        acc[c] *= inv;
+        if (out_split) acc[c] = pack_split(acc[c]);
+    }
     *reinterpret_cast<f32x4*>(O + row * ldo + c4 * 4) = acc;
 }
 
@@ -231,11 +234,14 @@ int launch_flash_attn(const float* Q, int ldq, const float* K, const float* V, i
     hipLaunchKernelGGL(flash_attn_f32_kernel, dim3(n_tiles), dim3(256), 0, s, Q, K, V, O, ldq, ldkv, ldo, tiles,
                        n_tiles, scale_log2e, sp);
     VLSAT_LAUNCH_CHECK("flash_attn_f32");
-    if (sp.parts > 1) {
-        const size_t n4 = (size_t)sp.rows * sp.heads * (FA_D / 4);
-        hipLaunchKernelGGL(flash_merge_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, O, ldo, sp);
-        VLSAT_LAUNCH_CHECK("flash_merge");
-    }
+    if (sp.parts > 1) return launch_flash_merge(O, ldo, sp, s, 0);
+    return 0;
+}
+
+int launch_flash_merge(float* O, int ldo, const FlashSplit& sp, hipStream_t s, int out_split) {
+    const size_t n4 = (size_t)sp.rows * sp.heads * (FA_D / 4);
+    hipLaunchKernelGGL(flash_merge_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, O, ldo, sp, out_split);
+    VLSAT_LAUNCH_CHECK("flash_merge");
     return 0;
 }
 

@@ -113,6 +113,7 @@ struct NoCtx {
 
 template <int BM, int BN>
 struct PipeF32 {
+    static constexpr bool PREFETCH = false;
     static constexpr int TM = BM / 64, TN = BN / 64;
     static constexpr int STAGE_BYTES = (BM + BN) * LDT * 4;
     struct Regs { f32x4 a[BM / 32], b[BN / 32]; };
@@ -128,7 +129,7 @@ struct PipeF32 {
         stage_store<BM>(s, r.a, tid);
         stage_store<BN>(s + BM * LDT, r.b, tid);
     }
-    static __device__ __forceinline__ void mma(const char* stage, int wm, int wn, f32x16 (&acc)[TM][TN], int lane) {
+    static __device__ __forceinline__ void mma(const char* stage, int wm, int wn, f32x16 (&acc)[TM][TN], int lane, int = 0) {
         const float* s = reinterpret_cast<const float*>(stage);
         mma_slice<TM, TN>(s + (wm * TM * 32) * LDT, s + BM * LDT + (wn * TN * 32) * LDT, acc, lane);
     }
@@ -150,6 +151,7 @@ struct PipeF32 {
 // (the whole offset travels in the VGPR: on gfx9 the range check does not see the SGPR offset).
 template <int BM, int BN>
 struct PipeF32Dma {
+    static constexpr bool PREFETCH = false;
     static constexpr int TM = BM / 64, TN = BN / 64;
     static constexpr int STAGE_BYTES = (BM + BN) * BK * 4;
     struct Regs {};
@@ -184,7 +186,7 @@ struct PipeF32Dma {
     }
     // the slice has had a whole slice of MFMAs to land; the caller's barrier publishes it
     static __device__ __forceinline__ void store(char*, Regs&, int, int) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-    static __device__ __forceinline__ void mma(const char* stage, int wm, int wn, f32x16 (&acc)[TM][TN], int lane) {
+    static __device__ __forceinline__ void mma(const char* stage, int wm, int wn, f32x16 (&acc)[TM][TN], int lane, int = 0) {
         const int li = lane & 31, hi = lane >> 5;
         const int sw = (li >> 1) & 7;
         const float* sA = reinterpret_cast<const float*>(stage) + (wm * TM * 32 + li) * BK + 4 * ((hi ^ sw) & 1);
@@ -232,6 +234,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 template <int BM, int BN, int TERMS>
 struct PipeBF16 {
+    static constexpr bool PREFETCH = false;
     static constexpr int TM = BM / 64, TN = BN / 64;
     static constexpr int PH = 40;                                  // row pitch in bf16 elements (80 B)
     static constexpr int PL = TERMS == 1 ? 1 : 2;                  // planes: hi (, lo)
@@ -275,7 +278,7 @@ struct PipeBF16 {
                 *reinterpret_cast<uint4*>(stage + A_PLANE * PL + W_PLANE * pl + ((idx >> 2) * PH + (idx & 3) * 8) * 2) = r.w[pl][i];
             }
     }
-    static __device__ __forceinline__ void mma(const char* stage, int wm, int wn, f32x16 (&acc)[TM][TN], int lane) {
+    static __device__ __forceinline__ void mma(const char* stage, int wm, int wn, f32x16 (&acc)[TM][TN], int lane, int = 0) {
         const int li = lane & 31, hi = lane >> 5;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -303,8 +306,146 @@ struct PipeBF16 {
     }
 };
 
+
+// bf16 / split-bf16 path with LDS-direct staging (round 2; what the forward uses in the bf16 modes).
+// A stays fp32 in HBM and travels HBM/L2 -> LDS exactly like PipeF32Dma's (same swizzled 128-byte rows); it is split
+// into bf16 hi/lo on the FRAGMENT READ side: 8 consecutive k = two ds_read_b128, 24 VALU (cvt_pk, shift, sub, cvt_pk),
+// hidden behind the 32-cycle bf16 MFMAs.  The pre-split weight planes (Whi / Wlo, [N,K] bf16) are DMA'd as 64-byte
+// rows, 16 rows per wave instruction (lane l -> row l>>2, 16-byte chunk l&3), chunks XOR-swizzled with (row>>2)&3 so
+// that the ds_read_b128 lane groups of MI355X_MICROARCH.md ({0-3,12-15,20-27} ...) touch every bank once.
+// Against PipeBF16 (VGPR staging, split while storing to LDS) this removes the global_load -> VGPR -> ds_write round
+// trip (8 loads + 12 ds_writes per wave per slice, ~64 matrix-pipe cycles each, tools/vmem_issue_probe.hip).
+// k-slot convention (A and W agree): kstep ks, lane half hi, element e covers k = 16 ks + 8 hi + e.
+// AS = true: A is stored in the SPLIT-PAIR format the bf16 modes keep their edge tensors in (one 32-bit word per element:
+// bf16 hi = rne(x) in the upper half, bf16 lo = rne(x - hi) in the lower half; written by the producing kernel's
+// epilogue, common.h pack_split).  Same footprint and addressing as fp32, so the DMA staging is unchanged, and the
+// fragment-side split shrinks from ~24 VALU per 8 elements (cvt_pk, shift, sub, cvt_pk) to 8 v_perm_b32.
+template <int BM, int BN, int TERMS, bool AS = false>
+struct PipeSplitDma {
+    // With bf16 MFMAs a k-slice is 256 (bf16) to 768 (bf16x3) matrix-pipe cycles per wave, far less than the latency of
+    // an A line that comes from HBM / the Infinity Cache, and LDS cannot hold enough slices in flight to cover it: the
+    // kernel touches the A lines of the slice `prefetch` steps ahead (one dword per line into a dead register) so
+    // that the LDS-direct loads that follow hit the XCD's L2.  See gemm_f32.hip.
+    static constexpr bool PREFETCH = true;
+    static constexpr int TM = BM / 64, TN = BN / 64;
+    static constexpr int PL = TERMS == 1 ? 1 : 2;
+    static constexpr int A_BYTES = BM * BK * 4, W_PLANE = BN * BK * 2;
+    static constexpr int STAGE_BYTES = A_BYTES + W_PLANE * PL;
+    struct Regs {};
+    struct Ctx {
+        int na, nw;                         // bytes addressable behind A / a W plane
+        unsigned va, vw;                    // per-lane byte offsets inside an instruction's row group (swizzled chunk)
+        template <class Args>
+        __device__ __forceinline__ Ctx(const Args& p, int tid) {
+            const int wave = tid >> 6, l = tid & 63;
+            na = (int)(((size_t)(p.M - 1) * p.lda + p.K) * 4);
+            nw = (int)(((size_t)(p.N - 1) * p.ldw + p.K) * 2);
+            const int row = 8 * wave + (l >> 3);
+            va = (unsigned)(row * p.lda + 4 * ((l & 7) ^ ((row >> 1) & 7))) * 4u;
+            const int wrow = 16 * wave + (l >> 2);                       // (wrow >> 2) & 3 == (l >> 4) & 3
+            vw = (unsigned)(wrow * p.ldw + 8 * ((l & 3) ^ ((l >> 4) & 3))) * 2u;
+        }
+    };
+    static __device__ __forceinline__ void load(const Ctx& c, const GemmArgs& p, int m0, int n0, int k0, Regs&, int tid, char* stage) {
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, c.na, 0x00020000);
+        float* sa = reinterpret_cast<float*>(stage) + wave * 8 * BK;
+#pragma unroll
+        for (int i = 0; i < BM / 32; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, sa + i * 32 * BK, 16, c.va + (unsigned)(((m0 + 32 * i) * p.lda + k0) * 4), 0, 0, 0);
+#pragma unroll
+        for (int pl = 0; pl < PL; ++pl) {
+            const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(pl ? p.Wlo : p.Whi), 0, c.nw, 0x00020000);
+            char* sw = stage + A_BYTES + pl * W_PLANE + wave * 16 * BK * 2;
+#pragma unroll
+            for (int i = 0; i < BN / 64; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, sw + i * 64 * BK * 2, 16, c.vw + (unsigned)(((n0 + 64 * i) * p.ldw + k0) * 2), 0, 0, 0);
+        }
+    }
+    static __device__ __forceinline__ void store(char*, Regs&, int, int) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    // the slice's loads have landed; one younger load (the prefetch touch) may stay in flight
+    static __device__ __forceinline__ void store_keep1() { asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); }
+    // 8 consecutive k of one row (two 16-byte chunks) -> the bf16 hi / lo operand registers
+    template <bool RELU>
+    static __device__ __forceinline__ void split8(f32x4 x0, f32x4 x1, bf16x8& hi, bf16x8& lo) {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        if (AS) {
+            u32x4 a = __builtin_bit_cast(u32x4, x0), b = __builtin_bit_cast(u32x4, x1);
+            if (RELU) {          // x < 0  <=>  its hi part is negative: sign bit of the word; the whole word becomes +0
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    a[c] = (unsigned)max((int)a[c], 0);
+                    b[c] = (unsigned)max((int)b[c], 0);
+                }
+            }
+            u32x4 h, l;                       // v_perm_b32: upper / lower halves of two words into one
+            h[0] = __builtin_amdgcn_perm(a[1], a[0], 0x07060302u); h[1] = __builtin_amdgcn_perm(a[3], a[2], 0x07060302u);
+            h[2] = __builtin_amdgcn_perm(b[1], b[0], 0x07060302u); h[3] = __builtin_amdgcn_perm(b[3], b[2], 0x07060302u);
+            hi = __builtin_bit_cast(bf16x8, h);
+            if (PL == 2) {
+                l[0] = __builtin_amdgcn_perm(a[1], a[0], 0x05040100u); l[1] = __builtin_amdgcn_perm(a[3], a[2], 0x05040100u);
+                l[2] = __builtin_amdgcn_perm(b[1], b[0], 0x05040100u); l[3] = __builtin_amdgcn_perm(b[3], b[2], 0x05040100u);
+                lo = __builtin_bit_cast(bf16x8, l);
+            }
+        } else {
+            if (RELU) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { x0[c] = fmaxf(x0[c], 0.f); x1[c] = fmaxf(x1[c], 0.f); }
+            }
+            const bf16x4 h0 = __builtin_convertvector(x0, bf16x4), h1 = __builtin_convertvector(x1, bf16x4);
+            hi = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+            if (PL == 2) {
+                const bf16x4 l0 = __builtin_convertvector(x0 - __builtin_convertvector(h0, f32x4), bf16x4);
+                const bf16x4 l1 = __builtin_convertvector(x1 - __builtin_convertvector(h1, f32x4), bf16x4);
+                lo = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+        }
+    }
+    static __device__ __forceinline__ void mma(const char* stage, int wm, int wn, f32x16 (&acc)[TM][TN], int lane, int relu_a = 0) {
+        if (relu_a) mma_t<true>(stage, wm, wn, acc, lane);          // wave-uniform: two straight-line bodies, no per-element select
+        else mma_t<false>(stage, wm, wn, acc, lane);
+    }
+    template <bool RELU>
+    static __device__ __forceinline__ void mma_t(const char* stage, int wm, int wn, f32x16 (&acc)[TM][TN], int lane) {
+        const int li = lane & 31, hi = lane >> 5;
+        const float* sA = reinterpret_cast<const float*>(stage) + (wm * TM * 32 + li) * BK;
+        const char* sW = stage + A_BYTES + (wn * TN * 32 + li) * BK * 2;
+        const int swa = (li >> 1) & 7, sww = (li >> 2) & 3;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            bf16x8 a[PL][TM], w[PL][TN];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const int c0 = (4 * ks + 2 * hi) ^ swa;                   // physical chunk of the first four k; the next four sit at c0 ^ 1
+                const f32x4 x0 = *reinterpret_cast<const f32x4*>(sA + tm * 32 * BK + 4 * c0);
+                const f32x4 x1 = *reinterpret_cast<const f32x4*>(sA + tm * 32 * BK + 4 * (c0 ^ 1));
+                split8<RELU>(x0, x1, a[0][tm], a[PL - 1][tm]);
+            }
+#pragma unroll
+            for (int pl = 0; pl < PL; ++pl)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    w[pl][tn] = *reinterpret_cast<const bf16x8*>(sW + pl * W_PLANE + tn * 32 * BK * 2 + 16 * ((2 * ks + hi) ^ sww));
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    if (PL == 2) {                          // small terms first
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][tm], w[0][tn], acc[tm][tn], 0, 0, 0);
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][tm], w[PL - 1][tn], acc[tm][tn], 0, 0, 0);
+                    }
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][tm], w[0][tn], acc[tm][tn], 0, 0, 0);
+                }
+        }
+    }
+};
+
 template <int BM, int BN, int PREC> struct PipeSel { using type = PipeBF16<BM, BN, PREC>; };
 template <int BM, int BN> struct PipeSel<BM, BN, 0> { using type = PipeF32<BM, BN>; };
 template <int BM, int BN> struct PipeSel<BM, BN, 4> { using type = PipeF32Dma<BM, BN>; };   // internal: fp32, LDS-direct staging
+template <int BM, int BN> struct PipeSel<BM, BN, 5> { using type = PipeSplitDma<BM, BN, 1>; }; // internal: bf16, LDS-direct staging
+template <int BM, int BN> struct PipeSel<BM, BN, 7> { using type = PipeSplitDma<BM, BN, 3>; }; // internal: bf16x3, LDS-direct staging
+template <int BM, int BN> struct PipeSel<BM, BN, 9> { using type = PipeSplitDma<BM, BN, 1, true>; };  // ... A in split-pair format
+template <int BM, int BN> struct PipeSel<BM, BN, 11> { using type = PipeSplitDma<BM, BN, 3, true>; };
 
 }  // namespace vlsat

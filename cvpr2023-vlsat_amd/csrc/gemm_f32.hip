@@ -55,6 +55,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int n_tile
     const int wm = wave >> 1, wn = wave & 1;
     const int g8 = gridDim.x >> 3, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int KT = p.K / (BK * KSL);
+    // k rotation: the blocks of an XCD run in near lock-step, so at any moment they would all fetch the SAME k-slice of their
+    // rows -- addresses a whole row pitch (a power of two) apart, which lands them on a couple of the XCD's 16 L2 channels
+    // (the bf16 kernels, 5x shorter slices, plateaued at ~29 GB/s per CU from L2 whatever the staging method).  Tile row
+    // panel i therefore starts its k loop at slice i mod KT: same sum, other order; the N-tile neighbours that share an
+    // A panel keep the same rotation, so they still meet in L2.
+    auto kslice = [&](int m_first, int kt) { int j = kt + (p.k_rotate ? (m_first / BM) % KT : 0); return (j >= KT ? j - KT : j) * (BK * KSL); };
 
     int round = 0;
     int v = xcd * g8 + slot;                 // tile of round r: (r*8 + xcd)*g8 + slot
@@ -68,10 +74,16 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int n_tile
     const typename Pipe::Ctx ctx(p, tid);
 
 #pragma unroll
-    for (int ks = 0; ks < KSL; ++ks) Pipe::load(ctx, p, m0, n0, ks * BK, regs[ks], tid, smem + ks * SLICE);
+    for (int ks = 0; ks < KSL; ++ks) Pipe::load(ctx, p, m0, n0, kslice(m0, 0) + ks * BK, regs[ks], tid, smem + ks * SLICE);
 #pragma unroll
     for (int ks = 0; ks < KSL; ++ks) Pipe::store(smem + ks * SLICE, regs[ks], tid, p.relu_a);
     __syncthreads();
+
+    // A-panel prefetch of the bf16 LDS-direct pipe (Pipe::PREFETCH): thread -> (line of the stage, part of the line)
+    constexpr int PF_TPL = 256 / (BM * KSL) > 0 ? 256 / (BM * KSL) : 1;          // threads per 128-byte line
+    const int pf_row = (tid / PF_TPL) % BM, pf_col = ((tid / PF_TPL) / BM) * BK + (tid % PF_TPL) * (32 / PF_TPL);
+    const int pf_dist = Pipe::PREFETCH ? (p.prefetch < 0 ? 6 : p.prefetch) : 0;
+    float pf_sink = 0.f;                     // destination of every prefetch touch: lives in one register for the whole kernel
 
     int buf = 0;
     while (true) {
@@ -84,9 +96,26 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int n_tile
             const bool last = kt == KT - 1;
             const bool more = !last || next_tile;
             if (more) {
-                const int lm0 = last ? nm0 : m0, ln0 = last ? nn0 : n0, lk = last ? 0 : (kt + 1) * BK * KSL;
+                const int lm0 = last ? nm0 : m0, ln0 = last ? nn0 : n0, lk = last ? kslice(nm0, 0) : kslice(m0, kt + 1);
 #pragma unroll
                 for (int ks = 0; ks < KSL; ++ks) Pipe::load(ctx, p, lm0, ln0, lk + ks * BK, regs[ks], tid, nxt + ks * SLICE);
+            }
+            bool touched = false;
+            if (Pipe::PREFETCH && pf_dist > 0) {
+                // slice kt + 1 + pf_dist of this block's (tile, k) sequence; it may belong to the next tile
+                const int j = kt + 1 + pf_dist;
+                const bool same = j < KT;
+                if (same || next_tile) {
+                    int jj = same ? j : j - KT;
+                    jj = jj < KT ? jj : KT - 1;
+                    int row = (same ? m0 : nm0) + pf_row;
+                    row = row < p.M ? row : p.M - 1;
+                    const float* src = p.A + (size_t)row * p.lda + kslice(same ? m0 : nm0, jj) + pf_col;
+                    // hidden from hipcc's wait counting on purpose (it would drain it at the next barrier); the register is
+                    // tied ("+v") so nothing else is ever allocated to it while a touch is in flight
+                    asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(src) : "memory");
+                    touched = true;
+                }
             }
             if (ADD != 0 && kt == 0) {
                 // additive epilogue operands (residual / gathered rows) are loaded straight into
@@ -110,7 +139,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int n_tile
                             int ml = (wm * TM + tm) * 32 + crow32(r, hi);   // row inside the tile
                             if (m0 + ml >= p.M) ml = p.M - 1 - m0;
                             float x = 0.f;
-                            if (ADD & 1) x = p.resid_scale * rbase[(unsigned)(ml * ldr + nl)];
+                            if (ADD & 1) {
+                                const float rv = rbase[(unsigned)(ml * ldr + nl)];
+                                x = p.resid_scale * (p.r_split ? unpack_split(rv) : rv);
+                            }
                             if (ADD & 2) x += p.g0[(unsigned)(p.gi0[m0 + ml] * ldg0 + n0 + nl)];
                             if (ADD & 4) x += p.g1[(unsigned)(p.gi1[m0 + ml] * ldg1 + n0 + nl)];
                             acc[tm][tn][r] = x;
@@ -118,12 +150,19 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int n_tile
                 }
             }
 #pragma unroll
-            for (int ks = 0; ks < KSL; ++ks) Pipe::mma(cur + ks * SLICE, wm, wn, acc, lane);
-            if (more) {
+            for (int ks = 0; ks < KSL; ++ks) Pipe::mma(cur + ks * SLICE, wm, wn, acc, lane, p.relu_a);
+            if constexpr (Pipe::PREFETCH) {
+                // counted wait + raw barrier: __syncthreads() would make hipcc drain every outstanding load, the touch included
+                if (touched) Pipe::store_keep1();
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            } else {
+                if (more) {
 #pragma unroll
-                for (int ks = 0; ks < KSL; ++ks) Pipe::store(nxt + ks * SLICE, regs[ks], tid, p.relu_a);
+                    for (int ks = 0; ks < KSL; ++ks) Pipe::store(nxt + ks * SLICE, regs[ks], tid, p.relu_a);
+                }
+                __syncthreads();
             }
-            __syncthreads();
             if (last) {
                 // ---- epilogue: lane holds column n, 16 rows per 32x32 tile ----
                 int ldc = p.ldc, lv = lane;
@@ -171,6 +210,22 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int n_tile
 #pragma unroll
                             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 1.f / (1.f + __expf(-acc[tm][tn][r]));
                 }
+                if (p.c_scale != 1.f) {
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[tm][tn][r] *= p.c_scale;
+                }
+                if (p.c_split) {                                  // bf16 modes: the consumer reads hi/lo bf16 pairs
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = pack_split(acc[tm][tn][r]);
+                }
                 if (m0 + BM <= p.M && n0 + BN <= p.N) {          // interior tile: unguarded stores
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn)
@@ -211,6 +266,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int n_tile
         m0 = nm0;
         n0 = nn0;
     }
+    if (Pipe::PREFETCH) {                    // no touch may outlive its register
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("" ::"v"(pf_sink));
+    }
 }
 
 double gemm_flops(const GemmArgs& a) { return 2.0 * a.M * (double)a.N * a.K; }
@@ -238,11 +297,17 @@ static int launch_t(const GemmArgs& a, int n_tiles, int grid, hipStream_t s) {
     // exact fp32 launches without ReLU-on-A take the LDS-direct staging pipe (internal precision code 4) when
     // the operands are addressable with 32-bit byte offsets and the additive mode is one the forward uses
     int prec = a.prec;
-    if (prec == 0 && !a.no_dma && !a.relu_a && (add == 0 || add == 1 || add == 6) &&
-        ((size_t)a.M + 256) * a.lda * 4 < (1ull << 32) && ((size_t)a.N + 256) * a.ldw * 4 < (1ull << 32))
-        prec = 4;
+    const bool dma_ok = !a.no_dma && (add == 0 || add == 1 || add == 6) &&
+                        ((size_t)a.M + 256) * a.lda * 4 < (1ull << 32) && ((size_t)a.N + 256) * a.ldw * 4 < (1ull << 32);
+    if (prec == 0 && dma_ok && !a.relu_a) prec = 4;
+    if ((prec == 1 || prec == 3) && dma_ok) prec += a.a_split ? 8 : 4;      // bf16 modes: A split on the fragment-read side, so ReLU-on-A is fine
+    else if (a.a_split) return fail(-1, "gemm: split-pair A needs a bf16 precision and the LDS-direct pipe");
     switch (prec * 8 + add) {
+        VLSAT_GEMM_CASE(0, 9) VLSAT_GEMM_CASE(1, 9) VLSAT_GEMM_CASE(6, 9)
+        VLSAT_GEMM_CASE(0, 11) VLSAT_GEMM_CASE(1, 11) VLSAT_GEMM_CASE(6, 11)
         VLSAT_GEMM_CASE(0, 4) VLSAT_GEMM_CASE(1, 4) VLSAT_GEMM_CASE(6, 4)
+        VLSAT_GEMM_CASE(0, 5) VLSAT_GEMM_CASE(1, 5) VLSAT_GEMM_CASE(6, 5)
+        VLSAT_GEMM_CASE(0, 7) VLSAT_GEMM_CASE(1, 7) VLSAT_GEMM_CASE(6, 7)
         VLSAT_GEMM_CASE(0, 0) VLSAT_GEMM_CASE(1, 0) VLSAT_GEMM_CASE(2, 0) VLSAT_GEMM_CASE(3, 0)
         VLSAT_GEMM_CASE(4, 0) VLSAT_GEMM_CASE(5, 0) VLSAT_GEMM_CASE(6, 0) VLSAT_GEMM_CASE(7, 0)
         VLSAT_GEMM_CASE(0, 1) VLSAT_GEMM_CASE(1, 1) VLSAT_GEMM_CASE(6, 1)
@@ -307,6 +372,25 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
         return fail(-1, "gemm: A/W must be 16-byte aligned");
     const int G = slots();
     auto blocks = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
+    // bf16 modes, large M: the full rounds go to the 3-stage ring kernel (gemm_bf16_ring.hip: one 8-wave block per CU,
+    // 256 x 128 tiles, two slices in flight), the remaining row panels to the kernels below
+    if ((a.prec == 1 || a.prec == 3) && !a.no_dma && !a.no_ring && a.N > 64 && !a.rowscale &&
+        ((size_t)a.M + 256) * a.lda * 4 < (1ull << 32) && ((size_t)a.N + 256) * a.ldw * 4 < (1ull << 32)) {
+        const int G1 = G / 2;
+        const long nbm = (a.M + 255) / 256, nbn = (a.N + 127) / 128;
+        const long rounds = nbm * nbn / G1;
+        const long main_panels = rounds * G1 / nbn;
+        if (main_panels > 0) {
+            GemmArgs m = a;
+            m.M = (int)std::min<long>(main_panels * 256, a.M);
+            const int r = launch_gemm_ring(m, (int)(main_panels * nbn), G1, s);
+            if (r < 0) return r;
+            if (r == 0) {
+                if (m.M == a.M) return 0;
+                return launch_gemm(tail_of(a, m.M), s);
+            }
+        }
+    }
     // Largest tile that still gives every resident slot a tile; small problems (and the tails
     // of big ones) take smaller tiles so the launch covers as many CUs as the problem allows.
     if (a.N > 64 && blocks(128, 128) >= G) return run_tiled<128, 128>(a, s);

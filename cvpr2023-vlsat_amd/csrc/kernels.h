@@ -26,10 +26,19 @@ struct GemmArgs {
     const uint16_t* Whi = nullptr;
     const uint16_t* Wlo = nullptr;
     long long* clock_probe = nullptr;           // optional [grid][4] DVFS probe buffer (vlsat_debug_gemm_clock_probe)
+    // split-pair format of the bf16 modes (common.h pack_split): which operands carry it
+    int a_split = 0, r_split = 0, c_split = 0;
+    float c_scale = 1.f;                        // final multiplier of C (after bias / activation)
+    int no_ring = 0;                            // debug: keep large bf16 launches on the two-stage 128 x 128 kernel
+    int k_rotate = 0;                           // (experiment, no gain measured) start each row panel's k loop at a different slice (L2 channel spreading)
+    int prefetch = -1;                          // bf16 LDS-direct pipe: slices of look-ahead of the A-panel prefetch (0 off, -1 default)
     int no_dma = 0;                             // debug: VGPR-staged fp32 operands instead of LDS-direct (vlsat_debug_option "gemm_dma")
     long* launches = nullptr;                   // optional host counter, +1 per kernel launched (profiling)
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
+// bf16 modes, full rounds of large-M launches: 3-stage LDS ring, 256 x 128 tiles, one 8-wave block per CU
+// (gemm_bf16_ring.hip); returns 1 if the operand combination is not built
+int launch_gemm_ring(const GemmArgs& a, int n_tiles, int grid, hipStream_t s);
 double gemm_flops(const GemmArgs& a);
 void gemm_set_clock_probe(long long* buf);
 
@@ -52,6 +61,13 @@ struct FlashSplit {
 };
 int launch_flash_attn(const float* Q, int ldq, const float* K, const float* V, int ldkv, float* O, int ldo,
                       const int4* tiles, int n_tiles, float scale_log2e, hipStream_t s, const FlashSplit* split = nullptr);
+int launch_flash_merge(float* O, int ldo, const FlashSplit& sp, hipStream_t s, int out_split);
+// the same attention on the bf16 matrix cores (flash_attn_bf16.hip): terms = 3 split-bf16 (~1e-5) | 1 single-rounded;
+// use_tr = 0 selects the gather fallback for the V operand instead of ds_read_b64_tr_b16 (tests); io_split = 1: Q (already
+// scaled), K, V and O are in the split-pair format of the bf16 modes (common.h pack_split)
+int launch_flash_attn_bf16(const float* Q, int ldq, const float* K, const float* V, int ldkv, float* O, int ldo,
+                           const int4* tiles, int n_tiles, float scale_log2e, int terms, int use_tr, int io_split,
+                           hipStream_t s, const FlashSplit* split = nullptr);
 constexpr int FLASH_BQ = 128;   // queries per block
 
 // ---- node attention with distance bias (per scene, per head) ----
@@ -76,6 +92,9 @@ int launch_desc_tail(const float* desc, int n_nodes, float* x, int ldx, int col0
 // in-place LayerNorm over rows of `dim` (dim == 512), optional ReLU
 int launch_layernorm(float* x, int ld, int rows, int dim, const float* gamma, const float* beta, int relu,
                      hipStream_t s);
+// out of place; out_split = 1 writes the split-pair format of the bf16 modes (common.h pack_split)
+int launch_layernorm_to(const float* x, int ld, float* y, int ldy, int rows, int dim, const float* gamma, const float* beta,
+                        int relu, int out_split, hipStream_t s);
 // rowscale[m] = scale / ||x[m,:]||_2  (dim == 512)
 int launch_row_invnorm(const float* x, int ld, int rows, int dim, float scale, float* out, hipStream_t s);
 

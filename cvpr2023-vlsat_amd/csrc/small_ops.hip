@@ -81,13 +81,13 @@ int launch_desc_tail(const float* desc, int n_nodes, float* x, int ldx, int col0
 // In-place LayerNorm over rows of 512 (eps 1e-5, biased variance = torch.nn.LayerNorm), optional
 // ReLU.  One wave per row, 8 values per lane as two float4 (columns 4*lane and 256 + 4*lane).
 // reference transformer/attention.py:122 (post-LN residual) and network_MMG.py:236-248 (ReLU).
-__global__ __launch_bounds__(256) void layernorm512_kernel(float* __restrict__ x, int ld, int rows,
-                                                           const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, int relu) {
+__global__ __launch_bounds__(256) void layernorm512_kernel(const float* __restrict__ x, int ld, float* __restrict__ y, int ldy,
+                                                           int rows, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, int relu, int out_split) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    float* p = x + (size_t)row * ld;
+    const float* p = x + (size_t)row * ld;
     f32x4 a = *reinterpret_cast<const f32x4*>(p + 4 * lane);
     f32x4 b = *reinterpret_cast<const f32x4*>(p + 256 + 4 * lane);
     float s = a[0] + a[1] + a[2] + a[3] + b[0] + b[1] + b[2] + b[3];
@@ -108,15 +108,21 @@ __global__ __launch_bounds__(256) void layernorm512_kernel(float* __restrict__ x
         a[c] = a[c] * rstd * ga[c] + ba[c];
         b[c] = b[c] * rstd * gb[c] + bb[c];
         if (relu) { a[c] = fmaxf(a[c], 0.f); b[c] = fmaxf(b[c], 0.f); }
+        if (out_split) { a[c] = pack_split(a[c]); b[c] = pack_split(b[c]); }     // bf16 modes: the consumers are GEMM A operands
     }
-    *reinterpret_cast<f32x4*>(p + 4 * lane) = a;
-    *reinterpret_cast<f32x4*>(p + 256 + 4 * lane) = b;
+    float* q = y + (size_t)row * ldy;
+    *reinterpret_cast<f32x4*>(q + 4 * lane) = a;
+    *reinterpret_cast<f32x4*>(q + 256 + 4 * lane) = b;
 }
 int launch_layernorm(float* x, int ld, int rows, int dim, const float* gamma, const float* beta, int relu,
                      hipStream_t s) {
+    return launch_layernorm_to(x, ld, x, ld, rows, dim, gamma, beta, relu, 0, s);
+}
+int launch_layernorm_to(const float* x, int ld, float* y, int ldy, int rows, int dim, const float* gamma, const float* beta,
+                        int relu, int out_split, hipStream_t s) {
     if (rows <= 0) return 0;
-    if (dim != 512 || (ld & 3)) return fail(-1, "layernorm: dim must be 512 and ld a multiple of 4");
-    hipLaunchKernelGGL(layernorm512_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, ld, rows, gamma, beta, relu);
+    if (dim != 512 || (ld & 3) || (ldy & 3)) return fail(-1, "layernorm: dim must be 512 and ld a multiple of 4");
+    hipLaunchKernelGGL(layernorm512_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, ld, y, ldy, rows, gamma, beta, relu, out_split);
     VLSAT_LAUNCH_CHECK("layernorm512");
     return 0;
 }

@@ -52,8 +52,14 @@ _SIGNATURES = {
     "vlsat_profile_read": (C.c_int, [_vp, _i32, C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(C.c_double)]),
     "vlsat_k_gemm": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _f32,
                                _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "vlsat_k_split_bf16": (C.c_int, [_vp, _sz, _vp, _vp, _vp]),
+    "vlsat_k_gemm_planes": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _f32,
+                                      _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "vlsat_k_gemm_bf16": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _f32,
+                                    _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vlsat_k_pointnet": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
     "vlsat_k_flash_attn": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _f32, _vp]),
+    "vlsat_k_flash_attn_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _f32, _i32, _i32, _vp]),
     "vlsat_k_layernorm": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
     "vlsat_prepare_objects": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "vlsat_fc_edges": (C.c_int, [_vp, _vp, _i32, _i64, _i64, _vp, _vp, _vp]),

@@ -162,6 +162,30 @@ int vlsat_k_gemm(const float* A, int32_t lda, const float* W, int32_t ldw, float
                  const float* g1, const int32_t* gi1, int32_t ldg1,
                  int32_t relu_a, int32_t act, void* stream);
 
+/* Weight planes of the bf16 modes: w[i] ~= bf16 hi[i] + bf16 lo[i] (asynchronous on `stream`). */
+int vlsat_k_split_bf16(const float* w, size_t n, uint16_t* hi, uint16_t* lo, void* stream);
+
+/* vlsat_k_gemm on the bf16 matrix cores (BASELINE configs[2]) with caller-provided planes of W (dense [N,K], ldw = K):
+ * prec 1 = single-rounded bf16 operands, 3 = split-bf16 (three MFMAs per product).  A stays fp32 and is split inside
+ * the kernel.  no_dma = 1: the VGPR-staged operand pipe of round 1 instead of the LDS-direct one; prefetch: slices of
+ * look-ahead of the A-panel prefetch (0 = off, -1 = default).  fmt: bit 0 = A, bit 1 = resid, bit 2 = C are in the
+ * split-pair format of the bf16 modes (one 32-bit word per element: bf16 hi = rne(x) in the upper half, bf16 lo =
+ * rne(x - hi) in the lower half); c_scale multiplies C last.  Asynchronous. */
+int vlsat_k_gemm_planes(const float* A, int32_t lda, const float* W, const uint16_t* Whi, const uint16_t* Wlo, int32_t ldw,
+                        float* C, int32_t ldc, int32_t M, int32_t N, int32_t K, const float* bias,
+                        const float* resid, int32_t ldr, float resid_scale,
+                        const float* g0, const int32_t* gi0, int32_t ldg0,
+                        const float* g1, const int32_t* gi1, int32_t ldg1,
+                        int32_t relu_a, int32_t act, int32_t prec, int32_t no_dma, int32_t prefetch, int32_t fmt,
+                        float c_scale, void* stream);
+/* Test entry point: the same with the planes made on the spot from W (allocates, synchronises). */
+int vlsat_k_gemm_bf16(const float* A, int32_t lda, const float* W, int32_t ldw, float* C, int32_t ldc,
+                      int32_t M, int32_t N, int32_t K, const float* bias,
+                      const float* resid, int32_t ldr, float resid_scale,
+                      const float* g0, const int32_t* gi0, int32_t ldg0,
+                      const float* g1, const int32_t* gi1, int32_t ldg1,
+                      int32_t relu_a, int32_t act, int32_t prec, int32_t no_dma, void* stream);
+
 /* PointNetfeat.forward (obj_encoder), reference network_PointNet.py:141-164:
  * pts [N,3,P] -> out [N,768] = max_p relu(W3 relu(W2 relu(W1 x + b1) + b2) + b3).
  * Weights in the reference layout (W1 [64,3], W2 [128,64], W3 [768,128]). */
@@ -176,6 +200,13 @@ int vlsat_k_pointnet(const float* pts, int32_t n_obj, int32_t n_points,
 int vlsat_k_flash_attn(const float* Q, const float* K, const float* V, float* O,
                        int32_t ld, const int64_t* tok_ptr_host, int32_t n_scenes, int32_t n_heads,
                        float scale, void* stream);
+
+/* The same attention on the bf16 matrix cores (BASELINE configs[2]): terms = 3 split-bf16 (three MFMAs per product,
+ * ~1e-5) or 1 (single-rounded operands); use_tr = 1 reads the V operand with the LDS transpose read, 0 gathers it,
+ * 2 = transpose read with Q (pre-multiplied by scale*log2 e), K, V and O in the split-pair format. */
+int vlsat_k_flash_attn_bf16(const float* Q, const float* K, const float* V, float* O,
+                            int32_t ld, const int64_t* tok_ptr_host, int32_t n_scenes, int32_t n_heads,
+                            float scale, int32_t terms, int32_t use_tr, void* stream);
 
 /* LayerNorm over rows of 512 in place, optional ReLU (reference attention.py:122 + MMG :236-248). */
 int vlsat_k_layernorm(float* x, int32_t ld, int32_t rows, int32_t dim, const float* gamma,
@@ -236,7 +267,10 @@ int vlsat_debug_gemm_clock_probe(int64_t* buf);
 /* Experiment switches of one handle; defaults are the measured-best settings and none changes results beyond
  * fp32 summation order.  "dual_stream" 0|1: 2D twin stages of small plans on a second stream; "flash_split" 0|1:
  * split-key edge attention for plans that cannot fill the chip (both: plans created afterwards); "gemm_dma" 0|1:
- * LDS-direct staging of fp32 GEMM operands; "gate_grid" n: persistent grid of the gate kernel (0 = default). */
+ * LDS-direct staging of fp32 GEMM operands; "gate_grid" n: persistent grid of the gate kernel (0 = default);
+ * "split_fmt" 0|1: in the bf16 modes, edge tensors between matrix kernels as bf16 hi/lo pairs (0: fp32, split on read);
+ * "flash_bf16" 0|1: in the bf16 modes, edge attention on the bf16 matrix cores; "flash_tr" 0|1: its V operand by
+ * ds_read_b64_tr_b16 (0: ds_read_u16 gather). */
 int vlsat_debug_option(vlsat_handle h, const char* name, int32_t value);
 
 #ifdef __cplusplus

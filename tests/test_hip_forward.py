@@ -444,5 +444,14 @@ def test_cfg3_full_batch_all_scenes(bench_batch_oracle, mode, tol):
         errs = {n: float((g - r).abs().max()) for n, g, r in zip(NAMES, got, ref)}
         print(f"{mode}: 64/64 scenes, worst scene {int(per.argmax())} at {float(per.max()):.2e}, per output {errs}")
         assert float(per.max()) < tol, f"{mode}: scenes over {tol}: {torch.nonzero(per >= tol).view(-1).tolist()}"
+        # the same with every experiment switch of the bf16 modes turned off one at a time (fp32 tensors between the
+        # kernels, fp32 attention, gather instead of the LDS transpose read): same contract
+        for opt in ("split_fmt", "flash_tr", "flash_bf16"):
+            m.debug_option(opt, 0)
+            alt = [o.cpu() for o in m(d["obj_points"], d["obj_2d_feats"], d["edge_indices"], d["descriptor"], d["batch_ids"])]
+            pa = _per_scene_err(alt, ref, S, N, E)
+            print(f"{mode} with {opt}=0: worst scene at {float(pa.max()):.2e}")
+            assert float(pa.max()) < tol, (mode, opt)
+            m.debug_option(opt, 1)
     finally:
         m.close()

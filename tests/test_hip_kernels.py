@@ -281,3 +281,216 @@ def test_layernorm(lib):
         _sync()
         assert float((x[:, :512].cpu() - ref.float()).abs().max()) < 2e-5
         assert torch.equal(x[:, 512:], tail), "layernorm wrote outside its 512 columns"
+
+
+# ---- bf16 matrix-core kernels of BASELINE configs[2] -----------------------------------------------------------------
+def _gemm_bf16(L, A, W, prec, no_dma=0, bias=None, resid=None, resid_scale=1.0, g0=None, gi0=None, g1=None, gi1=None,
+               relu_a=0, act=0, ldc=None):
+    l = L.load()
+    M, K = A.shape
+    N = W.shape[0]
+    ldc = ldc or N
+    Cbuf = torch.full((M, ldc), float("nan"), device=DEV)
+    L.check(l.vlsat_k_gemm_bf16(A.data_ptr(), A.stride(0), W.data_ptr(), W.stride(0), Cbuf.data_ptr(), ldc, M, N, K,
+                                L.ptr(bias), L.ptr(resid), 0 if resid is None else resid.stride(0), resid_scale,
+                                L.ptr(g0), L.ptr(gi0), 0 if g0 is None else g0.stride(0),
+                                L.ptr(g1), L.ptr(gi1), 0 if g1 is None else g1.stride(0), relu_a, act, prec, no_dma,
+                                L.stream_ptr()))
+    _sync()
+    return Cbuf[:, :N].cpu()
+
+
+@pytest.mark.parametrize("M,N,K,lda", [(1, 512, 512, 512), (56, 26, 256, 256), (1560, 1024, 512, 512), (2560, 3328, 512, 768),
+                                       (4097, 130, 64, 200), (9000, 512, 1024, 1024), (70000, 64, 128, 128)])
+def test_gemm_split_bf16_lds_direct_pipe(lib, M, N, K, lda):
+    """Split-bf16 GEMM (three bf16 MFMAs per product) with LDS-direct operand staging (PipeSplitDma): against fp64 at
+    ~2^-16 relative accuracy, and BIT-IDENTICAL to the VGPR-staged pipe of round 1 (same hi/lo split, same MFMA
+    order) -- ragged M/N, strided A, ReLU-on-A (applied at the fragment read), all additive modes the forward uses."""
+    g = torch.Generator().manual_seed(M + 3 * N)
+    A = torch.randn(M, lda, generator=g).to(DEV)[:, :K]
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    resid = torch.randn(M, N, generator=g).to(DEV)
+    NG = 61
+    gbuf = torch.randn(NG, 2 * N, generator=g).to(DEV)
+    gi0 = torch.randint(0, NG, (M,), generator=g, dtype=torch.int32).to(DEV)
+    gi1 = torch.randint(0, NG, (M,), generator=g, dtype=torch.int32).to(DEV)
+    cases = [dict(bias=b), dict(bias=b, relu_a=1, act=1), dict(bias=b, resid=resid, resid_scale=0.5),
+             dict(g0=gbuf[:, :N], gi0=gi0, g1=gbuf[:, N:], gi1=gi1, relu_a=1, act=1)]
+    for kw in cases:
+        ref = _ref_gemm(A, W, **kw)
+        dma = _gemm_bf16(lib, A, W, 3, 0, **kw)
+        old = _gemm_bf16(lib, A, W, 3, 1, **kw)
+        err = float((dma - ref).abs().max())
+        assert err < 1e-4 * math.sqrt(K / 64) + 2e-5, f"bf16x3 {M}x{N}x{K} {sorted(kw)}: {err:.3e}"
+        assert torch.equal(dma, old), f"LDS-direct vs VGPR-staged differ: {float((dma - old).abs().max()):.3e} {sorted(kw)}"
+        one = _gemm_bf16(lib, A, W, 1, 0, **kw)
+        one_old = _gemm_bf16(lib, A, W, 1, 1, **kw)
+        err1 = float((one - ref).abs().max())
+        assert err1 < 2e-2 * math.sqrt(K / 64) + 2e-2, f"bf16 {M}x{N}x{K}: {err1:.3e}"
+        assert torch.equal(one, one_old)
+
+
+def test_gemm_split_bf16_transpose_detecting(lib):
+    """A = I (exactly representable) with an asymmetric bf16-exact W: any k-slot / row / column mix-up shows."""
+    K = 64
+    A = torch.eye(K).to(DEV)
+    W = (torch.arange(96 * K, dtype=torch.float32).view(96, K) % 251 - 125).to(DEV)       # |w| <= 125: exact in bf16
+    for prec in (1, 3):
+        got = _gemm_bf16(lib, A, W, prec)
+        assert torch.equal(got, W.cpu().t().contiguous()), prec
+
+
+def _flash_bf16(L, q, k, v, tok_ptr, scale, terms, use_tr):
+    l = L.load()
+    o = torch.full_like(q, float("nan"))
+    tp = torch.tensor(tok_ptr, dtype=torch.int64)
+    L.check(l.vlsat_k_flash_attn_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), q.stride(0), tp.data_ptr(),
+                                      len(tok_ptr) - 1, 8, scale, terms, use_tr, L.stream_ptr()))
+    _sync()
+    return o.cpu()
+
+
+@pytest.mark.parametrize("tok_ptr", [[0, 56], [0, 1560], [0, 20, 65, 66, 400], [0, 1], [0, 129, 129 + 32], [0, 64, 128, 257]])
+def test_flash_attn_bf16_vs_softmax(lib, tok_ptr):
+    """Split-bf16 attention (QK^T and PV on bf16 MFMAs, three per product) against the fp64 softmax attention; the
+    LDS-transpose-read path for V must agree BIT FOR BIT with the gather path (same numbers, other load instruction)."""
+    g = torch.Generator().manual_seed(sum(tok_ptr))
+    T = tok_ptr[-1]
+    q, k, v = (torch.randn(T, 512, generator=g).to(DEV) for _ in range(3))
+    v = v * 3 + torch.arange(512, device=DEV)[None, :] * 0.01          # column-asymmetric values: transposes show
+    ref = _ref_attn(q, k, v, tok_ptr, 0.125)
+    tr = _flash_bf16(lib, q, k, v, tok_ptr, 0.125, 3, 1)
+    ga = _flash_bf16(lib, q, k, v, tok_ptr, 0.125, 3, 0)
+    assert torch.isfinite(ga).all() and torch.isfinite(tr).all()
+    err = float((ga - ref).abs().max())
+    assert err < 2e-4, f"bf16x3 attention (gather): {err:.3e}"
+    assert torch.equal(tr, ga), f"transpose-read path differs from the gather path by {float((tr - ga).abs().max()):.3e}"
+    one = _flash_bf16(lib, q, k, v, tok_ptr, 0.125, 1, 1)
+    err1 = float((one - ref).abs().max())
+    assert err1 < 8e-2, f"bf16 attention: {err1:.3e}"
+    assert torch.equal(one, _flash_bf16(lib, q, k, v, tok_ptr, 0.125, 1, 0))
+
+
+def test_flash_attn_bf16_forced_rescale(lib):
+    """A key whose score dwarfs the others late in the sequence forces the running-maximum rescale (guide rule 26)."""
+    g = torch.Generator().manual_seed(5)
+    T = 700
+    q, k, v = (torch.randn(T, 512, generator=g) for _ in range(3))
+    k[613] = q[17] * 3.0
+    k[64 * 5 + 1] = q[300] * 2.0
+    q, k, v = q.to(DEV), k.to(DEV), v.to(DEV)
+    ref = _ref_attn(q, k, v, [0, T], 0.125)
+    got = _flash_bf16(lib, q, k, v, [0, T], 0.125, 3, 1)
+    err = float((got - ref).abs().max())
+    assert err < 2e-4, f"{err:.3e}"
+
+
+def _pack_split(x):
+    """Host restatement of common.h pack_split: (bf16 rne(x) << 16) | bf16 rne(x - hi), as float32 bit patterns."""
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    w = (hi.view(torch.int16).to(torch.int32) << 16) | (lo.view(torch.int16).to(torch.int32) & 0xFFFF)
+    return w.view(torch.float32)
+
+
+def _unpack_split(w):
+    u = w.view(torch.int32)
+    return (u & -65536).view(torch.float32) + (u << 16).view(torch.float32)
+
+
+def test_split_pair_format_gemm(lib):
+    """The split-pair tensor format of the bf16 modes: A read as packed hi/lo words (ReLU on the packed word), residual
+    decoded, C packed and scaled -- all against the plain-fp32 operand path of the same kernel on the same values."""
+    l = lib.load()
+    g = torch.Generator().manual_seed(77)
+    M, N, K = 3000, 512, 256
+    A = torch.randn(M, K, generator=g)
+    A = _unpack_split(_pack_split(A))                       # values exactly representable as hi + lo
+    R = _unpack_split(_pack_split(torch.randn(M, N, generator=g)))
+    W = (torch.randn(N, K, generator=g) / 16).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    hi = torch.empty(N * K + 128, dtype=torch.int16, device=DEV)
+    lo = torch.empty_like(hi)
+    lib.check(l.vlsat_k_split_bf16(W.data_ptr(), N * K, hi.data_ptr(), lo.data_ptr(), lib.stream_ptr()))
+    Ad, Rd, As, Rs = A.to(DEV), R.to(DEV), _pack_split(A).to(DEV), _pack_split(R).to(DEV)
+
+    def run(a, r, fmt, prec, relu_a, scale=1.0):
+        Cb = torch.full((M, N), float("nan"), device=DEV)
+        lib.check(l.vlsat_k_gemm_planes(a.data_ptr(), K, W.data_ptr(), hi.data_ptr(), lo.data_ptr(), K, Cb.data_ptr(), N, M, N, K,
+                                        b.data_ptr(), r.data_ptr(), N, 0.5, 0, 0, 0, 0, 0, 0, relu_a, 1, prec, 0, -1, fmt, scale,
+                                        lib.stream_ptr()))
+        _sync()
+        return Cb.cpu()
+    for prec in (3, 1):
+        for relu_a in (0, 1):
+            plain = run(Ad, Rd, 0, prec, relu_a)
+            packed_in = run(As, Rs, 3, prec, relu_a)
+            # (not bit-identical: where x - hi is an exact tie the in-kernel split of the fp32 operand picks another hi/lo
+            #  pair with the same sum, which changes the fp32 summation order)
+            d = float((plain - packed_in).abs().max())
+            assert d < 2e-5, f"prec {prec} relu {relu_a}: packed operands differ from plain ones by {d:.3e}"
+            packed_out = run(As, Rs, 7, prec, relu_a, 0.25)
+            d = float((_unpack_split(packed_out) - plain * 0.25).abs().max())
+            assert d < 2e-5, f"prec {prec} relu {relu_a}: packed + scaled output off by {d:.3e}"
+
+
+def test_flash_attn_bf16_split_pair_io(lib):
+    """Attention with Q (pre-scaled), K, V, O in the split-pair format == the fp32-I/O kernel on the same values."""
+    g = torch.Generator().manual_seed(9)
+    tok = [0, 70, 70 + 333]
+    T = tok[-1]
+    sc = 0.125 * 1.4426950408889634
+    q, k, v = (_unpack_split(_pack_split(torch.randn(T, 512, generator=g))) for _ in range(3))
+    qs = _unpack_split(_pack_split(q * sc))                 # what the Q projection's epilogue hands over
+    ref = _ref_attn(qs / sc, k, v, tok, 0.125)
+    for terms, tol in ((3, 3e-4), (1, 8e-2)):
+        plain = _flash_bf16(lib, (qs / sc).to(DEV), k.to(DEV), v.to(DEV), tok, 0.125, terms, 1)
+        packed = _flash_bf16(lib, _pack_split(qs).to(DEV), _pack_split(k).to(DEV), _pack_split(v).to(DEV), tok, 0.125, terms, 2)
+        got = _unpack_split(packed)
+        assert float((got - ref).abs().max()) < tol, (terms, float((got - ref).abs().max()))
+        assert float((got - plain).abs().max()) < (2e-5 if terms == 3 else 2e-2)
+
+
+@pytest.mark.parametrize("M,N,K,fmt", [(70000, 512, 512, 0), (66000, 1024, 512, 0), (99840, 512, 1024, 1), (70001, 200, 128, 0)])
+def test_gemm_bf16_ring_kernel(lib, M, N, K, fmt):
+    """Large-M bf16 launches: the full rounds run on the 3-stage ring kernel (256 x 128 tiles, two slices in flight), the
+    rest on the 128 x 128 kernel.  Same k order and MFMA order, so the result must be BIT-IDENTICAL to the launch that
+    keeps everything on the 128 x 128 kernel (fmt bit 4) -- residual, gathered rows, ReLU-on-A, ragged N included."""
+    l = lib.load()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g)
+    if fmt & 1:
+        A = _pack_split(A)
+    A = A.to(DEV)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    R = torch.randn(M, N, generator=g).to(DEV)
+    NG = 999
+    gbuf = torch.randn(NG, 2 * N, generator=g).to(DEV)
+    gi0 = torch.randint(0, NG, (M,), generator=g, dtype=torch.int32).to(DEV)
+    gi1 = torch.randint(0, NG, (M,), generator=g, dtype=torch.int32).to(DEV)
+    hi = torch.empty(N * K + 128, dtype=torch.int16, device=DEV)
+    lo = torch.empty_like(hi)
+    lib.check(l.vlsat_k_split_bf16(W.data_ptr(), N * K, hi.data_ptr(), lo.data_ptr(), lib.stream_ptr()))
+
+    def run(prec, f, resid, gather, relu_a):
+        Cb = torch.full((M, N), float("nan"), device=DEV)
+        lib.check(l.vlsat_k_gemm_planes(A.data_ptr(), K, W.data_ptr(), hi.data_ptr(), lo.data_ptr(), K, Cb.data_ptr(), N, M, N, K,
+                                        b.data_ptr(), R.data_ptr() if resid else 0, N if resid else 0, 0.5,
+                                        gbuf.data_ptr() if gather else 0, gi0.data_ptr() if gather else 0, 2 * N if gather else 0,
+                                        gbuf.data_ptr() + 4 * N if gather else 0, gi1.data_ptr() if gather else 0, 2 * N if gather else 0,
+                                        relu_a, 1, prec, 0, -1, f, 1.0, lib.stream_ptr()))
+        _sync()
+        return Cb.cpu()
+    Af = (_unpack_split(A.cpu()) if fmt & 1 else A.cpu())
+    for prec in (3, 1):
+        for resid, gather, relu_a in ((0, 0, 0), (1, 0, 1), (0, 1, 0)):
+            ring = run(prec, fmt, resid, gather, relu_a)
+            flat = run(prec, fmt | 16, resid, gather, relu_a)
+            assert torch.isfinite(ring).all()
+            assert torch.equal(ring, flat), f"prec {prec} resid {resid} gather {gather}: ring vs 128x128 differ by {float((ring - flat).abs().max()):.3e}"
+        kw = dict(bias=b, act=1)
+        ref = _ref_gemm(Af.to(DEV), W, **kw)
+        err = float((run(prec, fmt, 0, 0, 0) - ref).abs().max())
+        assert err < (1e-4 if prec == 3 else 3e-2) * math.sqrt(K / 64) + 2e-5, f"prec {prec}: {err:.3e}"

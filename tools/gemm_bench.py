@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Micro-benchmark of the fp32 MFMA GEMM through the C ABI on the shapes the cfg-2 forward launches.
-    python tools/gemm_bench.py [--iters 20] [--only NAME]
-Prints one line per shape: time, TFLOP/s, fraction of the 157.3 TF fp32 MFMA peak."""
+"""Micro-benchmark of the MFMA GEMM through the C ABI on the shapes the cfg-2 forward launches.
+    python tools/gemm_bench.py [--iters 20] [--only NAME] [--prec 0|1|3] [--no-dma] [--prefetch D[,D...]] [--rows M]
+Prints one line per shape: time, TFLOP/s, fraction of the mode's MFMA peak (fp32 157.3 TF; bf16 2500 TF; bf16x3 833 TF)."""
 import argparse
 import os
 import sys
@@ -35,13 +35,21 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default="")
+    ap.add_argument("--prec", type=int, default=0, choices=[0, 1, 3])
+    ap.add_argument("--no-dma", action="store_true", help="bf16 modes: the VGPR-staged operand pipe of round 1")
+    ap.add_argument("--prefetch", default="-1", help="bf16 LDS-direct pipe: A-prefetch look-ahead(s) in slices, comma separated")
+    ap.add_argument("--fmt", type=int, default=0, help="bit 0: A, bit 1: resid, bit 2: C in the split-pair format (timing only)")
+    ap.add_argument("--rows", type=int, default=0, help="override M of the edge-row shapes (e.g. 8192: operands stay in L2)")
     a = ap.parse_args()
+    peak = {0: 157.3, 1: 2500.0, 3: 2500.0 / 3}[a.prec]
     lib = L.load()
     dev = "cuda:0"
     g = torch.Generator().manual_seed(0)
     for name, M, Nn, K, resid, gather in SHAPES:
         if a.only and a.only not in name:
             continue
+        if a.rows and M == E:
+            M = a.rows
         A = torch.randn(M, K, generator=g).to(dev)
         W = (torch.randn(Nn, K, generator=g) * 0.05).to(dev)
         Cb = torch.empty(M, Nn, device=dev)
@@ -50,24 +58,38 @@ def main():
         G0 = torch.randn(N, 2 * Nn, device=dev) if gather else None
         gi = torch.randint(0, N, (M,), dtype=torch.int32, device=dev) if gather else None
 
+        hi = torch.empty(Nn * K + 128, dtype=torch.int16, device=dev)
+        lo = torch.empty_like(hi)
+        if a.prec:
+            L.check(lib.vlsat_k_split_bf16(W.data_ptr(), Nn * K, hi.data_ptr(), lo.data_ptr(), L.stream_ptr()))
+
+        def run_planes(pf):
+            L.check(lib.vlsat_k_gemm_planes(A.data_ptr(), K, W.data_ptr(), hi.data_ptr(), lo.data_ptr(), K, Cb.data_ptr(), Nn, M, Nn, K,
+                                            bias.data_ptr(), L.ptr(R), Nn if resid else 0, 1.0,
+                                            L.ptr(G0), L.ptr(gi), 2 * Nn if gather else 0,
+                                            (G0.data_ptr() + 4 * Nn) if gather else 0, L.ptr(gi), 2 * Nn if gather else 0,
+                                            0, 1, a.prec, int(a.no_dma), pf, a.fmt, 1.0, L.stream_ptr()))
+
         def run():
             L.check(lib.vlsat_k_gemm(A.data_ptr(), K, W.data_ptr(), K, Cb.data_ptr(), Nn, M, Nn, K, bias.data_ptr(), 0,
                                      L.ptr(R), Nn if resid else 0, 1.0,
                                      L.ptr(G0), L.ptr(gi), 2 * Nn if gather else 0,
                                      (G0.data_ptr() + 4 * Nn) if gather else 0, L.ptr(gi), 2 * Nn if gather else 0,
                                      0, 1, L.stream_ptr()))
-        for _ in range(3):
-            run()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(a.iters):
-            run()
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / a.iters
-        tf = 2.0 * M * Nn * K / (ms * 1e-3) / 1e12
-        print(f"{name:34s} {ms * 1e3:9.1f} us  {tf:7.1f} TF  {100 * tf / 157.3:5.1f} %", flush=True)
+        variants = [("", run)] if not a.prec else [(f" pf={d}", (lambda d=d: run_planes(int(d)))) for d in a.prefetch.split(",")]
+        for tag, fn in variants:
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.iters):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / a.iters
+            tf = 2.0 * M * Nn * K / (ms * 1e-3) / 1e12
+            print(f"{name + tag:42s} M={M:6d} {ms * 1e3:9.1f} us  {tf:7.1f} TF  {100 * tf / peak:5.1f} %", flush=True)
 
 
 if __name__ == "__main__":
