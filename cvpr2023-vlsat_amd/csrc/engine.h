@@ -83,6 +83,7 @@ struct vlsat_ctx {
     int debug_stop = -1;
     int gemm_no_dma = 0, gate_grid = 0;      // vlsat_debug_option
     int split_fmt = 1;                       // bf16 modes: edge tensors between matrix kernels in the split-pair format
+    int pointnet_bf16 = 1, gate_bf16 = 1;    // bf16 modes: object encoder / edge gate on the bf16 matrix cores
     int flash_bf16 = 1, flash_tr = 1;        // bf16 modes: attention on the bf16 matrix cores / V operand by LDS transpose read
     long gemm_launches = 0;  // kernels launched by launch_gemm for this handle (main + tail launches)
     int cur_N = -1;          // node count of the plan whose forward is being enqueued (row class of a GEMM launch)

@@ -40,6 +40,7 @@ int vlsat_set_edge_attention_scope(vlsat_handle h, int32_t scope) {
 //   "gate_grid"   n     persistent grid of the gate kernel (0: default)
 //   "split_fmt"   0|1   bf16 modes: edge tensors between matrix kernels as bf16 hi/lo pairs (0: plain fp32, split on read)
 //   "flash_bf16"  0|1   bf16 modes: edge attention on the bf16 matrix cores (0: keep the fp32 kernel)
+//   "pointnet_bf16", "gate_bf16" 0|1   bf16 modes: object encoder / edge gate on the bf16 matrix cores (0: fp32 kernels)
 //   "flash_tr"    0|1   bf16 attention: V operand by ds_read_b64_tr_b16 (0: ds_read_u16 gather)
 int vlsat_debug_option(vlsat_handle h, const char* name, int32_t value) {
     if (!h || !name) return fail(VLSAT_EINVAL, "vlsat_debug_option: null argument");
@@ -50,6 +51,8 @@ int vlsat_debug_option(vlsat_handle h, const char* name, int32_t value) {
     else if (k == "gate_grid") h->gate_grid = value > 0 ? value : 0;
     else if (k == "split_fmt") h->split_fmt = value != 0;
     else if (k == "flash_bf16") h->flash_bf16 = value != 0;
+    else if (k == "pointnet_bf16") h->pointnet_bf16 = value != 0;
+    else if (k == "gate_bf16") h->gate_bf16 = value != 0;
     else if (k == "flash_tr") h->flash_tr = value != 0;
     else return fail(VLSAT_EINVAL, "vlsat_debug_option: unknown option " + k);
     return 0;

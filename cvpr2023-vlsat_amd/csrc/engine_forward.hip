@@ -123,6 +123,7 @@ int gcn_block(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const GcnW& w, float
     const int N = (int)p->N, E = (int)p->E, D = h->D, A = h->A, LDX = 768, NPC = 3328;
     RUN(gemm(h, s, G(x, LDX, w.wnode, D, sc.NP, NPC, N, NPC, w.bnode)));
     const int S = split_fmt(h);
+    const bool gate16 = h->prec_edge && h->gate_bf16;
     GemmArgs e1 = G(e, D, w.we1, D, sc.Hbig, 2 * D, E, 2 * D, nullptr, ACT_RELU);
     e1.relu_a = e_relu_pending;
     e1.a_split = S; e1.c_split = S;
@@ -132,7 +133,8 @@ int gcn_block(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const GcnW& w, float
     if (h->d.use_gcn_edge) {              // proj_edge feeds only the gate MLP (reference network_MMG.py:98-102)
         GemmArgs kp = G(e, D, w.wpe, D, sc.KP, D, E, D, w.bpe);
         kp.relu_a = e_relu_pending;
-        kp.a_split = S;                   // (its output feeds the fp32 gate kernel: plain fp32)
+        kp.a_split = S;
+        kp.c_split = S && gate16;         // (the fp32 gate kernel reads plain fp32)
         RUN(gemm(h, s, kp));
     }
     GemmArgs e2 = G(sc.Hbig, 2 * D, w.we2, 2 * D, e, D, E, D, w.be2);       // e <- nn_edge output (pre-activation)
@@ -144,7 +146,8 @@ int gcn_block(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const GcnW& w, float
         g.src = p->d_src; g.dst = p->d_dst; g.w0k = w.w0k; g.w3 = w.w3; g.b3 = w.b3; g.gated = sc.G;
         g.prob = p->prob; g.n_edges = E; g.use_edge = h->d.use_gcn_edge; g.grid_cap = h->gate_grid;
         Scope scope(h, s, PC_GATE, (double)E * h->H * (2.0 * 64 * 128 + 2.0 * 128 * 32));
-        RUN(launch_edge_gate(g, s));
+        if (gate16) RUN(launch_edge_gate_bf16(g, h->prec_edge == 3 ? 3 : 1, S, s));
+        else RUN(launch_edge_gate(g, s));
     }
     {
         Scope scope(h, s, PC_AGGREGATE, 0);
@@ -291,7 +294,14 @@ static int forward_impl(vlsat_handle h, vlsat_plan p, const float* pts, const fl
     const bool ft = h->d.feature_transform != 0;
     if (!ft) {   // a-2 object encoder
         Scope sc(h, s, PC_POINTNET, 213376.0 * N * p->P);
-        RUN(launch_pointnet(pts, N, p->P, h->d.dim_point, h->pn_w1, h->pn_b1, h->pn_w2, h->pn_b2, h->pn_w3, h->pn_b3, h->C_pt, p->F, s));
+        if (h->prec_edge && h->pointnet_bf16) {     // point rows count as edge-class work: the bf16 matrix cores
+            auto w2 = h->split.find(h->pn_w2), w3 = h->split.find(h->pn_w3);
+            if (w2 == h->split.end() || w3 == h->split.end()) return fail(VLSAT_ESTATE, "pointnet: weights have no bf16 planes");
+            RUN(launch_pointnet_bf16(pts, N, p->P, h->d.dim_point, h->pn_w1, h->pn_b1, w2->second.first, w2->second.second, h->pn_b2,
+                                     w3->second.first, w3->second.second, h->pn_b3, h->C_pt, h->prec_edge == 3 ? 3 : 1, p->F, s));
+        } else {
+            RUN(launch_pointnet(pts, N, p->P, h->d.dim_point, h->pn_w1, h->pn_b1, h->pn_w2, h->pn_b2, h->pn_w3, h->pn_b3, h->C_pt, p->F, s));
+        }
     } else {     // a-2 with the STNkd feature transform: conv1 as point rows, then GEMMs + a max over each object's rows
         float* rows = p->stn_ws + p->stn_ws_floats - (size_t)N * p->P * 64;       // h1 rows live at the end of the scratch
         {

@@ -343,7 +343,7 @@ int vlsat_finalize_weights(vlsat_handle h) {
     auto d6w = P.get(f + "6.weight", (size_t)h->H * 32), d6b = P.get(f + "6.bias", h->H);
     if (!P.missing.empty()) return fail(VLSAT_ESTATE, "missing weight: " + P.missing);
 
-    UP(w1, h->pn_w1); UP(b1, h->pn_b1); UP(w2, h->pn_w2); UP(b2, h->pn_b2); UP(w3, h->pn_w3); UP(b3, h->pn_b3);
+    UP(w1, h->pn_w1); UP(b1, h->pn_b1); UPW(w2, h->pn_w2); UP(b2, h->pn_b2); UPW(w3, h->pn_w3); UP(b3, h->pn_b3);
     UPW(mw, h->mlp_w); UP(mb, h->mlp_b);
     UP(w1cat, h->re_w1cat); UP(b1cat, h->re_b1cat);
     UPW(r3w2, h->re3_w2); UP(r3b2, h->re3_b2); UPW(r3w3, h->re3_w3); UP(r3b3, h->re3_b3);

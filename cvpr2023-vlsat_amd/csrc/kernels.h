@@ -47,6 +47,12 @@ int launch_pointnet(const float* pts, int n_obj, int n_points, int cin, const fl
                     const float* w2, const float* b2, const float* w3, const float* b3, int n_out,
                     float* out, hipStream_t s);
 
+// the same on the bf16 matrix cores (pointnet_bf16.hip): conv2 / conv3 weights as bf16 hi / lo planes ([128,64], [n_out,128]);
+// terms = 3 split-bf16 | 1 single-rounded (the lo planes are then not read)
+int launch_pointnet_bf16(const float* pts, int n_obj, int n_points, int cin, const float* w1, const float* b1,
+                         const uint16_t* w2h, const uint16_t* w2l, const float* b2, const uint16_t* w3h, const uint16_t* w3l,
+                         const float* b3, int n_out, int terms, float* out, hipStream_t s);
+
 // ---- edge cross-attention (flash style, fp32 MFMA) ----
 // tiles: device array of int4 {row_base, n_tokens, q0, head}; one block per entry.
 // Split-key mode (plans with too few blocks to fill the chip): tile i covers key tiles [krange[i].x, krange[i].y)
@@ -123,6 +129,9 @@ struct GateArgs {
     int grid_cap = 0;        // debug: persistent grid size (0 = 3 blocks per CU; vlsat_debug_option "gate_grid")
 };
 int launch_edge_gate(const GateArgs& a, hipStream_t s);
+// the same on the bf16 matrix cores (edge_gate_bf16.hip): terms = 3 split-bf16 | 1 single-rounded; kproj_split = 1: kproj is
+// in the split-pair format of the bf16 modes (common.h pack_split)
+int launch_edge_gate_bf16(const GateArgs& a, int terms, int kproj_split, hipStream_t s);
 
 // ---- scatter aggregation by source node over a CSR (rowptr[N+1], order[E]) ----
 // out[n, col0 + c] = reduce_{k in rowptr[n]..rowptr[n+1]} gated[order[k], c]; empty -> 0

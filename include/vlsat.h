@@ -269,7 +269,8 @@ int vlsat_debug_gemm_clock_probe(int64_t* buf);
  * split-key edge attention for plans that cannot fill the chip (both: plans created afterwards); "gemm_dma" 0|1:
  * LDS-direct staging of fp32 GEMM operands; "gate_grid" n: persistent grid of the gate kernel (0 = default);
  * "split_fmt" 0|1: in the bf16 modes, edge tensors between matrix kernels as bf16 hi/lo pairs (0: fp32, split on read);
- * "flash_bf16" 0|1: in the bf16 modes, edge attention on the bf16 matrix cores; "flash_tr" 0|1: its V operand by
+ * "flash_bf16" / "pointnet_bf16" / "gate_bf16" 0|1: in the bf16 modes, edge attention / object encoder / edge gate on
+ * the bf16 matrix cores (0: the fp32 kernels); "flash_tr" 0|1: its V operand by
  * ds_read_b64_tr_b16 (0: ds_read_u16 gather). */
 int vlsat_debug_option(vlsat_handle h, const char* name, int32_t value);
 

@@ -446,12 +446,57 @@ def test_cfg3_full_batch_all_scenes(bench_batch_oracle, mode, tol):
         assert float(per.max()) < tol, f"{mode}: scenes over {tol}: {torch.nonzero(per >= tol).view(-1).tolist()}"
         # the same with every experiment switch of the bf16 modes turned off one at a time (fp32 tensors between the
         # kernels, fp32 attention, gather instead of the LDS transpose read): same contract
-        for opt in ("split_fmt", "flash_tr", "flash_bf16"):
+        for opt in ("split_fmt", "flash_tr", "flash_bf16", "pointnet_bf16", "gate_bf16"):
             m.debug_option(opt, 0)
             alt = [o.cpu() for o in m(d["obj_points"], d["obj_2d_feats"], d["edge_indices"], d["descriptor"], d["batch_ids"])]
             pa = _per_scene_err(alt, ref, S, N, E)
             print(f"{mode} with {opt}=0: worst scene at {float(pa.max()):.2e}")
             assert float(pa.max()) < tol, (mode, opt)
             m.debug_option(opt, 1)
+    finally:
+        m.close()
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_graphs_bf16x3_vs_oracle(seed):
+    """The bf16 kernels (GEMM pipes, attention, object encoder, gate) on randomised batches: 1..5 scenes of 1..11
+    objects, odd point counts (partial 128-point chunks, objects split over several blocks), arbitrary edge lists with
+    self loops / duplicates / empty scenes, every aggregator; split-bf16 must stay inside the fp32 contract."""
+    from vlsat_amd.model import VLSATModel
+    g = np.random.default_rng(400 + seed)
+    cfg = VLSATConfig(N_LAYERS=int(g.integers(1, 4)), GCN_AGGR=("max", "add", "mean")[seed % 3])
+    n_pts = int(g.integers(2, 300))
+    scenes = []
+    for s in range(int(g.integers(1, 6))):
+        n = int(g.integers(1, 12))
+        sc = synth.make_scene(n, n_pts, 9500 + 10 * seed + s)
+        pairs = np.stack(np.meshgrid(np.arange(n), np.arange(n), indexing="ij"), 0).reshape(2, -1)
+        k = int(g.integers(0, pairs.shape[1] + 3))
+        pick = g.integers(0, pairs.shape[1], k) if k else np.zeros(0, np.int64)
+        sc["edge_indices"] = np.ascontiguousarray(pairs[:, pick]).astype(np.int64).reshape(2, -1)
+        scenes.append(sc)
+    b = synth.collate(scenes)
+    m = VLSATModel(cfg, DEV).load_state(synth.make_weights(cfg)).eval().set_gemm_precision("bf16x3")
+    try:
+        d = _dev(b)
+        got = [o.cpu() for o in m(d["obj_points"], d["obj_2d_feats"], d["edge_indices"], d["descriptor"], d["batch_ids"])]
+        _check(got, run_oracle(cfg, b), TOL, f"bf16x3 random graph batch #{seed}")
+    finally:
+        m.close()
+
+
+@pytest.mark.parametrize("case", ["switch_no_gcn_edge", "switch_rgb_normal", "switch_with_bn", "switch_single_rel"])
+def test_config_switches_bf16x3(golden_dir, case):
+    """The config switches that reach the bf16 kernels (gate without the edge half, 9 point channels, folded BN, log_softmax
+    head) in split-bf16 mode against the real reference's goldens."""
+    from vlsat_amd.model import VLSATModel
+    cfg = VLSATConfig(**synth.SWITCH_CASES[case])
+    b = synth.collate(synth.switch_scenes(cfg))
+    z = np.load(os.path.join(golden_dir, case + ".npz"))
+    m = VLSATModel(cfg, DEV).load_state(synth.make_weights(cfg)).eval().set_gemm_precision("bf16x3")
+    try:
+        d = _dev(b)
+        got = [o.cpu() for o in m(d["obj_points"], d["obj_2d_feats"], d["edge_indices"], d["descriptor"], d["batch_ids"])]
+        _check(got, [z[n] for n in NAMES], TOL, f"{case} in bf16x3 vs reference golden")
     finally:
         m.close()

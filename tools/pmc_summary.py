@@ -24,7 +24,7 @@ def load(d):
     per = collections.defaultdict(lambda: collections.defaultdict(float))
     cnt = collections.defaultdict(set)
     for r in csv.DictReader(open(cc)):
-        name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
         if "vlsat::" not in name:
             continue
         per[name][r["Counter_Name"]] += float(r["Counter_Value"])
@@ -35,10 +35,11 @@ def load(d):
     return per
 
 
-def main(sq, fetch, write, out):
+def main(sq, fetch, write, out, l2=None):
     a, f, w = load(sq), load(fetch), load(write)
-    lines = ["| kernel | launches | avg us | MfmaUtil % (vs 2.4 GHz) | LDS bank-conflict % | HBM read MB/launch (2x FETCH_SIZE) | HBM write MB/launch | HBM GB/s |",
-             "|---|---|---|---|---|---|---|---|"]
+    h = load(l2) if l2 and os.path.isdir(l2) else {}
+    lines = ["| kernel | launches | avg us | MfmaUtil % (vs 2.4 GHz) | wave cycles: waiting / issue-stalled / issuing % | LDS bank-conflict % | HBM read MB/launch (2x FETCH_SIZE) | HBM write MB/launch | HBM GB/s | L2 hit % |",
+             "|---|---|---|---|---|---|---|---|---|---|"]
     for name in sorted(a, key=lambda k: -a[k]["_dur_ns"]):
         c = a[name]
         n = c["_launches"]
@@ -48,7 +49,10 @@ def main(sq, fetch, write, out):
         rd = 2 * f[name]["FETCH_SIZE"] * 1024 / max(f[name]["_launches"], 1) / 1e6 if name in f else float("nan")
         wr = w[name]["WRITE_SIZE"] * 1024 / max(w[name]["_launches"], 1) / 1e6 if name in w else float("nan")
         bw = (rd + wr) * 1e6 / (us * 1e-6) / 1e9 if us > 0 else 0
-        lines.append(f"| `{name}` | {int(n)} | {us:.1f} | {mf:.1f} | {bc:.1f} | {rd:.1f} | {wr:.1f} | {bw:.0f} |")
+        wc = max(c.get("SQ_WAVE_CYCLES", 0), 1)
+        stall = f"{100 * c.get('SQ_WAIT_ANY', 0) / wc:.0f} / {100 * c.get('SQ_WAIT_INST_ANY', 0) / wc:.0f} / {100 * c.get('SQ_ACTIVE_INST_ANY', 0) / wc:.0f}"
+        hit = 100 * h[name]["TCC_HIT"] / max(h[name]["TCC_HIT"] + h[name]["TCC_MISS"], 1) if name in h else float("nan")
+        lines.append(f"| `{name}` | {int(n)} | {us:.1f} | {mf:.1f} | {stall} | {bc:.1f} | {rd:.1f} | {wr:.1f} | {bw:.0f} | {hit:.0f} |")
     open(out, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
     # per kernel CLASS (all template instantiations together): HBM bytes per launch for bench.py's roofline.traffic
@@ -76,4 +80,4 @@ def main(sq, fetch, write, out):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:5])
+    main(*sys.argv[1:6])
