@@ -130,6 +130,63 @@ __global__ __launch_bounds__(256, 2) void edge_gate_kernel(GateArgs p) {
     }
 }
 
+// Generic head geometry (MODEL.NUM_HEADS / DIM_ATTEN other than 8 / 256; reference network_MMG.py:48-50): d_k = 512 / H
+// query / edge channels per head, hidden width 2 d_k, d_o = DIM_ATTEN / H output channels.  Same algebra and layouts as
+// above (Gq per node, head-major kproj / value / gated), plain VALU: one thread per (edge, head), the hidden vector in
+// LDS (transposed, so a warp's accesses are conflict-free), weights read with wave-uniform (scalar) loads.  The MFMA
+// kernels above are built for the shipped 8 x (64, 64, 32) only.
+__global__ __launch_bounds__(64) void edge_gate_generic_kernel(GateArgs p, int n_heads, int dk, int dox) {
+    extern __shared__ float hid[];                      // [2 dk][64]
+    const int lane = threadIdx.x;
+    const long row = (long)blockIdx.x * 64 + lane;      // (edge, head)
+    const long n_rows = (long)p.n_edges * n_heads;
+    const bool valid = row < n_rows;
+    const long rr = valid ? row : n_rows - 1;
+    const int e = (int)(rr / n_heads), h = (int)(rr % n_heads);
+    const int HID = 2 * dk;
+    const float* z = p.kproj + (size_t)e * (n_heads * dk) + h * dk;
+    const float* gq = p.node + (size_t)p.src[e] * p.ld_node + p.gq_off + h * HID;
+    for (int o = 0; o < HID; ++o) {
+        float a = gq[o];
+        if (p.use_edge)
+            for (int c = 0; c < dk; ++c) a = fmaf(p.w0k[o * dk + c], z[c], a);
+        hid[o * 64 + lane] = fmaxf(a, 0.f);
+    }
+    float mx = -INFINITY;
+    for (int m = 0; m < dox; ++m) {                     // pass 1: maximum of the logits
+        float a = p.b3[m];
+        for (int o = 0; o < HID; ++o) a = fmaf(p.w3[m * HID + o], hid[o * 64 + lane], a);
+        mx = fmaxf(mx, a);
+    }
+    float sum = 0.f;
+    float* grow = p.gated + (size_t)e * (n_heads * dox) + h * dox;
+    const float* vrow = p.node + (size_t)p.dst[e] * p.ld_node + p.v_off + h * dox;
+    for (int m = 0; m < dox; ++m) {                     // pass 2: exponentials (kept in the output row), their sum
+        float a = p.b3[m];
+        for (int o = 0; o < HID; ++o) a = fmaf(p.w3[m * HID + o], hid[o * 64 + lane], a);
+        a = __expf(a - mx);
+        sum += a;
+        if (valid) grow[m] = a;
+    }
+    if (!valid) return;
+    const float inv = 1.f / sum;
+    for (int m = 0; m < dox; ++m) {
+        const float pr = grow[m] * inv;
+        if (p.prob) p.prob[(size_t)e * (n_heads * dox) + m * n_heads + h] = pr;
+        grow[m] = pr * vrow[m];
+    }
+}
+
+int launch_edge_gate_generic(const GateArgs& a, int n_heads, int dk, int dox, hipStream_t s) {
+    if (a.n_edges <= 0) return 0;
+    if (dk < 1 || dk > 128 || dox < 1) return fail(-1, "edge_gate: unsupported head geometry");
+    const long rows = (long)a.n_edges * n_heads;
+    hipLaunchKernelGGL(edge_gate_generic_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 2 * dk * 64 * sizeof(float), s, a,
+                       n_heads, dk, dox);
+    VLSAT_LAUNCH_CHECK("edge_gate_generic");
+    return 0;
+}
+
 int launch_edge_gate(const GateArgs& a, hipStream_t s) {
     if (a.n_edges <= 0) return 0;
     if ((a.ld_node & 3) || (a.gq_off & 3) || (a.v_off & 3)) return fail(-1, "edge_gate: ld_node/gq_off/v_off must be multiples of 4");

@@ -114,6 +114,8 @@ struct vlsat_plan_s {
     bool used = false;
     // device index arrays
     int32_t *d_src, *d_dst, *d_rowptr, *d_order, *d_scene_ptr;
+    int32_t* d_edge_ptr32 = nullptr;        // [S+1] edge ranges of the scenes (generic edge attention for d_k != 64)
+    int max_e = 0;                          // most edges in one scene
     int64_t* d_bias_ptr;
     int4* d_tiles;
     int n_tiles = 0;
@@ -140,6 +142,12 @@ extern const char* kProfNames[PC_COUNT];
 
 // scratch buffers of one modality branch
 struct Scratch { float *NP, *Hbig, *KP, *G, *T768, *R1, *R2, *rs, *H2; };
+
+// row pitches that depend on MODEL.DIM_ATTEN (A): node features carry [x (512) | aggregated message (A)], the node-side
+// projection buffer [P_i 1024 | P_j 1024 | Gq H*(2 d_k) = 1024 | value A]
+inline int ldx_of(const vlsat_ctx* h) { return h->D + h->A; }
+inline int npc_of(const vlsat_ctx* h) { return 6 * h->D + h->A; }
+inline bool default_heads(const vlsat_ctx* h) { return h->H == 8 && h->A == 256; }
 
 #define RUN(expr)                  \
     do {                           \

@@ -23,7 +23,8 @@ namespace {
 // MODEL.feature_transform (its encoder chain keeps fp32 rows) and not when a debug option disabled one of the kernels
 // that understand the format.
 static bool split_fmt(const vlsat_ctx* h) {
-    return h->prec_edge != 0 && h->split_fmt && h->flash_bf16 && h->flash_tr && !h->gemm_no_dma && !h->d.feature_transform;
+    return h->prec_edge != 0 && h->split_fmt && h->flash_bf16 && h->flash_tr && !h->gemm_no_dma && !h->d.feature_transform &&
+           default_heads(h);
 }
 
 // ---- profiling helpers ----
@@ -96,7 +97,7 @@ GemmArgs G(const float* A, int lda, const float* W, int K, float* C, int ldc, in
 }
 
 int attn_block(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const AttnW& w, float* xq, const float* xkv, bool self) {
-    const int N = (int)p->N, D = h->D, LDX = 768;
+    const int N = (int)p->N, D = h->D, LDX = ldx_of(h);
     if (self) {
         RUN(gemm(h, s, G(xq, LDX, w.wqkv, D, p->QKVn, 3 * D, N, 3 * D, w.bqkv)));
     } else {
@@ -106,7 +107,7 @@ int attn_block(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const AttnW& w, flo
     {
         Scope sc(h, s, PC_NODE_ATTN, 0);
         RUN(launch_node_attn(p->QKVn, 3 * D, p->QKVn + D, 3 * D, p->QKVn + 2 * D, 3 * D, p->On, D, p->bias,
-                             p->d_scene_ptr, p->d_bias_ptr, p->S, p->max_n, h->H, 1.0f, s));
+                             p->d_scene_ptr, p->d_bias_ptr, p->S, p->max_n, h->H, D / h->H, 1.0f, s));
     }
     GemmArgs o = G(p->On, D, w.wo, D, xq, LDX, N, D, w.bo);
     o.resid = xq; o.ldr = LDX;
@@ -120,10 +121,10 @@ int attn_block(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const AttnW& w, flo
 
 int gcn_block(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const GcnW& w, float* x, float* e, int e_relu_pending,
               int out_relu, const Scratch& sc) {
-    const int N = (int)p->N, E = (int)p->E, D = h->D, A = h->A, LDX = 768, NPC = 3328;
+    const int N = (int)p->N, E = (int)p->E, D = h->D, A = h->A, LDX = ldx_of(h), NPC = npc_of(h);
     RUN(gemm(h, s, G(x, LDX, w.wnode, D, sc.NP, NPC, N, NPC, w.bnode)));
     const int S = split_fmt(h);
-    const bool gate16 = h->prec_edge && h->gate_bf16;
+    const bool gate16 = h->prec_edge && h->gate_bf16 && default_heads(h);
     GemmArgs e1 = G(e, D, w.we1, D, sc.Hbig, 2 * D, E, 2 * D, nullptr, ACT_RELU);
     e1.relu_a = e_relu_pending;
     e1.a_split = S; e1.c_split = S;
@@ -142,11 +143,13 @@ int gcn_block(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const GcnW& w, float
     RUN(gemm(h, s, e2));
     {
         GateArgs g{};
-        g.kproj = sc.KP; g.node = sc.NP; g.ld_node = NPC; g.gq_off = 4 * D; g.v_off = 4 * D + h->H * 128;
+        g.kproj = sc.KP; g.node = sc.NP; g.ld_node = NPC; g.gq_off = 4 * D; g.v_off = 6 * D;    // Gq spans H * 2 d_k = 2 D columns
         g.src = p->d_src; g.dst = p->d_dst; g.w0k = w.w0k; g.w3 = w.w3; g.b3 = w.b3; g.gated = sc.G;
         g.prob = p->prob; g.n_edges = E; g.use_edge = h->d.use_gcn_edge; g.grid_cap = h->gate_grid;
-        Scope scope(h, s, PC_GATE, (double)E * h->H * (2.0 * 64 * 128 + 2.0 * 128 * 32));
-        if (gate16) RUN(launch_edge_gate_bf16(g, h->prec_edge == 3 ? 3 : 1, S, s));
+        const double dk = D / h->H, dox = A / h->H;
+        Scope scope(h, s, PC_GATE, (double)E * h->H * (2.0 * dk * 2 * dk + 2.0 * 2 * dk * dox));
+        if (!default_heads(h)) RUN(launch_edge_gate_generic(g, h->H, D / h->H, A / h->H, s));
+        else if (gate16) RUN(launch_edge_gate_bf16(g, h->prec_edge == 3 ? 3 : 1, S, s));
         else RUN(launch_edge_gate(g, s));
     }
     {
@@ -185,9 +188,9 @@ int obj_head(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const float* x, const
     const int N = (int)p->N, D = h->D, C = h->d.n_obj_class;
     {
         Scope scope(h, s, PC_MISC, 0);
-        RUN(launch_row_invnorm(x, 768, N, D, std::exp(h->d.obj_logit_scale), sc.rs, s));
+        RUN(launch_row_invnorm(x, ldx_of(h), N, D, std::exp(h->d.obj_logit_scale), sc.rs, s));
     }
-    GemmArgs a = G(x, 768, w, D, out, C, N, C, b);
+    GemmArgs a = G(x, ldx_of(h), w, D, out, C, N, C, b);
     a.rowscale = sc.rs;
     RUN(gemm(h, s, a));
     return 0;
@@ -248,7 +251,7 @@ static int forward_impl(vlsat_handle h, vlsat_plan p, const float* pts, const fl
         return fail(VLSAT_EINVAL, "vlsat_forward: 2D branch needs obj_2d_feats and both 2D outputs (or neither for 3D-only)");
     if (p->E > 0 && !rel3d) return fail(VLSAT_EINVAL, "vlsat_forward: null relation output");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int N = (int)p->N, E = (int)p->E, D = h->D, L = h->d.n_layers, LDX = 768;
+    const int N = (int)p->N, E = (int)p->E, D = h->D, L = h->d.n_layers, LDX = ldx_of(h);
     const int stop = h->debug_stop;
     h->cur_N = N;
     if (p->upload_pending) {               // the plan's index tables travel on the handle's copy stream
@@ -395,7 +398,11 @@ static int forward_impl(vlsat_handle h, vlsat_plan p, const float* pts, const fl
                 FlashSplit sp;
                 sp.parts = p->fa_parts; sp.krange = p->d_krange; sp.o_part = p->fa_opart; sp.m_part = p->fa_m;
                 sp.l_part = p->fa_l; sp.part_stride = (size_t)E * D; sp.rows = E; sp.heads = h->H;
-                if (h->prec_edge && h->flash_bf16)
+                if (D / h->H != 64)          // generic head dim: VALU attention over the scenes' edge ranges (no bias)
+                    RUN(launch_node_attn(p->Qe, D, p->KVe, 2 * D, p->KVe + D, 2 * D, p->Oe, D, nullptr, p->d_edge_ptr32, nullptr,
+                                         h->edge_scope == 1 ? 1 : p->S, h->edge_scope == 1 ? E : p->max_e, h->H, D / h->H,
+                                         1.f / std::sqrt((float)(D / h->H)), s));
+                else if (h->prec_edge && h->flash_bf16)
                     RUN(launch_flash_attn_bf16(p->Qe, D, p->KVe, p->KVe + D, 2 * D, p->Oe, D, p->d_tiles, p->n_tiles, sc2e,
                                                h->prec_edge == 3 ? 3 : 1, h->flash_tr, S, s, &sp));
                 else
@@ -418,7 +425,7 @@ static int forward_impl(vlsat_handle h, vlsat_plan p, const float* pts, const fl
         // gcn_edge_feature_2d_dis = triplet_projector_2d(cat[x2[ei[0]], x2[ei[1]], e2]) (:259-264,319-322): node columns of
         // its first Linear on N rows, gathered into the edge GEMM's accumulators like nn_edge.0
         if (!h->trip.wnode) return fail(VLSAT_ESTATE, "forward(istrain=True): triplet_projector_2d weights were not loaded");
-        const int NPC = 3328;
+        const int NPC = npc_of(h);
         RUN(gemm(h, s, G(p->X2, LDX, h->trip.wnode, D, sc2.NP, NPC, N, 4 * D, h->trip.bnode)));
         GemmArgs e1 = G(p->E2, D, h->trip.we, D, sc2.Hbig, 2 * D, E, 2 * D, nullptr, ACT_RELU);
         e1.g0 = sc2.NP; e1.gi0 = p->d_src; e1.ldg0 = NPC;

@@ -94,6 +94,7 @@ int vlsat_plan_create(vlsat_handle h, const int64_t* bid, const int64_t* edges, 
     std::unique_ptr<vlsat_plan_s> p(new vlsat_plan_s());
     p->h = h; p->N = N; p->E = E; p->P = P;
     const int H = h->H, D = h->D;
+    const size_t LDX = (size_t)ldx_of(h), NPC = (size_t)npc_of(h), A = (size_t)h->A;
     // ---- scenes: maximal runs of equal batch id (must not re-appear) ----
     std::vector<int32_t> node_scene(N);
     p->node_ptr.push_back(0);
@@ -192,20 +193,24 @@ int vlsat_plan_create(vlsat_handle h, const int64_t* bid, const int64_t* edges, 
     want(&p->d_src, Es, src.data()); want(&p->d_dst, Es, dst.data()); want(&p->d_order, Es, order.data());
     want(&p->d_rowptr, Ns + 1, rowptr.data()); want(&p->d_scene_ptr, (size_t)p->S + 1, p->node_ptr.data());
     want(&p->d_bias_ptr, (size_t)p->S, bias_ptr.data());
+    std::vector<int32_t> edge_ptr32(p->edge_ptr.begin(), p->edge_ptr.end());
+    if (h->edge_scope == 1) { edge_ptr32.assign((size_t)p->S + 1, (int32_t)E); edge_ptr32[0] = 0; }   // one range: the whole batch
+    for (int sc = 0; sc < p->S; ++sc) p->max_e = std::max<int>(p->max_e, (int)(p->edge_ptr[sc + 1] - p->edge_ptr[sc]));
+    want(&p->d_edge_ptr32, (size_t)p->S + 1, edge_ptr32.data());
     want(&p->d_tiles, std::max<size_t>(tiles.size(), 1), tiles.empty() ? nullptr : tiles.data());
     if (p->fa_parts > 1) want(&p->d_krange, krange.size(), krange.data());
     const size_t n_index_items = items.size();
-    want(&p->F, Ns * 768); want(&p->X3, Ns * 768); want(&p->X2, Ns * 768); want(&p->NP, Ns * 3328);
-    want(&p->QKVn, Ns * 1536); want(&p->On, Ns * 512); want(&p->T256, Ns * 256); want(&p->T768, Ns * 768);
+    want(&p->F, Ns * 768); want(&p->X3, Ns * LDX); want(&p->X2, Ns * LDX); want(&p->NP, Ns * NPC);
+    want(&p->QKVn, Ns * 1536); want(&p->On, Ns * 512); want(&p->T256, Ns * 256); want(&p->T768, Ns * LDX);
     want(&p->rs, Ns); want(&p->bias, (size_t)std::max<int64_t>(bias_total, 1));
     want(&p->H1, Es * 128); want(&p->H2, Es * 128); want(&p->E3, Es * 512); want(&p->E2, Es * 512);
-    want(&p->Hbig, Es * 1024); want(&p->KP, Es * 512); want(&p->G, Es * 256);
+    want(&p->Hbig, Es * 1024); want(&p->KP, Es * 512); want(&p->G, Es * A);
     want(&p->Qe, Es * 512); want(&p->KVe, Es * 1024); want(&p->Oe, Es * 512);
     // launch-bound plans (every edge GEMM fits one round of the grid): second scratch set for the 2D twin stages
     p->dual = h->dual_stream && E > 0 && E <= 8192;
     if (p->dual) {
-        want(&p->NP2, Ns * 3328); want(&p->Hbig2, Es * 1024); want(&p->KP2, Es * 512); want(&p->G2, Es * 256);
-        want(&p->T768b, Ns * 768); want(&p->rs2, Ns); want(&p->H2b, Es * 128);
+        want(&p->NP2, Ns * NPC); want(&p->Hbig2, Es * 1024); want(&p->KP2, Es * 512); want(&p->G2, Es * A);
+        want(&p->T768b, Ns * LDX); want(&p->rs2, Ns); want(&p->H2b, Es * 128);
     }
     if (h->d.feature_transform) {
         // point rows R = N*P (objects) or E (relation encoders, P = 1), one phase at a time:
@@ -311,10 +316,11 @@ int vlsat_plan_info(vlsat_plan p, int32_t* n_scenes, size_t* ws, int32_t* is_fc)
 int vlsat_debug_buffer(vlsat_plan p, const char* name, void** ptr, int64_t* rows, int32_t* cols, int32_t* ld) {
     if (!p || !name) return fail(VLSAT_EINVAL, "null argument");
     struct B { const char* n; float* p; int64_t r; int c, ld; };
-    const B tab[] = {{"F", p->F, p->N, 768, 768},       {"X3", p->X3, p->N, 512, 768},     {"X2", p->X2, p->N, 512, 768},
-                     {"AGG3", p->X3 + 512, p->N, 256, 768}, {"AGG2", p->X2 + 512, p->N, 256, 768},
-                     {"E3", p->E3, p->E, 512, 512},     {"E2", p->E2, p->E, 512, 512},     {"G", p->G, p->E, 256, 256},
-                     {"H1", p->H1, p->E, 128, 128},     {"KP", p->KP, p->E, 512, 512},     {"NP", p->NP, p->N, 3328, 3328},
+    const int LDX = ldx_of(p->h), NPC = npc_of(p->h), A = p->h->A;
+    const B tab[] = {{"F", p->F, p->N, 768, 768},       {"X3", p->X3, p->N, 512, LDX},     {"X2", p->X2, p->N, 512, LDX},
+                     {"AGG3", p->X3 + 512, p->N, A, LDX}, {"AGG2", p->X2 + 512, p->N, A, LDX},
+                     {"E3", p->E3, p->E, 512, 512},     {"E2", p->E2, p->E, 512, 512},     {"G", p->G, p->E, A, A},
+                     {"H1", p->H1, p->E, 128, 128},     {"KP", p->KP, p->E, 512, 512},     {"NP", p->NP, p->N, NPC, NPC},
                      {"Hbig", p->Hbig, p->E, 1024, 1024}, {"bias", p->bias, 1, 0, 0},      {"On", p->On, p->N, 512, 512},
                      {"Oe", p->Oe, p->E, 512, 512},     {"Qe", p->Qe, p->E, 512, 512},     {"KVe", p->KVe, p->E, 1024, 1024}};
     for (auto& b : tab)

@@ -109,7 +109,7 @@ int prepare_gcn(vlsat_ctx* h, Prep& P, const std::string& pre, GcnW& w) {
     auto w_p0 = P.get(pre + ".prop.0.weight", (size_t)(D + A) * (D + A)), b_p0 = P.get(pre + ".prop.0.bias", D + A);
     auto w_p2 = P.get(pre + ".prop.2.weight", (size_t)D * (D + A)), b_p2 = P.get(pre + ".prop.2.bias", D);
     if (!P.missing.empty()) return 0;
-    if (dn != 64 || de != 64 || dox != 32) return fail(VLSAT_EINVAL, "gate kernel is built for 8 heads x (64,64,32)");
+    (void)dox;
 
     // nn_edge.0 [1024, 1536] column blocks: [0:512] = x_i (source), [512:1024] = edge, [1024:1536] = x_j (target)
     const int NO = 2 * D, NI = 3 * D;
@@ -233,7 +233,12 @@ const char* vlsat_version(void) { return "vlsat-hip gfx950 r2 (fp32-mfma | bf16x
 int vlsat_create(const VlsatDims* d, vlsat_handle* out) {
     if (!d || !out) return fail(VLSAT_EINVAL, "vlsat_create: null argument");
     if (d->n_layers < 1 || d->n_layers > 16) return fail(VLSAT_EINVAL, "n_layers must be in [1,16]");
-    if (d->n_heads != 8 || d->dim_atten != 256) return fail(VLSAT_EINVAL, "only NUM_HEADS=8, DIM_ATTEN=256 are built");
+    // MODEL.NUM_HEADS must divide dim_node (512) and DIM_ATTEN (reference network_MMG.py:48-50); the per-head kernels are
+    // built for d_k = 512 / H in {32, 64, 128}.  8 x 256 (shipped) takes the MFMA gate / attention kernels, anything
+    // else the generic ones.
+    if (d->n_heads != 4 && d->n_heads != 8 && d->n_heads != 16) return fail(VLSAT_EINVAL, "NUM_HEADS must be 4, 8 or 16");
+    if (d->dim_atten < d->n_heads || d->dim_atten > 512 || d->dim_atten % (4 * d->n_heads))
+        return fail(VLSAT_EINVAL, "DIM_ATTEN must be a multiple of 4 * NUM_HEADS, at most 512");
     if (d->gcn_aggr < 0 || d->gcn_aggr > 2) return fail(VLSAT_EINVAL, "gcn_aggr must be 0 (max), 1 (add) or 2 (mean)");
     if (d->dim_point != 3 && d->dim_point != 6 && d->dim_point != 9)
         return fail(VLSAT_EINVAL, "dim_point must be 3, 6 or 9 (xyz [+ USE_RGB] [+ USE_NORMAL])");
@@ -242,6 +247,8 @@ int vlsat_create(const VlsatDims* d, vlsat_handle* out) {
     auto* h = new (std::nothrow) vlsat_ctx();
     if (!h) return fail(VLSAT_ENOMEM, "out of host memory");
     h->d = *d;
+    h->H = d->n_heads;
+    h->A = d->dim_atten;
     *out = h;
     return 0;
 }
@@ -357,8 +364,9 @@ int vlsat_finalize_weights(vlsat_handle h) {
     h->self_attn.resize(L); h->cross_attn.resize(L); h->cross_rel.resize(L); h->gcn3.resize(L); h->gcn2.resize(L);
     for (int l = 0; l < L; ++l) {
         const std::string ls = std::to_string(l);
-        RUN(prepare_attn(h, P, "mmg.self_attn." + ls, h->self_attn[l], true, 0.125f));
-        RUN(prepare_attn(h, P, "mmg.cross_attn." + ls, h->cross_attn[l], false, 0.125f));
+        const float qs = 1.0f / std::sqrt((float)(D / h->H));          // 1/sqrt(d_k): 0.125 (exact) for the shipped 8 heads
+        RUN(prepare_attn(h, P, "mmg.self_attn." + ls, h->self_attn[l], true, qs));
+        RUN(prepare_attn(h, P, "mmg.cross_attn." + ls, h->cross_attn[l], false, qs));
         RUN(prepare_attn(h, P, "mmg.cross_attn_rel." + ls, h->cross_rel[l], false, 1.0f));
         RUN(prepare_gcn(h, P, "mmg.gcn_3ds." + ls, h->gcn3[l]));
         RUN(prepare_gcn(h, P, "mmg.gcn_2ds." + ls, h->gcn2[l]));

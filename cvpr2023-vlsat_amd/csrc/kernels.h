@@ -79,9 +79,11 @@ constexpr int FLASH_BQ = 128;   // queries per block
 // ---- node attention with distance bias (per scene, per head) ----
 // scene_ptr: device [n_scenes+1] node offsets; bias_ptr: device [n_scenes] offsets into bias
 // (layout per scene: [H][n][n], query-major).  grid covers max_n queries per scene.
+// head dim dk = 512 / n_heads in {32, 64, 128}; bias may be NULL.  Also the generic (VALU) edge cross-attention for
+// dk != 64 (scene_ptr = the scenes' edge ranges).
 int launch_node_attn(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,
                      float* O, int ldo, const float* bias, const int32_t* scene_ptr,
-                     const int64_t* bias_ptr, int n_scenes, int max_n, int n_heads, float scale,
+                     const int64_t* bias_ptr, int n_scenes, int max_n, int n_heads, int dk, float scale,
                      hipStream_t s);
 // distance-bias MLP (MMG.self_attn_fc): centres = desc[:,0:3] (ld = 11)
 struct DistBiasW { const float *w0, *b0, *g2, *be2, *w3, *b3, *g5, *be5, *w6, *b6; };
@@ -129,6 +131,8 @@ struct GateArgs {
     int grid_cap = 0;        // debug: persistent grid size (0 = 3 blocks per CU; vlsat_debug_option "gate_grid")
 };
 int launch_edge_gate(const GateArgs& a, hipStream_t s);
+// any head geometry (dk query / edge channels per head, dox output channels per head): plain VALU
+int launch_edge_gate_generic(const GateArgs& a, int n_heads, int dk, int dox, hipStream_t s);
 // the same on the bf16 matrix cores (edge_gate_bf16.hip): terms = 3 split-bf16 | 1 single-rounded; kproj_split = 1: kproj is
 // in the split-pair format of the bf16 modes (common.h pack_split)
 int launch_edge_gate_bf16(const GateArgs& a, int terms, int kproj_split, hipStream_t s);

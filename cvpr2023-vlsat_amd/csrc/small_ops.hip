@@ -158,25 +158,25 @@ __global__ __launch_bounds__(256) void aggregate_kernel(const float* __restrict_
                                                         const int32_t* __restrict__ rowptr,
                                                         const int32_t* __restrict__ order, int aggr,
                                                         float* __restrict__ out, int ldo, int col0) {
-    const int n = blockIdx.x, c = threadIdx.x;
-    if (c >= n_ch) return;
+    const int n = blockIdx.x;
     const int b = rowptr[n], e = rowptr[n + 1];
-    float acc = 0.f;
-    if (e > b) {
-        if (aggr == 0) {
-            acc = -INFINITY;
-            for (int k = b; k < e; ++k) acc = fmaxf(acc, gated[(size_t)order[k] * n_ch + c]);
-        } else {
-            for (int k = b; k < e; ++k) acc += gated[(size_t)order[k] * n_ch + c];
-            if (aggr == 2) acc /= (float)(e - b);
+    for (int c = threadIdx.x; c < n_ch; c += 256) {          // (DIM_ATTEN = 512: two channels per thread)
+        float acc = 0.f;
+        if (e > b) {
+            if (aggr == 0) {
+                acc = -INFINITY;
+                for (int k = b; k < e; ++k) acc = fmaxf(acc, gated[(size_t)order[k] * n_ch + c]);
+            } else {
+                for (int k = b; k < e; ++k) acc += gated[(size_t)order[k] * n_ch + c];
+                if (aggr == 2) acc /= (float)(e - b);
+            }
         }
+        out[(size_t)n * ldo + col0 + c] = acc;
     }
-    out[(size_t)n * ldo + col0 + c] = acc;
 }
 int launch_aggregate(const float* gated, int n_ch, const int32_t* rowptr, const int32_t* order, int n_nodes,
                      int aggr, float* out, int ldo, int col0, hipStream_t s) {
     if (n_nodes <= 0) return 0;
-    if (n_ch > 256) return fail(-1, "aggregate: n_ch must be <= 256");
     hipLaunchKernelGGL(aggregate_kernel, dim3(n_nodes), dim3(256), 0, s, gated, n_ch, rowptr, order, aggr, out, ldo,
                        col0);
     VLSAT_LAUNCH_CHECK("aggregate");
@@ -255,6 +255,7 @@ int launch_dist_bias(const float* desc, int ld_desc, const int32_t* scene_ptr, c
 // (reference transformer/attention.py:60-76 as called from network_MMG.py:217-218.)
 // N per scene is small (40 at cfg 2, 200 at cfg 5): one query per lane, keys streamed through
 // LDS in chunks of 64 (wave-uniform broadcast reads), online softmax, fp32 VALU.
+template <int DK>
 __global__ __launch_bounds__(64) void node_attn_kernel(const float* __restrict__ Q, int ldq,
                                                        const float* __restrict__ K, int ldk,
                                                        const float* __restrict__ V, int ldv,
@@ -262,39 +263,39 @@ __global__ __launch_bounds__(64) void node_attn_kernel(const float* __restrict__
                                                        const float* __restrict__ bias,
                                                        const int32_t* __restrict__ scene_ptr,
                                                        const int64_t* __restrict__ bias_ptr, float scale) {
-    __shared__ __attribute__((aligned(16))) float sK[64 * 64];
-    __shared__ __attribute__((aligned(16))) float sV[64 * 64];
+    __shared__ __attribute__((aligned(16))) float sK[64 * DK];
+    __shared__ __attribute__((aligned(16))) float sV[64 * DK];
     const int s = blockIdx.z, h = blockIdx.y, lane = threadIdx.x;
     const int n0 = scene_ptr[s], n = scene_ptr[s + 1] - n0;
     const int qa = blockIdx.x * 64 + lane;
     if (blockIdx.x * 64 >= n) return;
     const bool valid = qa < n;
     const int qrow = n0 + (valid ? qa : n - 1);
-    float q[64], acc[64];
+    float q[DK], acc[DK];
 #pragma unroll
-    for (int g = 0; g < 16; ++g) {
-        const f32x4 x = *reinterpret_cast<const f32x4*>(Q + (size_t)qrow * ldq + h * 64 + 4 * g);
+    for (int g = 0; g < DK / 4; ++g) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(Q + (size_t)qrow * ldq + h * DK + 4 * g);
 #pragma unroll
         for (int c = 0; c < 4; ++c) { q[4 * g + c] = x[c] * scale; acc[4 * g + c] = 0.f; }
     }
     float m_run = -INFINITY, l_run = 0.f;
-    const float* brow = bias + bias_ptr[s] + ((size_t)h * n + (valid ? qa : n - 1)) * n;
+    const float* brow = bias ? bias + bias_ptr[s] + ((size_t)h * n + (valid ? qa : n - 1)) * n : nullptr;
     for (int k0 = 0; k0 < n; k0 += 64) {
         const int kn = min(64, n - k0);
         __syncthreads();
-        for (int i = lane; i < kn * 16; i += 64) {
-            const int r = i >> 4, c4 = (i & 15) * 4;
-            *reinterpret_cast<f32x4*>(sK + r * 64 + c4) =
-                *reinterpret_cast<const f32x4*>(K + (size_t)(n0 + k0 + r) * ldk + h * 64 + c4);
-            *reinterpret_cast<f32x4*>(sV + r * 64 + c4) =
-                *reinterpret_cast<const f32x4*>(V + (size_t)(n0 + k0 + r) * ldv + h * 64 + c4);
+        for (int i = lane; i < kn * (DK / 4); i += 64) {
+            const int r = i / (DK / 4), c4 = (i % (DK / 4)) * 4;
+            *reinterpret_cast<f32x4*>(sK + r * DK + c4) =
+                *reinterpret_cast<const f32x4*>(K + (size_t)(n0 + k0 + r) * ldk + h * DK + c4);
+            *reinterpret_cast<f32x4*>(sV + r * DK + c4) =
+                *reinterpret_cast<const f32x4*>(V + (size_t)(n0 + k0 + r) * ldv + h * DK + c4);
         }
         __syncthreads();
         for (int j = 0; j < kn; ++j) {
-            float sc = brow[k0 + j];
+            float sc = brow ? brow[k0 + j] : 0.f;
 #pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const f32x4 kk = *reinterpret_cast<const f32x4*>(sK + j * 64 + 4 * g);
+            for (int g = 0; g < DK / 4; ++g) {
+                const f32x4 kk = *reinterpret_cast<const f32x4*>(sK + j * DK + 4 * g);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) sc = fmaf(q[4 * g + c], kk[c], sc);
             }
@@ -304,8 +305,8 @@ __global__ __launch_bounds__(64) void node_attn_kernel(const float* __restrict__
             l_run = l_run * alpha + p;
             m_run = m_new;
 #pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const f32x4 vv = *reinterpret_cast<const f32x4*>(sV + j * 64 + 4 * g);
+            for (int g = 0; g < DK / 4; ++g) {
+                const f32x4 vv = *reinterpret_cast<const f32x4*>(sV + j * DK + 4 * g);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) acc[4 * g + c] = fmaf(acc[4 * g + c], alpha, p * vv[c]);
             }
@@ -314,21 +315,28 @@ __global__ __launch_bounds__(64) void node_attn_kernel(const float* __restrict__
     if (valid) {
         const float inv = 1.f / l_run;
 #pragma unroll
-        for (int g = 0; g < 16; ++g) {
+        for (int g = 0; g < DK / 4; ++g) {
             f32x4 o;
 #pragma unroll
             for (int c = 0; c < 4; ++c) o[c] = acc[4 * g + c] * inv;
-            *reinterpret_cast<f32x4*>(O + (size_t)qrow * ldo + h * 64 + 4 * g) = o;
+            *reinterpret_cast<f32x4*>(O + (size_t)qrow * ldo + h * DK + 4 * g) = o;
         }
     }
 }
+// d_k = 512 / NUM_HEADS: 64 (shipped), 32 or 128.  bias may be NULL (no additive term): the generic (VALU) path of the
+// edge cross-attention for d_k != 64 runs through this kernel too, with the scenes' EDGE ranges as scene_ptr.
 int launch_node_attn(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
                      const float* bias, const int32_t* scene_ptr, const int64_t* bias_ptr, int n_scenes, int max_n,
-                     int n_heads, float scale, hipStream_t s) {
+                     int n_heads, int dk, float scale, hipStream_t s) {
     if (n_scenes <= 0 || max_n <= 0) return 0;
     if ((ldq | ldk | ldv | ldo) & 3) return fail(-1, "node_attn: leading dims must be multiples of 4");
-    hipLaunchKernelGGL(node_attn_kernel, dim3((max_n + 63) / 64, n_heads, n_scenes), dim3(64), 0, s, Q, ldq, K, ldk,
-                       V, ldv, O, ldo, bias, scene_ptr, bias_ptr, scale);
+    const dim3 grid((max_n + 63) / 64, n_heads, n_scenes);
+    switch (dk) {
+        case 32: hipLaunchKernelGGL(node_attn_kernel<32>, grid, dim3(64), 0, s, Q, ldq, K, ldk, V, ldv, O, ldo, bias, scene_ptr, bias_ptr, scale); break;
+        case 64: hipLaunchKernelGGL(node_attn_kernel<64>, grid, dim3(64), 0, s, Q, ldq, K, ldk, V, ldv, O, ldo, bias, scene_ptr, bias_ptr, scale); break;
+        case 128: hipLaunchKernelGGL(node_attn_kernel<128>, grid, dim3(64), 0, s, Q, ldq, K, ldk, V, ldv, O, ldo, bias, scene_ptr, bias_ptr, scale); break;
+        default: return fail(-1, "node_attn: head dim must be 32, 64 or 128");
+    }
     VLSAT_LAUNCH_CHECK("node_attn");
     return 0;
 }

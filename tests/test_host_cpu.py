@@ -62,10 +62,14 @@ def test_c_abi_argument_validation_without_gpu(L):
     lib = L.load()
     h = C.c_void_p()
     good = L.VlsatDims(2, 8, 256, 0, 3, 160, 26, 2.6593, 1, 1, 0)
-    for bad in (L.VlsatDims(0, 8, 256, 0, 3, 160, 26, 2.65), L.VlsatDims(2, 4, 256, 0, 3, 160, 26, 2.65),
+    for bad in (L.VlsatDims(0, 8, 256, 0, 3, 160, 26, 2.65), L.VlsatDims(2, 5, 256, 0, 3, 160, 26, 2.65),
+                L.VlsatDims(2, 8, 250, 0, 3, 160, 26, 2.65),
                 L.VlsatDims(2, 8, 256, 3, 3, 160, 26, 2.65), L.VlsatDims(2, 8, 256, 0, 5, 160, 26, 2.65)):
         assert lib.vlsat_create(C.byref(bad), C.byref(h)) == -1
         assert len(lib.vlsat_last_error()) > 0
+    for ok in (L.VlsatDims(2, 4, 256, 0, 3, 160, 26, 2.65, 1, 1, 0), L.VlsatDims(2, 16, 512, 0, 3, 160, 26, 2.65, 1, 1, 0)):
+        assert lib.vlsat_create(C.byref(ok), C.byref(h)) == 0        # NUM_HEADS in {4, 8, 16}, DIM_ATTEN a multiple of 4 H
+        lib.vlsat_destroy(h)
     assert lib.vlsat_create(C.byref(good), C.byref(h)) == 0
     x = np.zeros(4, np.float32)
     assert lib.vlsat_load_weight(h, b"not.a.weight", x.ctypes.data, 4) == -1
