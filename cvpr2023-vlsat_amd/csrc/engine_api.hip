@@ -66,7 +66,8 @@ int vlsat_k_gemm(const float* A, int32_t lda, const float* W, int32_t ldw, float
     GemmArgs a;
     a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
     a.bias = bias; a.rowscale = rowscale; a.resid = resid; a.ldr = ldr; a.resid_scale = resid_scale;
-    a.g0 = g0; a.gi0 = gi0; a.ldg0 = ldg0; a.g1 = g1; a.gi1 = gi1; a.ldg1 = ldg1; a.relu_a = relu_a; a.act = act;
+    a.g0 = g0; a.gi0 = gi0; a.ldg0 = ldg0; a.g1 = g1; a.gi1 = gi1; a.ldg1 = ldg1; a.relu_a = relu_a & 1; a.act = act;
+    if (relu_a & 2) a.prefetch = 0;             // (bit 1 of relu_a: no A-panel prefetch -- benchmarking)
     return launch_gemm(a, static_cast<hipStream_t>(stream));
 }
 

@@ -151,7 +151,7 @@ struct PipeF32 {
 // (the whole offset travels in the VGPR: on gfx9 the range check does not see the SGPR offset).
 template <int BM, int BN>
 struct PipeF32Dma {
-    static constexpr bool PREFETCH = false;
+    static constexpr bool PREFETCH = false;          // (the A-panel touch of PipeSplitDma measured -2 % here: 4096-cycle slices already cover the load)
     static constexpr int TM = BM / 64, TN = BN / 64;
     static constexpr int STAGE_BYTES = (BM + BN) * BK * 4;
     struct Regs {};
@@ -186,6 +186,7 @@ struct PipeF32Dma {
     }
     // the slice has had a whole slice of MFMAs to land; the caller's barrier publishes it
     static __device__ __forceinline__ void store(char*, Regs&, int, int) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    static __device__ __forceinline__ void store_keep1() { asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); }
     static __device__ __forceinline__ void mma(const char* stage, int wm, int wn, f32x16 (&acc)[TM][TN], int lane, int = 0) {
         const int li = lane & 31, hi = lane >> 5;
         const int sw = (li >> 1) & 7;

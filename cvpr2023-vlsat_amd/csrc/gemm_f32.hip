@@ -340,7 +340,8 @@ static int run_tiled(const GemmArgs& a, hipStream_t s) {
     const long T = (long)nbm * nbn;
     if (T <= G) {                                   // one round: grid = tiles (rounded up to 8)
         const int grid = (int)((T + 7) / 8) * 8;
-        if (BM == 64 && BN == 64 && a.K % (2 * BK) == 0) return launch_t<64, 64, 2>(a, (int)T, grid, s);   // latency-bound
+        // latency-bound: two k-slices per pipeline step (four per step measured no faster: tools/latency_probe.py, round 2)
+        if (BM == 64 && BN == 64 && a.K % (2 * BK) == 0) return launch_t<64, 64, 2>(a, (int)T, grid, s);
         return launch_t<BM, BN>(a, (int)T, grid, s);
     }
     // full rounds with this tile; the remaining M-panels go to a smaller tile (see header)

@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--prec", type=int, default=0, choices=[0, 1, 3])
     ap.add_argument("--no-dma", action="store_true", help="bf16 modes: the VGPR-staged operand pipe of round 1")
     ap.add_argument("--prefetch", default="-1", help="bf16 LDS-direct pipe: A-prefetch look-ahead(s) in slices, comma separated")
+    ap.add_argument("--no-prefetch", action="store_true", help="fp32: without the A-panel prefetch")
     ap.add_argument("--fmt", type=int, default=0, help="bit 0: A, bit 1: resid, bit 2: C in the split-pair format (timing only)")
     ap.add_argument("--rows", type=int, default=0, help="override M of the edge-row shapes (e.g. 8192: operands stay in L2)")
     a = ap.parse_args()
@@ -75,7 +76,7 @@ def main():
                                      L.ptr(R), Nn if resid else 0, 1.0,
                                      L.ptr(G0), L.ptr(gi), 2 * Nn if gather else 0,
                                      (G0.data_ptr() + 4 * Nn) if gather else 0, L.ptr(gi), 2 * Nn if gather else 0,
-                                     0, 1, L.stream_ptr()))
+                                     2 if a.no_prefetch else 0, 1, L.stream_ptr()))
         variants = [("", run)] if not a.prec else [(f" pf={d}", (lambda d=d: run_planes(int(d)))) for d in a.prefetch.split(",")]
         for tag, fn in variants:
             for _ in range(3):

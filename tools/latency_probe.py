@@ -26,10 +26,12 @@ def main():
     ap.add_argument("--scenes", type=int, default=60)
     ap.add_argument("--points", type=int, default=256)
     ap.add_argument("--layers", type=int, default=3)
+    ap.add_argument("--gemm-precision", default="fp32", choices=["fp32", "bf16x3", "bf16_mixed", "bf16"])
+    ap.add_argument("--single-only", action="store_true", help="skip the all-scenes-in-one-call comparison (clean kernel traces)")
     a = ap.parse_args()
     dev = "cuda:0"
     cfg = VLSATConfig(N_LAYERS=a.layers)
-    model = VLSATModel(cfg, dev).load_state(synth.make_weights(cfg)).eval()
+    model = VLSATModel(cfg, dev).load_state(synth.make_weights(cfg)).eval().set_gemm_precision(a.gemm_precision)
     rng = np.random.default_rng(5)
     sizes = rng.integers(9, 81, a.scenes)
     scenes = [synth.make_scene(int(n), a.points, seed=100 + i) for i, n in enumerate(sizes)]
@@ -93,6 +95,8 @@ def main():
     print(f"  fresh tensors + fc_sizes hint, new sizes build a plan: {hi.mean():6.2f} ms mean ({np.median(hi):.2f} median)")
     print(f"  back to back, no host sync between scenes: {t_pipe * 1e3:6.2f} ms per scene")
     print(f"  plan cache: {model.plan_stats}")
+    if a.single_only:
+        return
     big = to_dev(synth.collate(scenes))
     call(big)
     torch.cuda.synchronize()
