@@ -22,7 +22,8 @@ namespace {
 constexpr int GB_P0 = 144;      // W0k plane row pitch (64 bf16 + 16 B)
 constexpr int GB_P3 = 264;      // W3 plane row pitch (128 bf16 + 8 B: the 32 rows of a ds_read_b64 land on 32 different bank pairs)
 
-template <int TERMS, bool KS>
+// KS: format of kproj -- 0 fp32, 1 split-pair words, 2 half rows (bf16; TERMS = 1)
+template <int TERMS, int KS>
 __global__ __launch_bounds__(256, 2) void edge_gate_bf16_kernel(GateArgs p) {
     constexpr int PL = TERMS == 1 ? 1 : 2;
     constexpr int W0B = 128 * GB_P0, W3B = 32 * GB_P3;
@@ -65,8 +66,13 @@ __global__ __launch_bounds__(256, 2) void edge_gate_bf16_kernel(GateArgs p) {
             const float* zrow = p.kproj + (size_t)e * 512 + h * 64 + 8 * hi;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
+                if (KS == 2) {                            // eight bf16 = one 16-byte load
+                    zh[ks] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(p.kproj + (size_t)e * 512) + (h * 64 + 8 * hi + 16 * ks) * 2);
+                    zl[ks] = zh[ks];
+                    continue;
+                }
                 const f32x4 x0 = *reinterpret_cast<const f32x4*>(zrow + 16 * ks), x1 = *reinterpret_cast<const f32x4*>(zrow + 16 * ks + 4);
-                if (KS) {
+                if (KS == 1) {
                     const u32x4 a = __builtin_bit_cast(u32x4, x0), b = __builtin_bit_cast(u32x4, x1);
                     u32x4 hh, ll;
                     hh[0] = __builtin_amdgcn_perm(a[1], a[0], 0x07060302u); hh[1] = __builtin_amdgcn_perm(a[3], a[2], 0x07060302u);
@@ -180,8 +186,9 @@ int launch_edge_gate_bf16(const GateArgs& a, int terms, int kproj_split, hipStre
     const int cap = a.grid_cap > 0 ? a.grid_cap : 768;            // persistent grid (weights staged once per block)
     const int grid = n_groups < cap ? n_groups : cap;
 #define VLSAT_GB(T, K) hipLaunchKernelGGL((edge_gate_bf16_kernel<T, K>), dim3(grid), dim3(256), 0, s, a)
-    if (terms == 3) { if (kproj_split) VLSAT_GB(3, true); else VLSAT_GB(3, false); }
-    else            { if (kproj_split) VLSAT_GB(1, true); else VLSAT_GB(1, false); }
+    if (kproj_split == 2 && terms != 1) return fail(-1, "edge_gate_bf16: half-row kproj needs terms = 1");
+    if (terms == 3) { if (kproj_split) VLSAT_GB(3, 1); else VLSAT_GB(3, 0); }
+    else            { if (kproj_split == 2) VLSAT_GB(1, 2); else if (kproj_split) VLSAT_GB(1, 1); else VLSAT_GB(1, 0); }
 #undef VLSAT_GB
     VLSAT_LAUNCH_CHECK("edge_gate_bf16");
     return 0;

@@ -82,6 +82,7 @@ struct vlsat_ctx {
     double acc_fl[vlsat::PC_COUNT] = {0};
     int debug_stop = -1;
     int gemm_no_dma = 0, gate_grid = 0;      // vlsat_debug_option
+    int half_fmt = 1;                        // single-rounding modes: those tensors as plain bf16 (half rows) instead of split pairs
     int split_fmt = 1;                       // bf16 modes: edge tensors between matrix kernels in the split-pair format
     int pointnet_bf16 = 1, gate_bf16 = 1;    // bf16 modes: object encoder / edge gate on the bf16 matrix cores
     int flash_bf16 = 1, flash_tr = 1;        // bf16 modes: attention on the bf16 matrix cores / V operand by LDS transpose read

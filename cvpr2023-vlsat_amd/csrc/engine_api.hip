@@ -39,6 +39,7 @@ int vlsat_set_edge_attention_scope(vlsat_handle h, int32_t scope) {
 //   "gemm_dma"    0|1   LDS-direct staging of fp32 GEMM operands (0: VGPR-staged)
 //   "gate_grid"   n     persistent grid of the gate kernel (0: default)
 //   "split_fmt"   0|1   bf16 modes: edge tensors between matrix kernels as bf16 hi/lo pairs (0: plain fp32, split on read)
+//   "half_fmt"    0|1   single-rounding modes: those tensors as plain bf16 at half the traffic (0: split pairs)
 //   "flash_bf16"  0|1   bf16 modes: edge attention on the bf16 matrix cores (0: keep the fp32 kernel)
 //   "pointnet_bf16", "gate_bf16" 0|1   bf16 modes: object encoder / edge gate on the bf16 matrix cores (0: fp32 kernels)
 //   "flash_tr"    0|1   bf16 attention: V operand by ds_read_b64_tr_b16 (0: ds_read_u16 gather)
@@ -50,6 +51,7 @@ int vlsat_debug_option(vlsat_handle h, const char* name, int32_t value) {
     else if (k == "gemm_dma") h->gemm_no_dma = value == 0;
     else if (k == "gate_grid") h->gate_grid = value > 0 ? value : 0;
     else if (k == "split_fmt") h->split_fmt = value != 0;
+    else if (k == "half_fmt") h->half_fmt = value != 0;
     else if (k == "flash_bf16") h->flash_bf16 = value != 0;
     else if (k == "pointnet_bf16") h->pointnet_bf16 = value != 0;
     else if (k == "gate_bf16") h->gate_bf16 = value != 0;
@@ -91,7 +93,8 @@ int vlsat_k_gemm_planes(const float* A, int32_t lda, const float* W, const uint1
     a.bias = bias; a.resid = resid; a.ldr = ldr; a.resid_scale = resid_scale;
     a.g0 = g0; a.gi0 = gi0; a.ldg0 = ldg0; a.g1 = g1; a.gi1 = gi1; a.ldg1 = ldg1; a.relu_a = relu_a; a.act = act;
     a.prec = prec; a.Whi = Whi; a.Wlo = Wlo; a.no_dma = no_dma; a.prefetch = prefetch;
-    a.a_split = fmt & 1; a.r_split = (fmt >> 1) & 1; a.c_split = (fmt >> 2) & 1; a.c_scale = c_scale;
+    const int code = (fmt >> 5) & 1 ? 2 : 1;   // (bit 5: the flagged operands are half rows instead of split pairs)
+    a.a_split = (fmt & 1) * code; a.r_split = ((fmt >> 1) & 1) * code; a.c_split = ((fmt >> 2) & 1) * code; a.c_scale = c_scale;
     a.k_rotate = (fmt >> 3) & 1;               // (bit 3: k rotation, bit 4: no ring kernel -- benchmarking)
     a.no_ring = (fmt >> 4) & 1;
     return launch_gemm(a, static_cast<hipStream_t>(stream));
@@ -158,7 +161,7 @@ int vlsat_k_flash_attn_bf16(const float* Q, const float* K, const float* V, floa
     VLSAT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d), tiles.size() * sizeof(int4)));
     VLSAT_HIP_CHECK(hipMemcpy(d, tiles.data(), tiles.size() * sizeof(int4), hipMemcpyHostToDevice));
     int r = launch_flash_attn_bf16(Q, ld, K, V, ld, O, ld, d, (int)tiles.size(), scale * 1.4426950408889634f, terms, use_tr != 0,
-                                   use_tr == 2, st);
+                                   use_tr == 2 ? 1 : use_tr == 3 ? 2 : 0, st);
     hipStreamSynchronize(st);     // test entry point only: the tile table is freed right away
     hipFree(d);
     return r;

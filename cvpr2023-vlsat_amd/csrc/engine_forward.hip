@@ -22,9 +22,14 @@ namespace {
 // separate hi / lo with two v_perm_b32 instead of re-splitting fp32 on every fragment read.  Not with
 // MODEL.feature_transform (its encoder chain keeps fp32 rows) and not when a debug option disabled one of the kernels
 // that understand the format.
-static bool split_fmt(const vlsat_ctx* h) {
-    return h->prec_edge != 0 && h->split_fmt && h->flash_bf16 && h->flash_tr && !h->gemm_no_dma && !h->d.feature_transform &&
-           default_heads(h);
+// Returns the format code: 0 fp32, 1 split-pair words (split-bf16 mode), 2 half rows = plain bf16 at half the HBM
+// traffic (single-rounding modes, whose kernels never read a low part).
+static int split_fmt(const vlsat_ctx* h) {
+    const bool on = h->prec_edge != 0 && h->split_fmt && h->flash_bf16 && h->flash_tr && !h->gemm_no_dma && !h->d.feature_transform &&
+                    default_heads(h);
+    if (!on) return 0;
+    if (h->prec_edge == 3) return 1;
+    return h->gate_bf16 && h->half_fmt ? 2 : 1;
 }
 
 // ---- profiling helpers ----
@@ -75,7 +80,8 @@ static void profile_close(vlsat_ctx* h, hipStream_t s) {
 // weights were made when the mode was set (engine_weights.hip), so nothing is allocated or converted here.
 int gemm(vlsat_ctx* h, hipStream_t s, const GemmArgs& a0) {
     GemmArgs a = a0;
-    const int prec = a.M == h->cur_N ? h->prec_node : h->prec_edge;
+    const bool edge_fmt = a.a_split || a.c_split || a.r_split;            // tensors in an edge format: an edge-row launch whatever M is
+    const int prec = (a.M == h->cur_N && !edge_fmt) ? h->prec_node : h->prec_edge;
     if (prec) {
         auto it = h->split.find(a.W);
         if (it == h->split.end()) return fail(VLSAT_ESTATE, "gemm: weight has no bf16 planes (set the precision after loading weights)");
@@ -135,7 +141,7 @@ int gcn_block(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const GcnW& w, float
         GemmArgs kp = G(e, D, w.wpe, D, sc.KP, D, E, D, w.bpe);
         kp.relu_a = e_relu_pending;
         kp.a_split = S;
-        kp.c_split = S && gate16;         // (the fp32 gate kernel reads plain fp32)
+        kp.c_split = gate16 ? S : 0;      // (the fp32 gate kernel reads plain fp32)
         RUN(gemm(h, s, kp));
     }
     GemmArgs e2 = G(sc.Hbig, 2 * D, w.we2, 2 * D, e, D, E, D, w.be2);       // e <- nn_edge output (pre-activation)
@@ -403,8 +409,8 @@ static int forward_impl(vlsat_handle h, vlsat_plan p, const float* pts, const fl
                                          h->edge_scope == 1 ? 1 : p->S, h->edge_scope == 1 ? E : p->max_e, h->H, D / h->H,
                                          1.f / std::sqrt((float)(D / h->H)), s));
                 else if (h->prec_edge && h->flash_bf16)
-                    RUN(launch_flash_attn_bf16(p->Qe, D, p->KVe, p->KVe + D, 2 * D, p->Oe, D, p->d_tiles, p->n_tiles, sc2e,
-                                               h->prec_edge == 3 ? 3 : 1, h->flash_tr, S, s, &sp));
+                    RUN(launch_flash_attn_bf16(p->Qe, D, p->KVe, p->KVe + (S == 2 ? D / 2 : D), 2 * D, p->Oe, D, p->d_tiles, p->n_tiles,
+                                               sc2e, h->prec_edge == 3 ? 3 : 1, h->flash_tr, S, s, &sp));    // (half rows: V starts at byte 2 D)
                 else
                     RUN(launch_flash_attn(p->Qe, D, p->KVe, p->KVe + D, 2 * D, p->Oe, D, p->d_tiles, p->n_tiles, sc2e, s, &sp));
             }

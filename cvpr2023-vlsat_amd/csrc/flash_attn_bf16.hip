@@ -45,9 +45,9 @@ __device__ __forceinline__ void split4(const f32x4& x, bf16x4& hi, bf16x4& lo) {
 }
 // four elements of an operand tensor -> bf16 hi / lo.  IO_S: the tensor is in the split-pair format (common.h
 // pack_split; written by the projection GEMMs' epilogues in the bf16 modes), so this is two v_perm_b32 per plane
-template <bool IO_S>
+template <int IO>
 __device__ __forceinline__ void planes4(const f32x4& x, bf16x4& hi, bf16x4& lo) {
-    if (IO_S) {
+    if (IO == 1) {
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
         const u32x4 w = __builtin_bit_cast(u32x4, x);
@@ -61,8 +61,31 @@ __device__ __forceinline__ void planes4(const f32x4& x, bf16x4& hi, bf16x4& lo) 
     }
 }
 
-// IO_S: Q, K, V arrive and O leaves in the split-pair format; Q is then already multiplied by scale * log2 e
-template <int TERMS, bool TR, bool IO_S>
+// four consecutive elements of a row, whatever the tensor format: IO = 0 fp32, 1 split-pair words (16 bytes each way),
+// 2 half rows (8 bytes: four bf16, returned in the low half of the f32x4)
+template <int IO>
+__device__ __forceinline__ f32x4 load4(const float* row, size_t col) {
+    if (IO == 2) {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 v = *reinterpret_cast<const f32x2*>(reinterpret_cast<const char*>(row) + col * 2);
+        return f32x4{v[0], v[1], 0.f, 0.f};
+    }
+    return *reinterpret_cast<const f32x4*>(row + col);
+}
+template <int IO>
+__device__ __forceinline__ void planes_of(const f32x4& x, bf16x4& hi, bf16x4& lo) {
+    if (IO == 2) {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        hi = __builtin_bit_cast(bf16x4, f32x2{x[0], x[1]});
+        lo = hi;                                   // (never read: TERMS = 1)
+    } else {
+        planes4<IO>(x, hi, lo);
+    }
+}
+
+// IO = 1 / 2: Q, K, V arrive and O leaves in the split-pair / half-row format; Q is then already multiplied by
+// scale * log2 e (the projection GEMM's epilogue did it)
+template <int TERMS, bool TR, int IO>
 __global__ __launch_bounds__(256, 2) void flash_attn_bf16_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
     float* __restrict__ O, int ldq, int ldkv, int ldo, const int4* __restrict__ tiles, int n_tiles,
@@ -88,17 +111,17 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bf16_kernel(
     // ---- this lane's query: d = 16 ks + 8 hi + e, pre-scaled, split into bf16 hi / lo ----
     bf16x8 qh[4], ql[4];
     {
-        const float* qp = Q + (size_t)(row_base + qrow) * ldq + col0 + 8 * hi;
+        const float* qrowp = Q + (size_t)(row_base + qrow) * ldq;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            f32x4 x0 = *reinterpret_cast<const f32x4*>(qp + 16 * ks), x1 = *reinterpret_cast<const f32x4*>(qp + 16 * ks + 4);
-            if (!IO_S) {
+            f32x4 x0 = load4<IO>(qrowp, col0 + 8 * hi + 16 * ks), x1 = load4<IO>(qrowp, col0 + 8 * hi + 16 * ks + 4);
+            if (IO == 0) {
                 x0 *= scale_log2e;
                 x1 *= scale_log2e;
             }
             bf16x4 h0, l0, h1, l1;
-            planes4<IO_S>(x0, h0, l0);
-            planes4<IO_S>(x1, h1, l1);
+            planes_of<IO>(x0, h0, l0);
+            planes_of<IO>(x1, h1, l1);
             qh[ks] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
             ql[ks] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
         }
@@ -119,21 +142,21 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bf16_kernel(
         for (int i = 0; i < 4; ++i) {
             int r = kv0 + krow + 16 * i;
             r = r < n_tok ? r : n_tok - 1;
-            rk[i] = *reinterpret_cast<const f32x4*>(K + (size_t)(row_base + r) * ldkv + col0 + kc4);
+            rk[i] = load4<IO>(K + (size_t)(row_base + r) * ldkv, col0 + kc4);
             int rv_ = kv0 + vkey + 16 * i;
             rv_ = rv_ < n_tok ? rv_ : n_tok - 1;
-            rv[i] = *reinterpret_cast<const f32x4*>(V + (size_t)(row_base + rv_) * ldkv + col0 + vc4);
+            rv[i] = load4<IO>(V + (size_t)(row_base + rv_) * ldkv, col0 + vc4);
         }
     };
     auto store_tile = [&](char* buf) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             bf16x4 h, l;
-            planes4<IO_S>(rk[i], h, l);
+            planes_of<IO>(rk[i], h, l);
             char* kp = buf + (krow + 16 * i) * FB_KPITCH + kc4 * 2;
             *reinterpret_cast<bf16x4*>(kp) = h;
             if (PL == 2) *reinterpret_cast<bf16x4*>(kp + FB_KPLANE) = l;
-            planes4<IO_S>(rv[i], h, l);
+            planes_of<IO>(rv[i], h, l);
             char* vp = buf + PL * FB_KPLANE + vsub * FB_VSUB + (vkey + 16 * i) * 32 + (lane & 3) * 8;
             *reinterpret_cast<bf16x4*>(vp) = h;
             if (PL == 2) *reinterpret_cast<bf16x4*>(vp + FB_VPLANE) = l;
@@ -160,19 +183,24 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bf16_kernel(
             // ---- S^T[key][query] = sum_d K[key][d] * Q[query][d], two blocks of 32 keys ----
             f32x16 s[2];
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
-                const char* kp = sK + (32 * kb + li) * FB_KPITCH + 16 * hi;
+            for (int r = 0; r < 16; ++r) { s[0][r] = 0.f; s[1][r] = 0.f; }
+            {
+                // the two 32-key blocks alternate, so consecutive MFMAs never wait for each other's accumulator
+                const char* kp = sK + li * FB_KPITCH + 16 * hi;
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
-                    const bf16x8 kh = *reinterpret_cast<const bf16x8*>(kp + 32 * ks);
+                    const bf16x8 kh0 = *reinterpret_cast<const bf16x8*>(kp + 32 * ks);
+                    const bf16x8 kh1 = *reinterpret_cast<const bf16x8*>(kp + 32 * FB_KPITCH + 32 * ks);
                     if (PL == 2) {
-                        const bf16x8 kl = *reinterpret_cast<const bf16x8*>(kp + FB_KPLANE + 32 * ks);
-                        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[ks], s[kb], 0, 0, 0);
-                        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[ks], s[kb], 0, 0, 0);
+                        const bf16x8 kl0 = *reinterpret_cast<const bf16x8*>(kp + FB_KPLANE + 32 * ks);
+                        const bf16x8 kl1 = *reinterpret_cast<const bf16x8*>(kp + FB_KPLANE + 32 * FB_KPITCH + 32 * ks);
+                        s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl0, qh[ks], s[0], 0, 0, 0);
+                        s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl1, qh[ks], s[1], 0, 0, 0);
+                        s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh0, ql[ks], s[0], 0, 0, 0);
+                        s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh1, ql[ks], s[1], 0, 0, 0);
                     }
-                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[ks], s[kb], 0, 0, 0);
+                    s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh0, qh[ks], s[0], 0, 0, 0);
+                    s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh1, qh[ks], s[1], 0, 0, 0);
                 }
             }
             // keys outside [key_lo, key_hi): beyond the scene's tokens (last tile) or another part's (split mode)
@@ -223,9 +251,9 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bf16_kernel(
                 const bf16x8 ph = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
                 const bf16x8 pl = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
                 const int k0 = 32 * kb + 16 * half + 4 * hi;          // first key of this lane half's k-slots (then +8)
+                bf16x8 vf[2][PL];
 #pragma unroll
-                for (int db = 0; db < 2; ++db) {
-                    bf16x8 vf[PL];
+                for (int db = 0; db < 2; ++db)
 #pragma unroll
                     for (int pln = 0; pln < PL; ++pln) {
                         const char* vb = sV + pln * FB_VPLANE + (2 * db + ((lane >> 4) & 1)) * FB_VSUB;
@@ -236,23 +264,25 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bf16_kernel(
                             const s16x4 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                                 (s16x4 __attribute__((address_space(3)))*)(a + 8 * 32));
                             const bf16x4 b0 = __builtin_bit_cast(bf16x4, x0), b1 = __builtin_bit_cast(bf16x4, x1);
-                            vf[pln] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+                            vf[db][pln] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
                         } else {
                             const unsigned short* g = reinterpret_cast<const unsigned short*>(vb) + (lane & 15);
                             typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
                             u16x8 u;
 #pragma unroll
                             for (int e = 0; e < 8; ++e) u[e] = g[(k0 + 8 * (e >> 2) + (e & 3)) * 16];
-                            vf[pln] = __builtin_bit_cast(bf16x8, u);
+                            vf[db][pln] = __builtin_bit_cast(bf16x8, u);
                         }
                     }
-                    f32x16& o = db ? o1 : o0;
-                    if (PL == 2) {
-                        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[PL - 1], ph, o, 0, 0, 0);
-                        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pl, o, 0, 0, 0);
-                    }
-                    o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], ph, o, 0, 0, 0);
+                // the two d-blocks alternate (independent accumulators back to back)
+                if (PL == 2) {
+                    o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0][PL - 1], ph, o0, 0, 0, 0);
+                    o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1][PL - 1], ph, o1, 0, 0, 0);
+                    o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0][0], pl, o0, 0, 0, 0);
+                    o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1][0], pl, o1, 0, 0, 0);
                 }
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0][0], ph, o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1][0], ph, o1, 0, 0, 0);
             }
         }   // wave_active
         if (more) store_tile(smem + ((kt + 1) & 1) * BUF);
@@ -276,8 +306,8 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bf16_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const float a = o0[r] * inv_l, b = o1[r] * inv_l;
-        so[li * FB_OPITCH + crow32(r, hi)] = (IO_S && !split) ? pack_split(a) : a;       // (split-key partials stay fp32: the merge packs)
-        so[li * FB_OPITCH + 32 + crow32(r, hi)] = (IO_S && !split) ? pack_split(b) : b;
+        so[li * FB_OPITCH + crow32(r, hi)] = (IO == 1 && !split) ? pack_split(a) : a;       // (split-key partials stay fp32: the merge packs)
+        so[li * FB_OPITCH + 32 + crow32(r, hi)] = (IO == 1 && !split) ? pack_split(b) : b;
     }
     __syncthreads();
 #pragma unroll
@@ -285,9 +315,14 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bf16_kernel(
         const int idx = lane + 64 * i;             // 512 float4 = 32 rows x 16
         const int r = idx >> 4, c4 = (idx & 15) * 4;
         const int qr = q0 + wave * 32 + r;
-        if (qr < n_tok)
-            *reinterpret_cast<f32x4*>(O + (size_t)(row_base + qr) * ldo + col0 + c4) =
-                *reinterpret_cast<const f32x4*>(so + r * FB_OPITCH + c4);
+        if (qr < n_tok) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(so + r * FB_OPITCH + c4);
+            float* orow = O + (size_t)(row_base + qr) * ldo;
+            if (IO == 2 && !split)
+                *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(orow) + (col0 + c4) * 2) = __builtin_convertvector(v, bf16x4);
+            else
+                *reinterpret_cast<f32x4*>(orow + col0 + c4) = v;
+        }
     }
 }
 
@@ -306,11 +341,14 @@ int launch_flash_attn_bf16(const float* Q, int ldq, const float* K, const float*
             return fail(-1, "flash_attn: incomplete split-key workspace");
     }
 #define VLSAT_FA(T, R, S) hipLaunchKernelGGL((flash_attn_bf16_kernel<T, R, S>), dim3(n_tiles), dim3(256), 0, s, Q, K, V, O, ldq, ldkv, ldo, tiles, n_tiles, scale_log2e, sp)
-    if (io_split) {
+    if (io_split == 2) {
+        if (!use_tr || terms != 1) return fail(-1, "flash_attn_bf16: half-row tensors need terms = 1 and the transpose-read path");
+        VLSAT_FA(1, true, 2);
+    } else if (io_split) {
         if (!use_tr) return fail(-1, "flash_attn_bf16: the split-pair format is built for the transpose-read path only");
-        if (terms == 3) VLSAT_FA(3, true, true); else VLSAT_FA(1, true, true);
-    } else if (terms == 3) { if (use_tr) VLSAT_FA(3, true, false); else VLSAT_FA(3, false, false); }
-    else                   { if (use_tr) VLSAT_FA(1, true, false); else VLSAT_FA(1, false, false); }
+        if (terms == 3) VLSAT_FA(3, true, 1); else VLSAT_FA(1, true, 1);
+    } else if (terms == 3) { if (use_tr) VLSAT_FA(3, true, 0); else VLSAT_FA(3, false, 0); }
+    else                   { if (use_tr) VLSAT_FA(1, true, 0); else VLSAT_FA(1, false, 0); }
 #undef VLSAT_FA
     VLSAT_LAUNCH_CHECK("flash_attn_bf16");
     if (sp.parts > 1) return launch_flash_merge(O, ldo, sp, s, io_split);

@@ -216,7 +216,12 @@ __global__ __launch_bounds__(256) void flash_merge_kernel(float* __restrict__ O,
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         acc[c] *= inv;
-        if (out_split) acc[c] = pack_split(acc[c]);
+        if (out_split == 1) acc[c] = pack_split(acc[c]);
+    }
+    if (out_split == 2) {                               // half rows
+        typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<bf16x4_t*>(reinterpret_cast<char*>(O + row * ldo) + c4 * 8) = __builtin_convertvector(acc, bf16x4_t);
+        return;
     }
     *reinterpret_cast<f32x4*>(O + row * ldo + c4 * 4) = acc;
 }

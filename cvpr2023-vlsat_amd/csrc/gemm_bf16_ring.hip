@@ -32,14 +32,15 @@ namespace {
 
 constexpr int RBM = 256, RBN = 128, RST = 3;
 
-template <int TERMS, bool AS, int ADD>
+template <int TERMS, int AFMT, int ADD>
 __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmArgs p, int n_tiles, int nbn) {
-    using Frag = PipeSplitDma<128, 128, TERMS, AS>;          // fragment-side helpers only (split8)
+    using Frag = PipeSplitDma<128, 128, TERMS, AFMT>;        // fragment-side helpers only (split8 / frag_half)
+    constexpr bool AH = AFMT == 2;                           // A as half rows (bf16): 64-byte slices like the weight planes
     constexpr int PL = TERMS == 1 ? 1 : 2;
     constexpr int TM = 2, TN = 2;
-    constexpr int A_BYTES = RBM * BK * 4, W_PLANE = RBN * BK * 2;
-    constexpr int STAGE = A_BYTES + PL * W_PLANE;            // 48 KB (40 KB with one plane)
-    constexpr int LPS = 4 + PL;                              // LDS-direct loads per wave per slice
+    constexpr int A_BYTES = AH ? RBM * BK * 2 : RBM * BK * 4, W_PLANE = RBN * BK * 2;
+    constexpr int STAGE = A_BYTES + PL * W_PLANE;            // 48 KB (40 KB with one plane, 24 KB with half-row A)
+    constexpr int LPS = (AH ? 2 : 4) + PL;                   // LDS-direct loads per wave per slice
     __shared__ __attribute__((aligned(16))) char smem[RST * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -52,19 +53,28 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmArgs p, int n_til
     if (tile_of_round(0) >= n_tiles) return;
 
     // ---- LDS-direct loader state (per lane) ----
-    const int na = (int)(((size_t)(p.M - 1) * p.lda + p.K) * 4), nw = (int)(((size_t)(p.N - 1) * p.ldw + p.K) * 2);
+    const int nw = (int)(((size_t)(p.N - 1) * p.ldw + p.K) * 2);
+    const int na = AH ? (int)((size_t)(p.M - 1) * p.lda * 4 + (size_t)p.K * 2) : (int)(((size_t)(p.M - 1) * p.lda + p.K) * 4);
     const int arow = 8 * wave + (lane >> 3);                                  // row inside a 64-row instruction group
-    const unsigned va = (unsigned)(arow * p.lda + 4 * ((lane & 7) ^ ((arow >> 1) & 7))) * 4u;
     const int wrow = 16 * wave + (lane >> 2);                                 // (wrow >> 2) & 3 == (lane >> 4) & 3
+    const unsigned va = AH ? (unsigned)(wrow * p.lda * 4 + 16 * ((lane & 3) ^ ((lane >> 4) & 3)))
+                           : (unsigned)(arow * p.lda + 4 * ((lane & 7) ^ ((arow >> 1) & 7))) * 4u;
     const unsigned vw = (unsigned)(wrow * p.ldw + 8 * ((lane & 3) ^ ((lane >> 4) & 3))) * 2u;
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, na, 0x00020000);
     const __amdgpu_buffer_rsrc_t rwh = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.Whi), 0, nw, 0x00020000);
     const __amdgpu_buffer_rsrc_t rwl = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(PL == 2 ? p.Wlo : p.Whi), 0, nw, 0x00020000);
     auto issue = [&](int m0, int n0, int k0, char* stage) {
-        float* sa = reinterpret_cast<float*>(stage) + wave * 8 * BK;
+        if (AH) {                     // 256 rows x 64 B: 16 rows per instruction, 8 waves -> 128 rows per round, two rounds
+            char* sa = stage + wave * 16 * BK * 2;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, sa + i * 64 * BK, 16, va + (unsigned)(((m0 + 64 * i) * p.lda + k0) * 4), 0, 0, 0);
+            for (int i = 0; i < 2; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, sa + i * 128 * BK * 2, 16, va + (unsigned)((m0 + 128 * i) * p.lda * 4 + k0 * 2), 0, 0, 0);
+        } else {
+            float* sa = reinterpret_cast<float*>(stage) + wave * 8 * BK;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, sa + i * 64 * BK, 16, va + (unsigned)(((m0 + 64 * i) * p.lda + k0) * 4), 0, 0, 0);
+        }
         char* sw = stage + A_BYTES + wave * 16 * BK * 2;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rwh, sw, 16, vw + (unsigned)((n0 * p.ldw + k0) * 2), 0, 0, 0);
         if (PL == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rwl, sw + W_PLANE, 16, vw + (unsigned)((n0 * p.ldw + k0) * 2), 0, 0, 0);
@@ -108,8 +118,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmArgs p, int n_til
                         if (m0 + ml >= p.M) ml = p.M - 1 - m0;
                         float x = 0.f;
                         if (ADD & 1) {
-                            const float rv = rbase[(unsigned)(ml * ldr + nl)];
-                            x = p.resid_scale * (p.r_split ? unpack_split(rv) : rv);
+                            x = p.resid_scale * load_resid(p, rbase, ml, nl, ldr, n0);
                         }
                         if (ADD & 2) x += p.g0[(unsigned)(p.gi0[m0 + ml] * ldg0 + n0 + nl)];
                         if (ADD & 4) x += p.g1[(unsigned)(p.gi1[m0 + ml] * ldg1 + n0 + nl)];
@@ -121,7 +130,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmArgs p, int n_til
             // this wave's part of the current slice has landed (at most one younger slice stays in flight) ...
             if (ahead >= 2) {
                 if (LPS == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                else if (LPS == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -132,6 +142,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmArgs p, int n_til
             const char* stage = smem + cbuf * STAGE;
             cbuf = cbuf == RST - 1 ? 0 : cbuf + 1;
             const float* sA = reinterpret_cast<const float*>(stage) + (wm * 64 + li) * BK;
+            const char* sAh = stage + (wm * 64 + li) * BK * 2;
             const char* sW = stage + A_BYTES + (wn * 64 + li) * BK * 2;
             const int swa = (li >> 1) & 7, sww = (li >> 2) & 3;
             auto slice = [&](auto relu_tag) {
@@ -141,26 +152,38 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmArgs p, int n_til
                     bf16x8 a[PL][TM], w[PL][TN];
 #pragma unroll
                     for (int tm = 0; tm < TM; ++tm) {
-                        const int c0 = (4 * ks + 2 * hi) ^ swa;
-                        const f32x4 x0 = *reinterpret_cast<const f32x4*>(sA + tm * 32 * BK + 4 * c0);
-                        const f32x4 x1 = *reinterpret_cast<const f32x4*>(sA + tm * 32 * BK + 4 * (c0 ^ 1));
-                        Frag::template split8<RELU>(x0, x1, a[0][tm], a[PL - 1][tm]);
+                        if (AH) {
+                            a[0][tm] = Frag::template frag_half<RELU>(sAh + tm * 32 * BK * 2 + 16 * ((2 * ks + hi) ^ sww));
+                        } else {
+                            const int c0 = (4 * ks + 2 * hi) ^ swa;
+                            const f32x4 x0 = *reinterpret_cast<const f32x4*>(sA + tm * 32 * BK + 4 * c0);
+                            const f32x4 x1 = *reinterpret_cast<const f32x4*>(sA + tm * 32 * BK + 4 * (c0 ^ 1));
+                            Frag::template split8<RELU>(x0, x1, a[0][tm], a[PL - 1][tm]);
+                        }
                     }
 #pragma unroll
                     for (int pl = 0; pl < PL; ++pl)
 #pragma unroll
                         for (int tn = 0; tn < TN; ++tn)
                             w[pl][tn] = *reinterpret_cast<const bf16x8*>(sW + pl * W_PLANE + tn * 32 * BK * 2 + 16 * ((2 * ks + hi) ^ sww));
+                    // term-major order: the four accumulators take turns (no MFMA waits for its predecessor)
+                    if (PL == 2) {
+#pragma unroll
+                        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                            for (int tn = 0; tn < TN; ++tn)
+                                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][tm], w[0][tn], acc[tm][tn], 0, 0, 0);
+#pragma unroll
+                        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                            for (int tn = 0; tn < TN; ++tn)
+                                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][tm], w[PL - 1][tn], acc[tm][tn], 0, 0, 0);
+                    }
 #pragma unroll
                     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                        for (int tn = 0; tn < TN; ++tn) {
-                            if (PL == 2) {
-                                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][tm], w[0][tn], acc[tm][tn], 0, 0, 0);
-                                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][tm], w[PL - 1][tn], acc[tm][tn], 0, 0, 0);
-                            }
+                        for (int tn = 0; tn < TN; ++tn)
                             acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][tm], w[0][tn], acc[tm][tn], 0, 0, 0);
-                        }
                 }
             };
             if (p.relu_a) slice(std::true_type{});
@@ -206,6 +229,17 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmArgs p, int n_til
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[tm][tn][r] *= p.c_scale;
         }
+        if (p.c_split == 2) {
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ml = (wm * TM + tm) * 32 + crow32(r, h2), nl = (wn * TN + tn) * 32 + l2;
+                        if (m0 + ml < p.M && n0 + nl < p.N) store_half(cbase, ml, nl, ldc, n0, acc[tm][tn][r]);
+                    }
+        } else {
         if (p.c_split) {
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
@@ -235,6 +269,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmArgs p, int n_til
                         if (m0 + ml < p.M && n0 + nl < p.N) cbase[(unsigned)(ml * ldc + nl)] = acc[tm][tn][r];
                     }
         }
+        }
         zero_acc<TM, TN>(acc);
     }
 }
@@ -254,8 +289,12 @@ int launch_gemm_ring(const GemmArgs& a, int n_tiles, int grid, hipStream_t s) {
         case 1: VLSAT_RING(T, S, 1); break;       \
         default: VLSAT_RING(T, S, 6); break;      \
     }
-    if (a.prec == 3) { if (a.a_split) { VLSAT_RING_ADD(3, true) } else { VLSAT_RING_ADD(3, false) } }
-    else             { if (a.a_split) { VLSAT_RING_ADD(1, true) } else { VLSAT_RING_ADD(1, false) } }
+    if (a.prec == 3) {
+        if (a.a_split == 2) return 1;
+        if (a.a_split) { VLSAT_RING_ADD(3, 1) } else { VLSAT_RING_ADD(3, 0) }
+    } else {
+        if (a.a_split == 2) { VLSAT_RING_ADD(1, 2) } else if (a.a_split) { VLSAT_RING_ADD(1, 1) } else { VLSAT_RING_ADD(1, 0) }
+    }
 #undef VLSAT_RING_ADD
 #undef VLSAT_RING
     if (a.launches) ++*a.launches;

@@ -20,6 +20,22 @@
 namespace vlsat {
 
 constexpr int BK = 32;    // k-slice held in LDS per pipeline stage
+
+// residual element (ml, nl) of the tile whose first element is rbase = resid + m0 * ldr + n0, in the operand's format:
+// 0 fp32, 1 split-pair word, 2 half row (bf16 at byte 2 * column of the fp32-pitched row)
+__device__ __forceinline__ float load_resid(const GemmArgs& p, const float* rbase, int ml, int nl, int ldr, int n0) {
+    if (p.r_split == 2) {
+        const unsigned short* row = reinterpret_cast<const unsigned short*>(rbase - n0 + (size_t)ml * ldr);
+        return __uint_as_float((unsigned)row[n0 + nl] << 16);
+    }
+    const float rv = rbase[(unsigned)(ml * ldr + nl)];
+    return p.r_split ? unpack_split(rv) : rv;
+}
+// store of a finished accumulator element in the half-row format
+__device__ __forceinline__ void store_half(float* c_tile_row0, int ml, int nl, int ldc, int n0, float v) {
+    unsigned short* row = reinterpret_cast<unsigned short*>(c_tile_row0 - n0 + (size_t)ml * ldc);
+    row[n0 + nl] = __builtin_bit_cast(unsigned short, (__bf16)v);
+}
 constexpr int LDT = 36;   // LDS row pitch in floats (BK + 4 pad)
 
 // Issue the global loads of a [ROWS][BK] slice (rows row0.., k0..k0+31) into registers.
@@ -293,16 +309,24 @@ struct PipeBF16 {
                 for (int tn = 0; tn < TN; ++tn)
                     w[pl][tn] = *reinterpret_cast<const bf16x8*>(stage + A_PLANE * PL + W_PLANE * pl + (((wn * TN + tn) * 32 + li) * PH + ks * 16 + hi * 8) * 2);
             }
+            // term-major order (small terms first): the TM x TN accumulators take turns, so no MFMA waits for the one before it
+            if (PL == 2) {
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][tm], w[0][tn], acc[tm][tn], 0, 0, 0);
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][tm], w[PL - 1][tn], acc[tm][tn], 0, 0, 0);
+            }
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                for (int tn = 0; tn < TN; ++tn) {
-                    if (PL == 2) {                          // small terms first
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][tm], w[0][tn], acc[tm][tn], 0, 0, 0);
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][tm], w[PL - 1][tn], acc[tm][tn], 0, 0, 0);
-                    }
+                for (int tn = 0; tn < TN; ++tn)
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][tm], w[0][tn], acc[tm][tn], 0, 0, 0);
-                }
         }
     }
 };
@@ -317,12 +341,18 @@ struct PipeBF16 {
 // Against PipeBF16 (VGPR staging, split while storing to LDS) this removes the global_load -> VGPR -> ds_write round
 // trip (8 loads + 12 ds_writes per wave per slice, ~64 matrix-pipe cycles each, tools/vmem_issue_probe.hip).
 // k-slot convention (A and W agree): kstep ks, lane half hi, element e covers k = 16 ks + 8 hi + e.
-// AS = true: A is stored in the SPLIT-PAIR format the bf16 modes keep their edge tensors in (one 32-bit word per element:
-// bf16 hi = rne(x) in the upper half, bf16 lo = rne(x - hi) in the lower half; written by the producing kernel's
-// epilogue, common.h pack_split).  Same footprint and addressing as fp32, so the DMA staging is unchanged, and the
-// fragment-side split shrinks from ~24 VALU per 8 elements (cvt_pk, shift, sub, cvt_pk) to 8 v_perm_b32.
-template <int BM, int BN, int TERMS, bool AS = false>
+// AFMT: how A is stored.  0 = fp32.  1 = SPLIT-PAIR words, the format the split-bf16 mode keeps its edge tensors in (one
+// 32-bit word per element: bf16 hi = rne(x) in the upper half, bf16 lo = rne(x - hi) in the lower half; written by the
+// producing kernel's epilogue, common.h pack_split): same footprint and addressing as fp32, so the DMA staging is
+// unchanged, and the fragment-side split shrinks from ~24 VALU per 8 elements (cvt_pk, shift, sub, cvt_pk) to 8
+// v_perm_b32.  2 = HALF rows, the format of the single-rounding modes: the row keeps its fp32 pitch but only its first
+// K * 2 bytes are used, K bf16 values -- half the HBM traffic; staged as 64-byte rows exactly like the weight planes,
+// fragments are read with one ds_read_b128 and need no VALU at all (TERMS = 1 only).
+template <int BM, int BN, int TERMS, int AFMT = 0>
 struct PipeSplitDma {
+    static constexpr bool AS = AFMT == 1;
+    static constexpr bool AH = AFMT == 2;
+    static_assert(!AH || TERMS == 1, "half-row operands carry no low part");
     // With bf16 MFMAs a k-slice is 256 (bf16) to 768 (bf16x3) matrix-pipe cycles per wave, far less than the latency of
     // an A line that comes from HBM / the Infinity Cache, and LDS cannot hold enough slices in flight to cover it: the
     // kernel touches the A lines of the slice `prefetch` steps ahead (one dword per line into a dead register) so
@@ -330,7 +360,7 @@ struct PipeSplitDma {
     static constexpr bool PREFETCH = true;
     static constexpr int TM = BM / 64, TN = BN / 64;
     static constexpr int PL = TERMS == 1 ? 1 : 2;
-    static constexpr int A_BYTES = BM * BK * 4, W_PLANE = BN * BK * 2;
+    static constexpr int A_BYTES = AH ? BM * BK * 2 : BM * BK * 4, W_PLANE = BN * BK * 2;
     static constexpr int STAGE_BYTES = A_BYTES + W_PLANE * PL;
     struct Regs {};
     struct Ctx {
@@ -339,21 +369,33 @@ struct PipeSplitDma {
         template <class Args>
         __device__ __forceinline__ Ctx(const Args& p, int tid) {
             const int wave = tid >> 6, l = tid & 63;
-            na = (int)(((size_t)(p.M - 1) * p.lda + p.K) * 4);
             nw = (int)(((size_t)(p.N - 1) * p.ldw + p.K) * 2);
-            const int row = 8 * wave + (l >> 3);
-            va = (unsigned)(row * p.lda + 4 * ((l & 7) ^ ((row >> 1) & 7))) * 4u;
             const int wrow = 16 * wave + (l >> 2);                       // (wrow >> 2) & 3 == (l >> 4) & 3
             vw = (unsigned)(wrow * p.ldw + 8 * ((l & 3) ^ ((l >> 4) & 3))) * 2u;
+            if (AH) {                                                    // 64-byte row pieces at the fp32 row pitch
+                na = (int)((size_t)(p.M - 1) * p.lda * 4 + (size_t)p.K * 2);
+                va = (unsigned)(wrow * p.lda * 4 + 16 * ((l & 3) ^ ((l >> 4) & 3)));
+            } else {
+                na = (int)(((size_t)(p.M - 1) * p.lda + p.K) * 4);
+                const int row = 8 * wave + (l >> 3);
+                va = (unsigned)(row * p.lda + 4 * ((l & 7) ^ ((row >> 1) & 7))) * 4u;
+            }
         }
     };
     static __device__ __forceinline__ void load(const Ctx& c, const GemmArgs& p, int m0, int n0, int k0, Regs&, int tid, char* stage) {
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, c.na, 0x00020000);
-        float* sa = reinterpret_cast<float*>(stage) + wave * 8 * BK;
+        if (AH) {
+            char* sa = stage + wave * 16 * BK * 2;
 #pragma unroll
-        for (int i = 0; i < BM / 32; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, sa + i * 32 * BK, 16, c.va + (unsigned)(((m0 + 32 * i) * p.lda + k0) * 4), 0, 0, 0);
+            for (int i = 0; i < BM / 64; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, sa + i * 64 * BK * 2, 16, c.va + (unsigned)((m0 + 64 * i) * p.lda * 4 + k0 * 2), 0, 0, 0);
+        } else {
+            float* sa = reinterpret_cast<float*>(stage) + wave * 8 * BK;
+#pragma unroll
+            for (int i = 0; i < BM / 32; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, sa + i * 32 * BK, 16, c.va + (unsigned)(((m0 + 32 * i) * p.lda + k0) * 4), 0, 0, 0);
+        }
 #pragma unroll
         for (int pl = 0; pl < PL; ++pl) {
             const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(pl ? p.Wlo : p.Whi), 0, c.nw, 0x00020000);
@@ -366,6 +408,14 @@ struct PipeSplitDma {
     static __device__ __forceinline__ void store(char*, Regs&, int, int) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     // the slice's loads have landed; one younger load (the prefetch touch) may stay in flight
     static __device__ __forceinline__ void store_keep1() { asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); }
+    // half rows: the eight bf16 of a k-slot are one 16-byte LDS read; ReLU = max with +0 on the sign-magnitude patterns
+    template <bool RELU>
+    static __device__ __forceinline__ bf16x8 frag_half(const char* p) {
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        s16x8 v = *reinterpret_cast<const s16x8*>(p);
+        if (RELU) v = __builtin_elementwise_max(v, s16x8{0, 0, 0, 0, 0, 0, 0, 0});
+        return __builtin_bit_cast(bf16x8, v);
+    }
     // 8 consecutive k of one row (two 16-byte chunks) -> the bf16 hi / lo operand registers
     template <bool RELU>
     static __device__ __forceinline__ void split8(f32x4 x0, f32x4 x1, bf16x8& hi, bf16x8& lo) {
@@ -410,6 +460,7 @@ struct PipeSplitDma {
     static __device__ __forceinline__ void mma_t(const char* stage, int wm, int wn, f32x16 (&acc)[TM][TN], int lane) {
         const int li = lane & 31, hi = lane >> 5;
         const float* sA = reinterpret_cast<const float*>(stage) + (wm * TM * 32 + li) * BK;
+        const char* sAh = stage + (wm * TM * 32 + li) * BK * 2;
         const char* sW = stage + A_BYTES + (wn * TN * 32 + li) * BK * 2;
         const int swa = (li >> 1) & 7, sww = (li >> 2) & 3;
 #pragma unroll
@@ -417,26 +468,38 @@ struct PipeSplitDma {
             bf16x8 a[PL][TM], w[PL][TN];
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) {
-                const int c0 = (4 * ks + 2 * hi) ^ swa;                   // physical chunk of the first four k; the next four sit at c0 ^ 1
-                const f32x4 x0 = *reinterpret_cast<const f32x4*>(sA + tm * 32 * BK + 4 * c0);
-                const f32x4 x1 = *reinterpret_cast<const f32x4*>(sA + tm * 32 * BK + 4 * (c0 ^ 1));
-                split8<RELU>(x0, x1, a[0][tm], a[PL - 1][tm]);
+                if (AH) {
+                    a[0][tm] = frag_half<RELU>(sAh + tm * 32 * BK * 2 + 16 * ((2 * ks + hi) ^ sww));
+                } else {
+                    const int c0 = (4 * ks + 2 * hi) ^ swa;               // physical chunk of the first four k; the next four sit at c0 ^ 1
+                    const f32x4 x0 = *reinterpret_cast<const f32x4*>(sA + tm * 32 * BK + 4 * c0);
+                    const f32x4 x1 = *reinterpret_cast<const f32x4*>(sA + tm * 32 * BK + 4 * (c0 ^ 1));
+                    split8<RELU>(x0, x1, a[0][tm], a[PL - 1][tm]);
+                }
             }
 #pragma unroll
             for (int pl = 0; pl < PL; ++pl)
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn)
                     w[pl][tn] = *reinterpret_cast<const bf16x8*>(sW + pl * W_PLANE + tn * 32 * BK * 2 + 16 * ((2 * ks + hi) ^ sww));
+            // term-major order (small terms first): the TM x TN accumulators take turns, so no MFMA waits for the one before it
+            if (PL == 2) {
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][tm], w[0][tn], acc[tm][tn], 0, 0, 0);
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][tm], w[PL - 1][tn], acc[tm][tn], 0, 0, 0);
+            }
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                for (int tn = 0; tn < TN; ++tn) {
-                    if (PL == 2) {                          // small terms first
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][tm], w[0][tn], acc[tm][tn], 0, 0, 0);
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][tm], w[PL - 1][tn], acc[tm][tn], 0, 0, 0);
-                    }
+                for (int tn = 0; tn < TN; ++tn)
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][tm], w[0][tn], acc[tm][tn], 0, 0, 0);
-                }
         }
     }
 };
@@ -446,7 +509,8 @@ template <int BM, int BN> struct PipeSel<BM, BN, 0> { using type = PipeF32<BM, B
 template <int BM, int BN> struct PipeSel<BM, BN, 4> { using type = PipeF32Dma<BM, BN>; };   // internal: fp32, LDS-direct staging
 template <int BM, int BN> struct PipeSel<BM, BN, 5> { using type = PipeSplitDma<BM, BN, 1>; }; // internal: bf16, LDS-direct staging
 template <int BM, int BN> struct PipeSel<BM, BN, 7> { using type = PipeSplitDma<BM, BN, 3>; }; // internal: bf16x3, LDS-direct staging
-template <int BM, int BN> struct PipeSel<BM, BN, 9> { using type = PipeSplitDma<BM, BN, 1, true>; };  // ... A in split-pair format
-template <int BM, int BN> struct PipeSel<BM, BN, 11> { using type = PipeSplitDma<BM, BN, 3, true>; };
+template <int BM, int BN> struct PipeSel<BM, BN, 9> { using type = PipeSplitDma<BM, BN, 1, 1>; };   // ... A in split-pair format
+template <int BM, int BN> struct PipeSel<BM, BN, 11> { using type = PipeSplitDma<BM, BN, 3, 1>; };
+template <int BM, int BN> struct PipeSel<BM, BN, 13> { using type = PipeSplitDma<BM, BN, 1, 2>; };  // ... A as half rows (bf16)
 
 }  // namespace vlsat

@@ -140,8 +140,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int n_tile
                             if (m0 + ml >= p.M) ml = p.M - 1 - m0;
                             float x = 0.f;
                             if (ADD & 1) {
-                                const float rv = rbase[(unsigned)(ml * ldr + nl)];
-                                x = p.resid_scale * (p.r_split ? unpack_split(rv) : rv);
+                                x = p.resid_scale * load_resid(p, rbase, ml, nl, ldr, n0);
                             }
                             if (ADD & 2) x += p.g0[(unsigned)(p.gi0[m0 + ml] * ldg0 + n0 + nl)];
                             if (ADD & 4) x += p.g1[(unsigned)(p.gi1[m0 + ml] * ldg1 + n0 + nl)];
@@ -218,6 +217,17 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int n_tile
 #pragma unroll
                             for (int r = 0; r < 16; ++r) acc[tm][tn][r] *= p.c_scale;
                 }
+                if (p.c_split == 2) {                             // half rows: bf16 at byte 2 * column of the fp32-pitched row
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int ml = (wm * TM + tm) * 32 + crow32(r, hi), nl = (wn * TN + tn) * 32 + li;
+                                if (m0 + ml < p.M && n0 + nl < p.N) store_half(cbase, ml, nl, ldc, n0, acc[tm][tn][r]);
+                            }
+                } else {
                 if (p.c_split) {                                  // bf16 modes: the consumer reads hi/lo bf16 pairs
 #pragma unroll
                     for (int tm = 0; tm < TM; ++tm)
@@ -246,6 +256,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int n_tile
                                 const int ml = (wm * TM + tm) * 32 + crow32(r, hi), nl = (wn * TN + tn) * 32 + li;
                                 if (m0 + ml < p.M && n0 + nl < p.N) cbase[(unsigned)(ml * ldc + nl)] = acc[tm][tn][r];
                             }
+                }
                 }
                 zero_acc<TM, TN>(acc);
             }
@@ -300,9 +311,11 @@ static int launch_t(const GemmArgs& a, int n_tiles, int grid, hipStream_t s) {
     const bool dma_ok = !a.no_dma && (add == 0 || add == 1 || add == 6) &&
                         ((size_t)a.M + 256) * a.lda * 4 < (1ull << 32) && ((size_t)a.N + 256) * a.ldw * 4 < (1ull << 32);
     if (prec == 0 && dma_ok && !a.relu_a) prec = 4;
-    if ((prec == 1 || prec == 3) && dma_ok) prec += a.a_split ? 8 : 4;      // bf16 modes: A split on the fragment-read side, so ReLU-on-A is fine
+    if (a.a_split == 2 && !(prec == 1 && dma_ok)) return fail(-1, "gemm: half-row A needs the single-rounding bf16 precision and the LDS-direct pipe");
+    if ((prec == 1 || prec == 3) && dma_ok) prec += a.a_split == 2 ? 12 : a.a_split ? 8 : 4;   // bf16 modes: A split on the fragment-read side, so ReLU-on-A is fine
     else if (a.a_split) return fail(-1, "gemm: split-pair A needs a bf16 precision and the LDS-direct pipe");
     switch (prec * 8 + add) {
+        VLSAT_GEMM_CASE(0, 13) VLSAT_GEMM_CASE(1, 13) VLSAT_GEMM_CASE(6, 13)
         VLSAT_GEMM_CASE(0, 9) VLSAT_GEMM_CASE(1, 9) VLSAT_GEMM_CASE(6, 9)
         VLSAT_GEMM_CASE(0, 11) VLSAT_GEMM_CASE(1, 11) VLSAT_GEMM_CASE(6, 11)
         VLSAT_GEMM_CASE(0, 4) VLSAT_GEMM_CASE(1, 4) VLSAT_GEMM_CASE(6, 4)

@@ -26,7 +26,8 @@ struct GemmArgs {
     const uint16_t* Whi = nullptr;
     const uint16_t* Wlo = nullptr;
     long long* clock_probe = nullptr;           // optional [grid][4] DVFS probe buffer (vlsat_debug_gemm_clock_probe)
-    // split-pair format of the bf16 modes (common.h pack_split): which operands carry it
+    // storage format of A / the residual / C: 0 fp32, 1 split-pair words (common.h pack_split; split-bf16 mode),
+    // 2 half rows (bf16 values at byte 2 * column of an fp32-pitched row; single-rounding modes)
     int a_split = 0, r_split = 0, c_split = 0;
     float c_scale = 1.f;                        // final multiplier of C (after bias / activation)
     int no_ring = 0;                            // debug: keep large bf16 launches on the two-stage 128 x 128 kernel

@@ -108,9 +108,16 @@ __global__ __launch_bounds__(256) void layernorm512_kernel(const float* __restri
         a[c] = a[c] * rstd * ga[c] + ba[c];
         b[c] = b[c] * rstd * gb[c] + bb[c];
         if (relu) { a[c] = fmaxf(a[c], 0.f); b[c] = fmaxf(b[c], 0.f); }
-        if (out_split) { a[c] = pack_split(a[c]); b[c] = pack_split(b[c]); }     // bf16 modes: the consumers are GEMM A operands
+        if (out_split == 1) { a[c] = pack_split(a[c]); b[c] = pack_split(b[c]); }     // bf16 modes: the consumers are GEMM A operands
     }
     float* q = y + (size_t)row * ldy;
+    if (out_split == 2) {                                  // half rows: bf16 at byte 2 * column
+        typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+        bf16x4_t* h = reinterpret_cast<bf16x4_t*>(q);
+        h[lane] = __builtin_convertvector(a, bf16x4_t);
+        h[64 + lane] = __builtin_convertvector(b, bf16x4_t);
+        return;
+    }
     *reinterpret_cast<f32x4*>(q + 4 * lane) = a;
     *reinterpret_cast<f32x4*>(q + 256 + 4 * lane) = b;
 }

@@ -169,8 +169,9 @@ int vlsat_k_split_bf16(const float* w, size_t n, uint16_t* hi, uint16_t* lo, voi
  * prec 1 = single-rounded bf16 operands, 3 = split-bf16 (three MFMAs per product).  A stays fp32 and is split inside
  * the kernel.  no_dma = 1: the VGPR-staged operand pipe of round 1 instead of the LDS-direct one; prefetch: slices of
  * look-ahead of the A-panel prefetch (0 = off, -1 = default).  fmt: bit 0 = A, bit 1 = resid, bit 2 = C are in the
- * split-pair format of the bf16 modes (one 32-bit word per element: bf16 hi = rne(x) in the upper half, bf16 lo =
- * rne(x - hi) in the lower half); c_scale multiplies C last.  Asynchronous. */
+ * split-pair format of the split-bf16 mode (one 32-bit word per element: bf16 hi = rne(x) in the upper half, bf16 lo =
+ * rne(x - hi) in the lower half) or, with bit 5 set, in the half-row format of the single-rounding modes (bf16 values
+ * at byte 2 * column of the fp32-pitched row; prec 1 only); c_scale multiplies C last.  Asynchronous. */
 int vlsat_k_gemm_planes(const float* A, int32_t lda, const float* W, const uint16_t* Whi, const uint16_t* Wlo, int32_t ldw,
                         float* C, int32_t ldc, int32_t M, int32_t N, int32_t K, const float* bias,
                         const float* resid, int32_t ldr, float resid_scale,
@@ -203,7 +204,8 @@ int vlsat_k_flash_attn(const float* Q, const float* K, const float* V, float* O,
 
 /* The same attention on the bf16 matrix cores (BASELINE configs[2]): terms = 3 split-bf16 (three MFMAs per product,
  * ~1e-5) or 1 (single-rounded operands); use_tr = 1 reads the V operand with the LDS transpose read, 0 gathers it,
- * 2 = transpose read with Q (pre-multiplied by scale*log2 e), K, V and O in the split-pair format. */
+ * 2 = transpose read with Q (pre-multiplied by scale*log2 e), K, V and O in the split-pair format, 3 = the same in the
+ * half-row format (terms = 1). */
 int vlsat_k_flash_attn_bf16(const float* Q, const float* K, const float* V, float* O,
                             int32_t ld, const int64_t* tok_ptr_host, int32_t n_scenes, int32_t n_heads,
                             float scale, int32_t terms, int32_t use_tr, void* stream);
@@ -269,6 +271,7 @@ int vlsat_debug_gemm_clock_probe(int64_t* buf);
  * split-key edge attention for plans that cannot fill the chip (both: plans created afterwards); "gemm_dma" 0|1:
  * LDS-direct staging of fp32 GEMM operands; "gate_grid" n: persistent grid of the gate kernel (0 = default);
  * "split_fmt" 0|1: in the bf16 modes, edge tensors between matrix kernels as bf16 hi/lo pairs (0: fp32, split on read);
+ * "half_fmt" 0|1: in the single-rounding modes, those tensors as plain bf16 at half the traffic (0: hi/lo pairs);
  * "flash_bf16" / "pointnet_bf16" / "gate_bf16" 0|1: in the bf16 modes, edge attention / object encoder / edge gate on
  * the bf16 matrix cores (0: the fp32 kernels); "flash_tr" 0|1: its V operand by
  * ds_read_b64_tr_b16 (0: ds_read_u16 gather). */

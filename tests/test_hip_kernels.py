@@ -494,3 +494,57 @@ def test_gemm_bf16_ring_kernel(lib, M, N, K, fmt):
         ref = _ref_gemm(Af.to(DEV), W, **kw)
         err = float((run(prec, fmt, 0, 0, 0) - ref).abs().max())
         assert err < (1e-4 if prec == 3 else 3e-2) * math.sqrt(K / 64) + 2e-5, f"prec {prec}: {err:.3e}"
+
+
+def _to_half_rows(x):
+    """fp32-pitched rows carrying bf16 values at byte 2 * column (the half-row format of the single-rounding modes)."""
+    M, N = x.shape
+    out = torch.zeros(M, N, dtype=torch.float32)
+    out.view(torch.bfloat16).view(M, 2 * N)[:, :N] = x.to(torch.bfloat16)
+    return out
+
+
+def _from_half_rows(w, N):
+    return w.view(torch.bfloat16).view(w.shape[0], -1)[:, :N].float()
+
+
+def test_half_row_format_gemm_and_attention(lib):
+    """Half-row tensors (plain bf16 inside fp32-pitched rows): GEMM with A / residual / C in that format, small and
+    ring-kernel sizes, and the attention with Q / K / V / O in it, against the same kernels on fp32 tensors holding the
+    same bf16-representable values."""
+    l = lib.load()
+    g = torch.Generator().manual_seed(123)
+    for M in (3000, 70000):
+        N, K = 512, 256
+        A = torch.randn(M, K, generator=g).to(torch.bfloat16).float()
+        R = torch.randn(M, N, generator=g).to(torch.bfloat16).float()
+        W = (torch.randn(N, K, generator=g) / 16).to(DEV)
+        b = torch.randn(N, generator=g).to(DEV)
+        hi = torch.empty(N * K + 128, dtype=torch.int16, device=DEV)
+        lo = torch.empty_like(hi)
+        lib.check(l.vlsat_k_split_bf16(W.data_ptr(), N * K, hi.data_ptr(), lo.data_ptr(), lib.stream_ptr()))
+        Ad, Rd, Ah, Rh = A.to(DEV), R.to(DEV), _to_half_rows(A).to(DEV), _to_half_rows(R).to(DEV)
+
+        def run(a, r, fmt, relu_a):
+            Cb = torch.zeros(M, N, device=DEV)
+            lib.check(l.vlsat_k_gemm_planes(a.data_ptr(), K, W.data_ptr(), hi.data_ptr(), lo.data_ptr(), K, Cb.data_ptr(), N, M, N, K,
+                                            b.data_ptr(), r.data_ptr(), N, 0.5, 0, 0, 0, 0, 0, 0, relu_a, 1, 1, 0, -1, fmt, 1.0,
+                                            lib.stream_ptr()))
+            _sync()
+            return Cb.cpu()
+        for relu_a in (0, 1):
+            plain = run(Ad, Rd, 0, relu_a)
+            half_in = run(Ah, Rh, 32 | 3, relu_a)
+            assert torch.equal(plain, half_in), f"M={M} relu {relu_a}: {float((plain - half_in).abs().max()):.3e}"
+            half_out = _from_half_rows(run(Ah, Rh, 32 | 7, relu_a), N)
+            assert torch.equal(half_out, plain.to(torch.bfloat16).float())
+    tok = [0, 70, 70 + 333]
+    T = tok[-1]
+    sc = 0.125 * 1.4426950408889634
+    q, k, v = (torch.randn(T, 512, generator=g).to(torch.bfloat16).float() for _ in range(3))
+    qs = (q * sc).to(torch.bfloat16).float()
+    plain = _flash_bf16(lib, (qs / sc).to(DEV), k.to(DEV), v.to(DEV), tok, 0.125, 1, 1)
+    got = _from_half_rows(_flash_bf16(lib, _to_half_rows(qs).to(DEV), _to_half_rows(k).to(DEV), _to_half_rows(v).to(DEV), tok, 0.125, 1, 3), 512)
+    ref = _ref_attn(qs / sc, k, v, tok, 0.125)
+    assert float((got - ref).abs().max()) < 8e-2
+    assert float((got - plain).abs().max()) < 3e-2          # (the outputs themselves are rounded to bf16 here)
