@@ -102,6 +102,8 @@ def main():
     ap.add_argument("--layers", type=int, default=3)
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--debug-option", action="append", default=[], metavar="NAME=VALUE",
+                    help="experiment switch of the library (vlsat_debug_option), e.g. node_attn_split=0; repeatable")
     ap.add_argument("--gemm-precision", default="fp32", choices=["fp32", "bf16x3", "bf16_mixed", "bf16"],
                     help="fp32 = BASELINE configs[1] (default, the headline); bf16x3 / bf16_mixed = configs[2] "
                          "(split-bf16 MFMA: <=1e-3; mixed single/split bf16: <=1e-2)")
@@ -124,6 +126,8 @@ def main():
     cfg = VLSATConfig(N_LAYERS=args.layers)
     model = VLSATModel(cfg, str(dev)).load_state(synth.make_weights(cfg)).eval()
     model.set_gemm_precision(args.gemm_precision)
+    for kv in args.debug_option:
+        model.debug_option(kv.split("=")[0], int(kv.split("=")[1]))
     # this rank's shard of the global scene list (weak scaling: args.scenes per GPU)
     scenes = vdist.shard(args.scenes * world, rank, world)
     batch = synth.collate([synth.make_scene(args.objects, args.points, 1000 + s) for s in scenes])

@@ -38,6 +38,8 @@ int vlsat_set_edge_attention_scope(vlsat_handle h, int32_t scope) {
 //   "flash_split" 0|1   split-key edge attention for plans that cannot fill the chip (plans created afterwards)
 //   "gemm_dma"    0|1   LDS-direct staging of fp32 GEMM operands (0: VGPR-staged)
 //   "gate_grid"   n     persistent grid of the gate kernel (0: default)
+//   "node_attn_split" n  node attention with sixteen lanes per query for plans of fewer than n one-query-per-lane waves
+//   "gemm_splitk" 0|1   small GEMM launches on the split-K kernel (0: everything on the persistent kernel)
 //   "split_fmt"   0|1   bf16 modes: edge tensors between matrix kernels as bf16 hi/lo pairs (0: plain fp32, split on read)
 //   "half_fmt"    0|1   single-rounding modes: those tensors as plain bf16 at half the traffic (0: split pairs)
 //   "flash_bf16"  0|1   bf16 modes: edge attention on the bf16 matrix cores (0: keep the fp32 kernel)
@@ -50,6 +52,8 @@ int vlsat_debug_option(vlsat_handle h, const char* name, int32_t value) {
     else if (k == "flash_split") h->fa_split = value != 0;
     else if (k == "gemm_dma") h->gemm_no_dma = value == 0;
     else if (k == "gate_grid") h->gate_grid = value > 0 ? value : 0;
+    else if (k == "gemm_splitk") h->gemm_splitk = value != 0;
+    else if (k == "node_attn_split") h->node_attn_split = value;
     else if (k == "split_fmt") h->split_fmt = value != 0;
     else if (k == "half_fmt") h->half_fmt = value != 0;
     else if (k == "flash_bf16") h->flash_bf16 = value != 0;
@@ -61,6 +65,19 @@ int vlsat_debug_option(vlsat_handle h, const char* name, int32_t value) {
 }
 
 // -------------------------------------------------------------------------------------------
+// workspace of the split-K kernel for the handle-free test entry points (allocated on first use, never freed)
+static int test_splitk_ws(GemmArgs& a) {
+    static float* ws = nullptr;
+    static unsigned* cnt = nullptr;
+    if (!ws) {
+        VLSAT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&ws), SPLITK_WS_FLOATS * sizeof(float)));
+        VLSAT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&cnt), SPLITK_COUNTERS * sizeof(unsigned)));
+        VLSAT_HIP_CHECK(hipMemset(cnt, 0, SPLITK_COUNTERS * sizeof(unsigned)));
+    }
+    a.sk_ws = ws; a.sk_ws_floats = SPLITK_WS_FLOATS; a.sk_counters = cnt; a.sk_n_counters = SPLITK_COUNTERS;
+    return 0;
+}
+
 int vlsat_k_gemm(const float* A, int32_t lda, const float* W, int32_t ldw, float* C, int32_t ldc, int32_t M, int32_t N,
                  int32_t K, const float* bias, const float* rowscale, const float* resid, int32_t ldr, float resid_scale,
                  const float* g0, const int32_t* gi0, int32_t ldg0, const float* g1, const int32_t* gi1, int32_t ldg1,
@@ -70,6 +87,7 @@ int vlsat_k_gemm(const float* A, int32_t lda, const float* W, int32_t ldw, float
     a.bias = bias; a.rowscale = rowscale; a.resid = resid; a.ldr = ldr; a.resid_scale = resid_scale;
     a.g0 = g0; a.gi0 = gi0; a.ldg0 = ldg0; a.g1 = g1; a.gi1 = gi1; a.ldg1 = ldg1; a.relu_a = relu_a & 1; a.act = act;
     if (relu_a & 2) a.prefetch = 0;             // (bit 1 of relu_a: no A-panel prefetch -- benchmarking)
+    if (relu_a & 4) RUN(test_splitk_ws(a));     // (bit 2: small launches may take the split-K kernel)
     return launch_gemm(a, static_cast<hipStream_t>(stream));
 }
 
@@ -97,6 +115,7 @@ int vlsat_k_gemm_planes(const float* A, int32_t lda, const float* W, const uint1
     a.a_split = (fmt & 1) * code; a.r_split = ((fmt >> 1) & 1) * code; a.c_split = ((fmt >> 2) & 1) * code; a.c_scale = c_scale;
     a.k_rotate = (fmt >> 3) & 1;               // (bit 3: k rotation, bit 4: no ring kernel -- benchmarking)
     a.no_ring = (fmt >> 4) & 1;
+    if ((fmt >> 6) & 1) RUN(test_splitk_ws(a));    // (bit 6: small launches may take the split-K kernel)
     return launch_gemm(a, static_cast<hipStream_t>(stream));
 }
 

@@ -91,6 +91,11 @@ int gemm(vlsat_ctx* h, hipStream_t s, const GemmArgs& a0) {
     }
     a.no_dma = h->gemm_no_dma;
     a.launches = &h->gemm_launches;
+    if (h->gemm_splitk) {
+        const int w = (h->side && s == h->side) ? 1 : 0;
+        a.sk_ws = h->sk_ws[w]; a.sk_ws_floats = SPLITK_WS_FLOATS;
+        a.sk_counters = h->sk_cnt[w]; a.sk_n_counters = SPLITK_COUNTERS;
+    }
     Scope sc(h, s, PC_GEMM, gemm_flops(a));
     return launch_gemm(a, s);
 }
@@ -113,7 +118,7 @@ int attn_block(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const AttnW& w, flo
     {
         Scope sc(h, s, PC_NODE_ATTN, 0);
         RUN(launch_node_attn(p->QKVn, 3 * D, p->QKVn + D, 3 * D, p->QKVn + 2 * D, 3 * D, p->On, D, p->bias,
-                             p->d_scene_ptr, p->d_bias_ptr, p->S, p->max_n, h->H, D / h->H, 1.0f, s));
+                             p->d_scene_ptr, p->d_bias_ptr, p->S, p->max_n, h->H, D / h->H, 1.0f, s, h->node_attn_split));
     }
     GemmArgs o = G(p->On, D, w.wo, D, xq, LDX, N, D, w.bo);
     o.resid = xq; o.ldr = LDX;
@@ -407,7 +412,7 @@ static int forward_impl(vlsat_handle h, vlsat_plan p, const float* pts, const fl
                 if (D / h->H != 64)          // generic head dim: VALU attention over the scenes' edge ranges (no bias)
                     RUN(launch_node_attn(p->Qe, D, p->KVe, 2 * D, p->KVe + D, 2 * D, p->Oe, D, nullptr, p->d_edge_ptr32, nullptr,
                                          h->edge_scope == 1 ? 1 : p->S, h->edge_scope == 1 ? E : p->max_e, h->H, D / h->H,
-                                         1.f / std::sqrt((float)(D / h->H)), s));
+                                         1.f / std::sqrt((float)(D / h->H)), s, h->node_attn_split));
                 else if (h->prec_edge && h->flash_bf16)
                     RUN(launch_flash_attn_bf16(p->Qe, D, p->KVe, p->KVe + (S == 2 ? D / 2 : D), 2 * D, p->Oe, D, p->d_tiles, p->n_tiles,
                                                sc2e, h->prec_edge == 3 ? 3 : 1, h->flash_tr, S, s, &sp));    // (half rows: V starts at byte 2 D)

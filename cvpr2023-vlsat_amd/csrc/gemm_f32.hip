@@ -386,6 +386,10 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
         return fail(-1, "gemm: A/W must be 16-byte aligned");
     const int G = slots();
     auto blocks = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
+    if (a.sk_ws && !a.clock_probe) {                  // small launch: k range spread over otherwise idle CUs
+        const int r = launch_gemm_splitk(a, G, s);
+        if (r <= 0) return r;
+    }
     // bf16 modes, large M: the full rounds go to the 3-stage ring kernel (gemm_bf16_ring.hip: one 8-wave block per CU,
     // 256 x 128 tiles, two slices in flight), the remaining row panels to the kernels below
     if ((a.prec == 1 || a.prec == 3) && !a.no_dma && !a.no_ring && a.N > 64 && !a.rowscale &&

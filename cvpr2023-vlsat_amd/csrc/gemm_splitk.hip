@@ -1,0 +1,154 @@
+// Split-K GEMM for the small launches of a one-scene forward (the reference's own call pattern: validation() runs
+// batch_size = 1, src/model/model.py:185, so every nn.Linear sees 9..80 node rows or a few thousand edge rows).
+//
+// Why: a 64 x 64 output tile with K = 512 pulls 256 KB of operands through ONE CU, and a CU sustains 30-70 GB/s from
+// L2 / Infinity Cache (tools/l2_fill_probe.hip) -- 15-19 us per launch whatever the problem size, with 16..300 of the 512
+// resident slots in use (profiles/r02_single_scene_*: 52 such launches per forward).  Here the k range of a tile is cut
+// into `ks` parts that run on different CUs (all parts of a tile on one XCD, so the partial sums meet in that XCD's L2);
+// every part loads its whole k range with one round of LDS-direct loads, multiplies, writes its 64 x 64 partial sum to a
+// workspace and bumps the tile's counter; the block that arrives last adds the parts IN PART ORDER (so the result does
+// not depend on which block that is: same launch -> same bits) and runs the epilogue of the persistent kernel
+// (gemm_f32.hip): accumulator init from residual / gathered rows, row scale, bias, activation, scale, output format.
+#include <algorithm>
+#include "gemm_core.h"
+#include "kernels.h"
+
+namespace vlsat {
+
+namespace {
+
+constexpr int SK_MAXS = 4;                   // k-slices (of 32) a block holds in LDS at once
+
+template <int PREC>
+__global__ __launch_bounds__(256, 2) void gemm_splitk_kernel(GemmArgs p, int n_tiles, int nbn, int ks, int slices, float* __restrict__ ws,
+                                                             unsigned* __restrict__ counters) {
+    using Pipe = typename PipeSel<64, 64, PREC>::type;
+    constexpr int SLICE = Pipe::STAGE_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[SK_MAXS * SLICE];
+    __shared__ unsigned s_last;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int tile = (j / ks) * 8 + xcd, part = j % ks;
+    if (tile >= n_tiles) return;
+    const int m0 = (tile / nbn) * 64, n0 = (tile % nbn) * 64;
+    const int k_begin = part * slices * BK;
+    const int n_sl = min(slices, (p.K - k_begin) / BK);
+
+    f32x16 acc[1][1];
+    zero_acc<1, 1>(acc);
+    typename Pipe::Regs regs[SK_MAXS];
+    const typename Pipe::Ctx ctx(p, tid);
+    for (int c0 = 0; c0 < n_sl; c0 += SK_MAXS) {
+        if (c0) __syncthreads();                                     // the previous chunk's fragments have been read
+#pragma unroll
+        for (int i = 0; i < SK_MAXS; ++i)
+            if (c0 + i < n_sl) Pipe::load(ctx, p, m0, n0, k_begin + (c0 + i) * BK, regs[i], tid, smem + i * SLICE);
+#pragma unroll
+        for (int i = 0; i < SK_MAXS; ++i)
+            if (c0 + i < n_sl) Pipe::store(smem + i * SLICE, regs[i], tid, p.relu_a);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < SK_MAXS; ++i)
+            if (c0 + i < n_sl) Pipe::mma(smem + i * SLICE, wm, wn, acc, lane, p.relu_a);
+    }
+
+    const int li = lane & 31, hi = lane >> 5;
+    if (ks > 1) {
+        // partial sums in accumulator order: element (wave, r, lane) -> one coalesced 256-byte store per wave and r
+        float* mine = ws + ((size_t)tile * ks + part) * 4096 + wave * 1024 + lane;
+        // Device-coherent accesses (sc1: written through / read past the XCD's L2) instead of fences: an agent-scope
+        // release / acquire is a writeback + invalidate of the WHOLE L2 on this part (buffer_wbl2 / buffer_inv sc1), which
+        // every one of the few hundred blocks would pay (measured: 55 us instead of 14 us per launch).
+#pragma unroll
+        for (int r = 0; r < 16; ++r) __hip_atomic_store(mine + r * 64, acc[0][0][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the stores are acknowledged before the counter moves
+        __syncthreads();
+        if (tid == 0) s_last = __hip_atomic_fetch_add(&counters[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(ks - 1);
+        __syncthreads();
+        if (!s_last) return;
+        if (tid == 0) __hip_atomic_store(&counters[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    }
+
+    // ---- accumulator init (the persistent kernel's ADD operands), then the parts in order ----
+    const int nl = wn * 32 + li;
+    const int ncl = n0 + nl < p.N ? nl : p.N - 1 - n0;               // clamped column for the loads
+    float out[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        int ml = wm * 32 + crow32(r, hi);
+        if (m0 + ml >= p.M) ml = p.M - 1 - m0;
+        float x = 0.f;
+        if (p.resid) x = p.resid_scale * load_resid(p, p.resid + (size_t)m0 * p.ldr + n0, ml, ncl, p.ldr, n0);
+        if (p.g0) x += p.g0[(size_t)p.gi0[m0 + ml] * p.ldg0 + n0 + ncl];
+        if (p.g1) x += p.g1[(size_t)p.gi1[m0 + ml] * p.ldg1 + n0 + ncl];
+        out[r] = x;
+    }
+    if (ks > 1) {
+        const float* parts = ws + (size_t)tile * ks * 4096 + wave * 1024 + lane;
+        for (int s = 0; s < ks; ++s)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) out[r] += __hip_atomic_load(parts + (size_t)s * 4096 + r * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[r] += acc[0][0][r];
+    }
+    // ---- epilogue (same order of operations as gemm_f32.hip) ----
+    const float bn = p.bias ? p.bias[n0 + ncl] : 0.f;
+    float* cbase = p.C + (size_t)m0 * p.ldc + n0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int ml = wm * 32 + crow32(r, hi);
+        const bool ok = m0 + ml < p.M && n0 + nl < p.N;
+        float v = out[r];
+        if (p.rowscale) v *= p.rowscale[ok ? m0 + ml : p.M - 1];
+        v += bn;
+        if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
+        else if (p.act == ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
+        if (p.c_scale != 1.f) v *= p.c_scale;
+        if (!ok) continue;
+        if (p.c_split == 2) store_half(cbase, ml, nl, p.ldc, n0, v);
+        else cbase[(size_t)ml * p.ldc + nl] = p.c_split ? pack_split(v) : v;
+    }
+}
+
+}  // namespace
+
+// Decides whether the launch is one of the small ones this kernel is for and, if so, runs it.  Returns 0 = launched,
+// 1 = not applicable (the caller falls through to the persistent kernel), < 0 = error.
+int launch_gemm_splitk(const GemmArgs& a, int slots, hipStream_t s) {
+    if (!a.sk_ws || !a.sk_counters) return 1;
+    const long nbm = (a.M + 63) / 64, nbn = (a.N + 63) / 64, T = nbm * nbn;
+    const int total = a.K / BK;                                      // k-slices
+    if (total < 4 || T > slots / 2) return 1;                        // at least two parts of >= 2 slices, and room for them
+    // as many parts as fill the resident slots once, each at least two slices (64 of K) long
+    int ks = (int)std::min<long>(total / 2, std::max<long>(1, slots / T));
+    ks = std::min(ks, 16);
+    if (ks < 2) return 1;
+    const int slices = (total + ks - 1) / ks;
+    ks = (total + slices - 1) / slices;                              // no empty parts
+    if ((size_t)T * ks * 4096 > a.sk_ws_floats || (size_t)T > a.sk_n_counters) return 1;
+    const int add = (a.resid ? 1 : 0) | (a.g0 ? 2 : 0) | (a.g1 ? 4 : 0);
+    (void)add;
+    int prec = a.prec;
+    const bool dma_ok = !a.no_dma && ((size_t)a.M + 256) * a.lda * 4 < (1ull << 32) && ((size_t)a.N + 256) * a.ldw * 4 < (1ull << 32);
+    if (prec == 0 && dma_ok && !a.relu_a) prec = 4;
+    if (a.a_split == 2 && !(prec == 1 && dma_ok)) return 1;
+    if ((prec == 1 || prec == 3) && dma_ok) prec += a.a_split == 2 ? 12 : a.a_split ? 8 : 4;
+    else if (a.a_split) return 1;
+    const int grid = (int)((T + 7) / 8) * 8 * ks;
+#define VLSAT_SK_CASE(PREC) \
+    case PREC: hipLaunchKernelGGL((gemm_splitk_kernel<PREC>), dim3(grid), dim3(256), 0, s, a, (int)T, (int)nbn, ks, slices, a.sk_ws, a.sk_counters); break;
+    switch (prec) {
+        VLSAT_SK_CASE(0) VLSAT_SK_CASE(1) VLSAT_SK_CASE(3) VLSAT_SK_CASE(4) VLSAT_SK_CASE(5) VLSAT_SK_CASE(7)
+        VLSAT_SK_CASE(9) VLSAT_SK_CASE(11) VLSAT_SK_CASE(13)
+        default: return 1;
+    }
+#undef VLSAT_SK_CASE
+    if (a.launches) ++*a.launches;
+    VLSAT_LAUNCH_CHECK("gemm_splitk");
+    return 0;
+}
+
+}  // namespace vlsat

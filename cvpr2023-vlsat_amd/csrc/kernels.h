@@ -35,8 +35,16 @@ struct GemmArgs {
     int prefetch = -1;                          // bf16 LDS-direct pipe: slices of look-ahead of the A-panel prefetch (0 off, -1 default)
     int no_dma = 0;                             // debug: VGPR-staged fp32 operands instead of LDS-direct (vlsat_debug_option "gemm_dma")
     long* launches = nullptr;                   // optional host counter, +1 per kernel launched (profiling)
+    // split-K path of small launches (gemm_splitk.hip): partial-sum workspace + per-tile arrival counters (zero between
+    // launches), owned by the caller and private to the stream the launch goes to; null = never split
+    float* sk_ws = nullptr; size_t sk_ws_floats = 0;
+    unsigned* sk_counters = nullptr; size_t sk_n_counters = 0;
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
+// small launches: k range cut over several CUs, deterministic in-kernel reduction; 1 = not applicable, 0 = launched
+int launch_gemm_splitk(const GemmArgs& a, int slots, hipStream_t s);
+constexpr size_t SPLITK_WS_FLOATS = (size_t)768 * 4096;    // room for 768 partial 64 x 64 tiles (12 MB)
+constexpr size_t SPLITK_COUNTERS = 512;
 // bf16 modes, full rounds of large-M launches: 3-stage LDS ring, 256 x 128 tiles, one 8-wave block per CU
 // (gemm_bf16_ring.hip); returns 1 if the operand combination is not built
 int launch_gemm_ring(const GemmArgs& a, int n_tiles, int grid, hipStream_t s);
@@ -85,7 +93,7 @@ constexpr int FLASH_BQ = 128;   // queries per block
 int launch_node_attn(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,
                      float* O, int ldo, const float* bias, const int32_t* scene_ptr,
                      const int64_t* bias_ptr, int n_scenes, int max_n, int n_heads, int dk, float scale,
-                     hipStream_t s);
+                     hipStream_t s, int split_below = 1024);
 // distance-bias MLP (MMG.self_attn_fc): centres = desc[:,0:3] (ld = 11)
 struct DistBiasW { const float *w0, *b0, *g2, *be2, *w3, *b3, *g5, *be5, *w6, *b6; };
 int launch_dist_bias(const float* desc, int ld_desc, const int32_t* scene_ptr, const int64_t* bias_ptr,

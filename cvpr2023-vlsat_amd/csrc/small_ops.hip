@@ -330,14 +330,113 @@ __global__ __launch_bounds__(64) void node_attn_kernel(const float* __restrict__
         }
     }
 }
+// The same attention for plans too small to fill the chip with one query per lane (a one-scene call: 8 heads x
+// ceil(n / 64) waves on 256 CUs, each walking all n keys with 128 FMAs per key: 30 us at n = 40).  Sixteen lanes share a
+// query: 4 split the head dim (partial dots meet through two quad shuffles), 4 take every fourth key each (own online
+// softmax, merged at the end); 16 queries per 256-thread block.  K / V rows sit in LDS with a 16-byte pad so that the
+// four key phases of a wave read disjoint banks.
+template <int DK>
+__global__ __launch_bounds__(256) void node_attn_split_kernel(const float* __restrict__ Q, int ldq,
+                                                              const float* __restrict__ K, int ldk,
+                                                              const float* __restrict__ V, int ldv,
+                                                              float* __restrict__ O, int ldo,
+                                                              const float* __restrict__ bias,
+                                                              const int32_t* __restrict__ scene_ptr,
+                                                              const int64_t* __restrict__ bias_ptr, float scale) {
+    constexpr int DP = DK / 4, PITCH = DK + 4, CHUNK = 64;
+    __shared__ __attribute__((aligned(16))) float sK[CHUNK * PITCH];
+    __shared__ __attribute__((aligned(16))) float sV[CHUNK * PITCH];
+    const int s = blockIdx.z, h = blockIdx.y, tid = threadIdx.x;
+    const int n0 = scene_ptr[s], n = scene_ptr[s + 1] - n0;
+    if (blockIdx.x * 16 >= n) return;
+    const int part = tid & 3, ksi = (tid >> 2) & 3;
+    const int qa = blockIdx.x * 16 + (tid >> 4);
+    const bool valid = qa < n;
+    const int qrow = n0 + (valid ? qa : n - 1);
+    float q[DP], acc[DP];
+#pragma unroll
+    for (int g = 0; g < DP / 4; ++g) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(Q + (size_t)qrow * ldq + h * DK + part * DP + 4 * g);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { q[4 * g + c] = x[c] * scale; acc[4 * g + c] = 0.f; }
+    }
+    float m_run = -INFINITY, l_run = 0.f;
+    const float* brow = bias ? bias + bias_ptr[s] + ((size_t)h * n + (valid ? qa : n - 1)) * n : nullptr;
+    for (int k0 = 0; k0 < n; k0 += CHUNK) {
+        const int kn = min(CHUNK, n - k0);
+        __syncthreads();
+        for (int i = tid; i < kn * (DK / 4); i += 256) {
+            const int r = i / (DK / 4), c4 = (i % (DK / 4)) * 4;
+            *reinterpret_cast<f32x4*>(sK + r * PITCH + c4) = *reinterpret_cast<const f32x4*>(K + (size_t)(n0 + k0 + r) * ldk + h * DK + c4);
+            *reinterpret_cast<f32x4*>(sV + r * PITCH + c4) = *reinterpret_cast<const f32x4*>(V + (size_t)(n0 + k0 + r) * ldv + h * DK + c4);
+        }
+        __syncthreads();
+        for (int j = ksi; j < kn; j += 4) {
+            float sc = 0.f;
+#pragma unroll
+            for (int g = 0; g < DP / 4; ++g) {
+                const f32x4 kk = *reinterpret_cast<const f32x4*>(sK + j * PITCH + part * DP + 4 * g);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) sc = fmaf(q[4 * g + c], kk[c], sc);
+            }
+            sc += __shfl_xor(sc, 1);
+            sc += __shfl_xor(sc, 2);
+            if (brow) sc += brow[k0 + j];
+            const float m_new = fmaxf(m_run, sc);
+            const float alpha = __expf(m_run - m_new);
+            const float p = __expf(sc - m_new);
+            l_run = l_run * alpha + p;
+            m_run = m_new;
+#pragma unroll
+            for (int g = 0; g < DP / 4; ++g) {
+                const f32x4 vv = *reinterpret_cast<const f32x4*>(sV + j * PITCH + part * DP + 4 * g);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[4 * g + c] = fmaf(acc[4 * g + c], alpha, p * vv[c]);
+            }
+        }
+    }
+    // merge the four key phases (lane bits 2 and 3); a phase that saw no key has m = -inf, l = 0
+#pragma unroll
+    for (int sh = 4; sh <= 8; sh <<= 1) {
+        const float m_o = __shfl_xor(m_run, sh), l_o = __shfl_xor(l_run, sh);
+        const float m_new = fmaxf(m_run, m_o);
+        const float a = m_run == -INFINITY ? 0.f : __expf(m_run - m_new), b = m_o == -INFINITY ? 0.f : __expf(m_o - m_new);
+        l_run = l_run * a + l_o * b;
+#pragma unroll
+        for (int d = 0; d < DP; ++d) acc[d] = acc[d] * a + __shfl_xor(acc[d], sh) * b;
+        m_run = m_new;
+    }
+    if (valid && ksi == 0) {
+        const float inv = 1.f / l_run;
+#pragma unroll
+        for (int g = 0; g < DP / 4; ++g) {
+            f32x4 o;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[c] = acc[4 * g + c] * inv;
+            *reinterpret_cast<f32x4*>(O + (size_t)qrow * ldo + h * DK + part * DP + 4 * g) = o;
+        }
+    }
+}
 // d_k = 512 / NUM_HEADS: 64 (shipped), 32 or 128.  bias may be NULL (no additive term): the generic (VALU) path of the
 // edge cross-attention for d_k != 64 runs through this kernel too, with the scenes' EDGE ranges as scene_ptr.
 int launch_node_attn(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
                      const float* bias, const int32_t* scene_ptr, const int64_t* bias_ptr, int n_scenes, int max_n,
-                     int n_heads, int dk, float scale, hipStream_t s) {
+                     int n_heads, int dk, float scale, hipStream_t s, int split_below) {
     if (n_scenes <= 0 || max_n <= 0) return 0;
     if ((ldq | ldk | ldv | ldo) & 3) return fail(-1, "node_attn: leading dims must be multiples of 4");
     const dim3 grid((max_n + 63) / 64, n_heads, n_scenes);
+    // too few one-query-per-lane waves to occupy the chip: sixteen lanes per query instead
+    if ((long)grid.x * n_heads * n_scenes < split_below) {
+        const dim3 g16((max_n + 15) / 16, n_heads, n_scenes);
+        switch (dk) {
+            case 32: hipLaunchKernelGGL(node_attn_split_kernel<32>, g16, dim3(256), 0, s, Q, ldq, K, ldk, V, ldv, O, ldo, bias, scene_ptr, bias_ptr, scale); break;
+            case 64: hipLaunchKernelGGL(node_attn_split_kernel<64>, g16, dim3(256), 0, s, Q, ldq, K, ldk, V, ldv, O, ldo, bias, scene_ptr, bias_ptr, scale); break;
+            case 128: hipLaunchKernelGGL(node_attn_split_kernel<128>, g16, dim3(256), 0, s, Q, ldq, K, ldk, V, ldv, O, ldo, bias, scene_ptr, bias_ptr, scale); break;
+            default: return fail(-1, "node_attn: head dim must be 32, 64 or 128");
+        }
+        VLSAT_LAUNCH_CHECK("node_attn");
+        return 0;
+    }
     switch (dk) {
         case 32: hipLaunchKernelGGL(node_attn_kernel<32>, grid, dim3(64), 0, s, Q, ldq, K, ldk, V, ldv, O, ldo, bias, scene_ptr, bias_ptr, scale); break;
         case 64: hipLaunchKernelGGL(node_attn_kernel<64>, grid, dim3(64), 0, s, Q, ldq, K, ldk, V, ldv, O, ldo, bias, scene_ptr, bias_ptr, scale); break;

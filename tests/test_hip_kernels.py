@@ -548,3 +548,68 @@ def test_half_row_format_gemm_and_attention(lib):
     ref = _ref_attn(qs / sc, k, v, tok, 0.125)
     assert float((got - ref).abs().max()) < 8e-2
     assert float((got - plain).abs().max()) < 3e-2          # (the outputs themselves are rounded to bf16 here)
+
+
+# ---- split-K kernel of the small launches (gemm_splitk.hip) ---------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(9, 512, 512), (80, 3328, 512), (80, 512, 768), (40, 160, 512), (72, 26, 256), (600, 512, 1024),
+                                   (1500, 1024, 512), (130, 1536, 128), (7, 40, 64)])
+def test_gemm_splitk_matches_persistent_kernel(lib, M, N, K):
+    """Small launches cut their k range over several CUs and reduce in the kernel.  Against the persistent kernel (other
+    summation order: fp32 roundoff only), with every epilogue operand, and twice for run-to-run bit equality (the
+    reduction order is fixed, whichever block arrives last)."""
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A = torch.randn(M, K, generator=g).to(DEV)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    resid = torch.randn(M, N, generator=g).to(DEV)
+    rows = torch.rand(M, generator=g).to(DEV) + 0.5
+    G0 = torch.randn(50, 2 * N, generator=g).to(DEV)
+    gi0 = torch.randint(0, 50, (M,), generator=g).to(torch.int32).to(DEV)
+    gi1 = torch.randint(0, 50, (M,), generator=g).to(torch.int32).to(DEV)
+    cases = [dict(bias=bias), dict(bias=bias, resid=resid, resid_scale=0.5, act=1), dict(bias=bias, rowscale=rows),
+             dict(g0=G0, gi0=gi0, g1=G0[:, N:], gi1=gi1, act=1, relu_a=1), dict(bias=bias, act=2, relu_a=1)]
+    for kw in cases:
+        ref = _ref_gemm(A, W, **kw)
+        plain = _gemm(lib, A, W, **kw)
+        kw4 = dict(kw, relu_a=kw.get("relu_a", 0) | 4)
+        got = _gemm(lib, A, W, **kw4)
+        again = _gemm(lib, A, W, **kw4)
+        assert torch.equal(got, again), "split-K result changed between two identical launches"
+        assert float((got - ref).abs().max()) < 2e-4 and float((got - plain).abs().max()) < 1e-4, kw.keys()
+
+
+@pytest.mark.parametrize("prec,fmt", [(3, 0), (1, 0), (3, 5), (1, 5), (1, 37)])
+def test_gemm_splitk_bf16_modes(lib, prec, fmt):
+    """The same in the bf16 modes (fp32, split-pair and half-row operands) against the persistent kernel."""
+    l = lib.load()
+    g = torch.Generator().manual_seed(99 + fmt)
+    for M, N, K in ((80, 512, 512), (600, 1024, 512), (300, 512, 1024)):
+        A = torch.randn(M, K, generator=g)
+        if fmt & 32:
+            A = A.to(torch.bfloat16).float()
+        W = (torch.randn(N, K, generator=g) / 16).to(DEV)
+        b = torch.randn(N, generator=g).to(DEV)
+        hi = torch.empty(N * K + 128, dtype=torch.int16, device=DEV)
+        lo = torch.empty_like(hi)
+        lib.check(l.vlsat_k_split_bf16(W.data_ptr(), N * K, hi.data_ptr(), lo.data_ptr(), lib.stream_ptr()))
+        if fmt & 32:
+            Ad = _to_half_rows(A).to(DEV)
+        elif fmt & 1:
+            Ad = _pack_split(A).to(DEV)
+        else:
+            Ad = A.to(DEV)
+
+        def run(extra):
+            Cb = torch.zeros(M, N, device=DEV)
+            lib.check(l.vlsat_k_gemm_planes(Ad.data_ptr(), K, W.data_ptr(), hi.data_ptr(), lo.data_ptr(), K, Cb.data_ptr(), N, M, N, K,
+                                            b.data_ptr(), 0, 0, 1.0, 0, 0, 0, 0, 0, 0, 1, 1, prec, 0, -1, fmt | extra, 1.0,
+                                            lib.stream_ptr()))
+            _sync()
+            return Cb.cpu()
+        plain, split = run(0), run(64)
+        if fmt & 4:
+            unpack = (lambda t: _from_half_rows(t, N)) if fmt & 32 else _unpack_split
+            plain, split = unpack(plain), unpack(split)
+        tol = 2e-2 if fmt & 32 else 1e-4
+        assert float((plain - split).abs().max()) < tol, (M, N, K, float((plain - split).abs().max()))
+        assert torch.equal(split, (lambda t: (_from_half_rows(t, N) if fmt & 32 else _unpack_split(t)) if fmt & 4 else t)(run(64)))

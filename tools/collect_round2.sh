@@ -8,11 +8,13 @@ cd "$ROOT"
 python bench.py > "$OUT/bench_fp32.json" 2> "$OUT/bench_fp32.err"
 python bench.py --gemm-precision bf16x3 > "$OUT/bench_cfg3_bf16x3.json" 2> "$OUT/bench_cfg3_bf16x3.err"
 python bench.py --gemm-precision bf16_mixed > "$OUT/bench_cfg3_bf16_mixed.json" 2> "$OUT/bench_cfg3_bf16_mixed.err"
+python bench.py --no-cpu --gemm-precision bf16 > "$OUT/bench_cfg3_bf16.json" 2> "$OUT/bench_cfg3_bf16.err"
 for m in fp32 bf16x3; do
   python bench.py --scenes 1 --objects 200 --points 1024 --steps 10 --warmup 2 --no-cpu --gemm-precision $m > "$OUT/bench_cfg5_$m.json" 2> "$OUT/bench_cfg5_$m.err"
 done
 tools/profile_run.sh r02/prof_fp32 > /dev/null 2>&1
 tools/profile_run.sh r02/prof_cfg3 --gemm-precision bf16x3 > /dev/null 2>&1
+tools/profile_run.sh r02/prof_cfg3_mixed --gemm-precision bf16_mixed > /dev/null 2>&1
 python tools/latency_probe.py > "$OUT/latency_fp32.txt" 2>&1
 python tools/latency_probe.py --gemm-precision bf16x3 > "$OUT/latency_bf16x3.txt" 2>&1
 tools/single_scene_trace.sh r02/single_fp32 --single-only > /dev/null 2>&1
@@ -22,8 +24,18 @@ python tools/gemm_bench.py --prec 3 --only E --fmt 5 --prefetch 0,6 > "$OUT/gemm
 python tools/gemm_bench.py --prec 3 --only E --fmt 21 --prefetch 6 > "$OUT/gemm_bf16x3_noring.txt" 2>&1
 python tools/gemm_bench.py --prec 3 --only E --no-dma > "$OUT/gemm_bf16x3_vgpr.txt" 2>&1
 python tools/gemm_bench.py --prec 1 --only E --fmt 5 > "$OUT/gemm_bf16.txt" 2>&1
+python tools/gemm_bench.py --prec 1 --only E --fmt 37 > "$OUT/gemm_bf16_half.txt" 2>&1
 tools/bin/l2_fill_probe > "$OUT/l2_fill.txt" 2>&1
 tools/bin/tr_read_probe > "$OUT/tr_read.txt" 2>&1
 python tools/eval_synth.py > "$OUT/eval_synth.txt" 2>&1
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --hip-runtime-trace --stats -d "$OUT/api" -o api --output-format csv -- python "$ROOT/tools/api_trace_forward.py" > "$OUT/api_trace.txt" 2> "$OUT/api_trace.log" )
+python - "$OUT" <<'PY'
+import csv, glob, sys
+out = sys.argv[1]
+for f in glob.glob(out + "/api/**/*hip_api_stats.csv", recursive=True) + glob.glob(out + "/api/**/*_stats.csv", recursive=True):
+    rows = list(csv.reader(open(f)))
+    open(out + "/api_stats_" + f.split("/")[-1], "w").write("\n".join(",".join(r) for r in rows[:40]) + "\n")
+PY
+rm -rf "$OUT/api"
+du -sh "$OUT"
 ls "$OUT"

@@ -39,8 +39,10 @@ def main():
     ap.add_argument("--no-dma", action="store_true", help="bf16 modes: the VGPR-staged operand pipe of round 1")
     ap.add_argument("--prefetch", default="-1", help="bf16 LDS-direct pipe: A-prefetch look-ahead(s) in slices, comma separated")
     ap.add_argument("--no-prefetch", action="store_true", help="fp32: without the A-panel prefetch")
-    ap.add_argument("--fmt", type=int, default=0, help="bit 0: A, bit 1: resid, bit 2: C in the split-pair format (timing only)")
+    ap.add_argument("--fmt", type=int, default=0, help="bit 0: A, bit 1: resid, bit 2: C in the split-pair format, bit 5: half rows instead (timing only)")
     ap.add_argument("--rows", type=int, default=0, help="override M of the edge-row shapes (e.g. 8192: operands stay in L2)")
+    ap.add_argument("--splitk", action="store_true", help="small launches may take the split-K kernel (what the engine does)")
+    ap.add_argument("--nodes", type=int, default=0, help="override M of the node-row shapes (one scene: 9..80)")
     a = ap.parse_args()
     peak = {0: 157.3, 1: 2500.0, 3: 2500.0 / 3}[a.prec]
     lib = L.load()
@@ -51,6 +53,8 @@ def main():
             continue
         if a.rows and M == E:
             M = a.rows
+        elif a.nodes and M == N:
+            M = a.nodes
         A = torch.randn(M, K, generator=g).to(dev)
         W = (torch.randn(Nn, K, generator=g) * 0.05).to(dev)
         Cb = torch.empty(M, Nn, device=dev)
@@ -69,14 +73,14 @@ def main():
                                             bias.data_ptr(), L.ptr(R), Nn if resid else 0, 1.0,
                                             L.ptr(G0), L.ptr(gi), 2 * Nn if gather else 0,
                                             (G0.data_ptr() + 4 * Nn) if gather else 0, L.ptr(gi), 2 * Nn if gather else 0,
-                                            0, 1, a.prec, int(a.no_dma), pf, a.fmt, 1.0, L.stream_ptr()))
+                                            0, 1, a.prec, int(a.no_dma), pf, a.fmt | (64 if a.splitk else 0), 1.0, L.stream_ptr()))
 
         def run():
             L.check(lib.vlsat_k_gemm(A.data_ptr(), K, W.data_ptr(), K, Cb.data_ptr(), Nn, M, Nn, K, bias.data_ptr(), 0,
                                      L.ptr(R), Nn if resid else 0, 1.0,
                                      L.ptr(G0), L.ptr(gi), 2 * Nn if gather else 0,
                                      (G0.data_ptr() + 4 * Nn) if gather else 0, L.ptr(gi), 2 * Nn if gather else 0,
-                                     2 if a.no_prefetch else 0, 1, L.stream_ptr()))
+                                     (2 if a.no_prefetch else 0) | (4 if a.splitk else 0), 1, L.stream_ptr()))
         variants = [("", run)] if not a.prec else [(f" pf={d}", (lambda d=d: run_planes(int(d)))) for d in a.prefetch.split(",")]
         for tag, fn in variants:
             for _ in range(3):

@@ -27,11 +27,14 @@ def main():
     ap.add_argument("--points", type=int, default=256)
     ap.add_argument("--layers", type=int, default=3)
     ap.add_argument("--gemm-precision", default="fp32", choices=["fp32", "bf16x3", "bf16_mixed", "bf16"])
+    ap.add_argument("--debug-option", action="append", default=[], metavar="NAME=VALUE")
     ap.add_argument("--single-only", action="store_true", help="skip the all-scenes-in-one-call comparison (clean kernel traces)")
     a = ap.parse_args()
     dev = "cuda:0"
     cfg = VLSATConfig(N_LAYERS=a.layers)
     model = VLSATModel(cfg, dev).load_state(synth.make_weights(cfg)).eval().set_gemm_precision(a.gemm_precision)
+    for kv in a.debug_option:
+        model.debug_option(kv.split("=")[0], int(kv.split("=")[1]))
     rng = np.random.default_rng(5)
     sizes = rng.integers(9, 81, a.scenes)
     scenes = [synth.make_scene(int(n), a.points, seed=100 + i) for i, n in enumerate(sizes)]
@@ -47,8 +50,10 @@ def main():
         return model.forward(it["obj_points"], it["obj_2d_feats"], it["edge_indices"], it["descriptor"], it["batch_ids"],
                              fc_sizes=[n] if hint else None)
 
-    for it in items[:3]:                                   # warm-up: allocator, kernels
-        call(it)
+    # warm-up with OTHER scenes across the size range: allocator, and the code object of every kernel variant the sizes
+    # select is loaded on its first launch (a long-running evaluation has seen them all after a few scenes)
+    for n in (9, 20, 33, 47, 64, 80):
+        call(to_dev(synth.collate([synth.make_scene(n, a.points, seed=9000 + n)])))
     torch.cuda.synchronize()
     model._drop_plans()
     t_fwd, t_rank = [], []

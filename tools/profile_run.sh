@@ -24,4 +24,6 @@ pass fetch FETCH_SIZE
 pass write WRITE_SIZE
 pass l2 TCC_HIT TCC_MISS TCC_REQ TCC_EA0_RDREQ
 python "$ROOT/tools/pmc_summary.py" "$OUT/pmc_sq" "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc.md" "$OUT/pmc_l2" > /dev/null 2> "$OUT/pmc_summary.err"
+# the raw traces are tens of MB; gpurun merges at most 64 MiB back (KEEP_RAW=1 keeps them)
+[ "${KEEP_RAW:-0}" = 1 ] || rm -rf "$OUT/kt" "$OUT"/pmc_sq "$OUT"/pmc_fetch "$OUT"/pmc_write "$OUT"/pmc_l2
 ls "$OUT"

@@ -32,4 +32,5 @@ txt = (f"{len(vl)} vlsat kernel launches: total execution {busy / 1e6:.2f} ms, m
 open(out + "/trace_summary.txt", "w").write(txt)
 print(txt)
 PY
+[ "${KEEP_RAW:-0}" = 1 ] || rm -rf "$OUT/kt"
 cat "$OUT/latency.txt"
