@@ -106,6 +106,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmArgs p, int n_til
             asm volatile("" : "+s"(ldr), "+s"(ldg0), "+s"(ldg1), "+v"(lv));
             const int l2 = lv & 31, h2 = lv >> 5;
             const float* rbase = (ADD & 1) ? p.resid + (size_t)m0 * ldr + n0 : nullptr;
+with_resid_format((ADD & 1) ? p.r_split : 0, [&](auto fmt) {
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) {
                 int nl = (wn * TN + tn) * 32 + l2;
@@ -118,13 +119,14 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmArgs p, int n_til
                         if (m0 + ml >= p.M) ml = p.M - 1 - m0;
                         float x = 0.f;
                         if (ADD & 1) {
-                            x = p.resid_scale * load_resid(p, rbase, ml, nl, ldr, n0);
+                            x = p.resid_scale * load_resid<decltype(fmt)::value>(rbase, ml, nl, ldr, n0);
                         }
                         if (ADD & 2) x += p.g0[(unsigned)(p.gi0[m0 + ml] * ldg0 + n0 + nl)];
                         if (ADD & 4) x += p.g1[(unsigned)(p.gi1[m0 + ml] * ldg1 + n0 + nl)];
                         acc[tm][tn][r] = x;
                     }
             }
+            });
         }
         for (int kt = 0; kt < KT; ++kt) {
             // this wave's part of the current slice has landed (at most one younger slice stays in flight) ...

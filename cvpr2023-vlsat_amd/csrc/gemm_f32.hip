@@ -128,6 +128,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int n_tile
                 asm volatile("" : "+s"(ldr), "+s"(ldg0), "+s"(ldg1), "+v"(lv));
                 const int li = lv & 31, hi = lv >> 5;
                 const float* rbase = (ADD & 1) ? p.resid + (size_t)m0 * ldr + n0 : nullptr;
+                with_resid_format((ADD & 1) ? p.r_split : 0, [&](auto fmt) {
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) {
                     int nl = (wn * TN + tn) * 32 + li;                    // column inside the tile
@@ -140,13 +141,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int n_tile
                             if (m0 + ml >= p.M) ml = p.M - 1 - m0;
                             float x = 0.f;
                             if (ADD & 1) {
-                                x = p.resid_scale * load_resid(p, rbase, ml, nl, ldr, n0);
+                                x = p.resid_scale * load_resid<decltype(fmt)::value>(rbase, ml, nl, ldr, n0);
                             }
                             if (ADD & 2) x += p.g0[(unsigned)(p.gi0[m0 + ml] * ldg0 + n0 + nl)];
                             if (ADD & 4) x += p.g1[(unsigned)(p.gi1[m0 + ml] * ldg1 + n0 + nl)];
                             acc[tm][tn][r] = x;
                         }
                 }
+                });
             }
 #pragma unroll
             for (int ks = 0; ks < KSL; ++ks) Pipe::mma(cur + ks * SLICE, wm, wn, acc, lane, p.relu_a);

@@ -80,7 +80,11 @@ __global__ __launch_bounds__(256, 2) void gemm_splitk_kernel(GemmArgs p, int n_t
         int ml = wm * 32 + crow32(r, hi);
         if (m0 + ml >= p.M) ml = p.M - 1 - m0;
         float x = 0.f;
-        if (p.resid) x = p.resid_scale * load_resid(p, p.resid + (size_t)m0 * p.ldr + n0, ml, ncl, p.ldr, n0);
+        if (p.resid) {
+            const float* rb = p.resid + (size_t)m0 * p.ldr + n0;
+            x = p.resid_scale * (p.r_split == 2 ? load_resid<2>(rb, ml, ncl, p.ldr, n0) : p.r_split == 1 ? load_resid<1>(rb, ml, ncl, p.ldr, n0)
+                                                                                                      : load_resid<0>(rb, ml, ncl, p.ldr, n0));
+        }
         if (p.g0) x += p.g0[(size_t)p.gi0[m0 + ml] * p.ldg0 + n0 + ncl];
         if (p.g1) x += p.g1[(size_t)p.gi1[m0 + ml] * p.ldg1 + n0 + ncl];
         out[r] = x;
