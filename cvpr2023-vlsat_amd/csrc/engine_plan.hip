@@ -232,20 +232,25 @@ int vlsat_plan_create(vlsat_handle h, const int64_t* bid, const int64_t* edges, 
     }
     sweep_trash(h, false);
     hipEvent_t prev_use = nullptr;
-    {   // smallest pooled arena that fits (and is not absurdly larger), else a fresh allocation
+    {   // smallest pooled arena that fits (and is not absurdly larger), else a fresh allocation of the next SIZE CLASS
+        // (2^k or 1.5 * 2^k bytes): an evaluation loop sees a new graph size almost every scene, and with exact sizes
+        // nearly every plan would allocate and nearly every evicted one would end in hipFree (which waits for the device:
+        // profiles/r02_hip_api_trace.txt had 48 of them in 80 forwards before the classes)
         int best = -1;
         for (size_t i = 0; i < h->arena_pool.size(); ++i)
             if (h->arena_pool[i].bytes >= total && h->arena_pool[i].bytes <= 4 * total + (64u << 20) &&
                 (best < 0 || h->arena_pool[i].bytes < h->arena_pool[best].bytes))
                 best = (int)i;
+        size_t cls = size_t(1) << 20;
+        while (cls < total) cls = (cls & (cls - 1)) ? (cls / 3) * 4 : cls + cls / 2;      // 1, 1.5, 2, 3, 4, 6, ... MiB
         if (best >= 0) {
             p->arena = h->arena_pool[best].p;
             p->arena_bytes = h->arena_pool[best].bytes;
             prev_use = h->arena_pool[best].last;
             h->arena_pool.erase(h->arena_pool.begin() + best);
         } else {
-            VLSAT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p->arena), total));
-            p->arena_bytes = total;
+            VLSAT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p->arena), cls));
+            p->arena_bytes = cls;
         }
     }
     size_t off = 0;
@@ -297,8 +302,17 @@ void vlsat_plan_destroy(vlsat_plan p) {
         // of the upload, if the plan never ran) and whoever takes it next waits for it ON THE DEVICE.  No host wait.
         Arena a{p->arena, p->arena_bytes, p->used ? p->last_use : p->uploaded};
         give_event(h, p->used ? p->uploaded : p->last_use);
-        if (h->arena_pool.size() < 8) h->arena_pool.push_back(a);
-        else h->arena_trash.push_back(a);
+        // the pool is bounded by bytes (8 GiB of 288) and count; beyond that the largest pooled arena goes
+        h->arena_pool.push_back(a);
+        size_t pooled = 0;
+        for (auto& x : h->arena_pool) pooled += x.bytes;
+        while (h->arena_pool.size() > 1 && (pooled > (size_t(8) << 30) || h->arena_pool.size() > 64)) {
+            size_t big = 0;
+            for (size_t i = 1; i < h->arena_pool.size(); ++i) if (h->arena_pool[i].bytes > h->arena_pool[big].bytes) big = i;
+            pooled -= h->arena_pool[big].bytes;
+            h->arena_trash.push_back(h->arena_pool[big]);
+            h->arena_pool.erase(h->arena_pool.begin() + big);
+        }
         sweep_trash(h, false);
     }
     delete p;

@@ -30,22 +30,30 @@ namespace vlsat {
 
 namespace {
 
-constexpr int RBM = 256, RBN = 128, RST = 3;
 
-template <int TERMS, int AFMT, int ADD>
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// Block tile RBM x RBN = 256 x 128 (waves 4 x 2; the default) or 128 x 256 (waves 2 x 4; GemmArgs::ring_wide); wave tile
+// 64 x 64 either way.  The second shape halves the bytes of A (read once, from HBM / Infinity Cache) per flop and doubles
+// those of the weights (re-read from L2); it measured the same time on every launch of the forward -- the fill path does
+// not care where the bytes come from -- and is kept as an experiment switch only.
+template <int TERMS, int AFMT, int ADD, int RBN>
 __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmArgs p, int n_tiles, int nbn) {
+    constexpr int RBM = 32768 / RBN;
     using Frag = PipeSplitDma<128, 128, TERMS, AFMT>;        // fragment-side helpers only (split8 / frag_half)
     constexpr bool AH = AFMT == 2;                           // A as half rows (bf16): 64-byte slices like the weight planes
     constexpr int PL = TERMS == 1 ? 1 : 2;
-    constexpr int TM = 2, TN = 2;
+    constexpr int TM = 2, TN = 2, WR = RBN / 128;            // (WR: 128-row rounds of a weight-plane slice)
+    constexpr int AR = AFMT == 2 ? RBM / 128 : RBM / 64;     // instruction rounds of an A slice (128 | 64 rows each)
     constexpr int A_BYTES = AH ? RBM * BK * 2 : RBM * BK * 4, W_PLANE = RBN * BK * 2;
     constexpr int STAGE = A_BYTES + PL * W_PLANE;            // 48 KB (40 KB with one plane, 24 KB with half-row A)
-    constexpr int LPS = (AH ? 2 : 4) + PL;                   // LDS-direct loads per wave per slice
+    constexpr int LPS = AR + PL * WR;                        // LDS-direct loads per wave per slice
+    constexpr int RST = 3;                                   // ring stages (five 24 KB stages in the half-row mode measured no faster)
     __shared__ __attribute__((aligned(16))) char smem[RST * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = RBN == 128 ? wave >> 1 : wave >> 2, wn = RBN == 128 ? wave & 1 : wave & 3;
     const int li = lane & 31, hi = lane >> 5;
     const int g8 = gridDim.x >> 3, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int KT = p.K / BK;
@@ -67,17 +75,21 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmArgs p, int n_til
         if (AH) {                     // 256 rows x 64 B: 16 rows per instruction, 8 waves -> 128 rows per round, two rounds
             char* sa = stage + wave * 16 * BK * 2;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < AR; ++i)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, sa + i * 128 * BK * 2, 16, va + (unsigned)((m0 + 128 * i) * p.lda * 4 + k0 * 2), 0, 0, 0);
         } else {
             float* sa = reinterpret_cast<float*>(stage) + wave * 8 * BK;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < AR; ++i)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, sa + i * 64 * BK, 16, va + (unsigned)(((m0 + 64 * i) * p.lda + k0) * 4), 0, 0, 0);
         }
         char* sw = stage + A_BYTES + wave * 16 * BK * 2;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rwh, sw, 16, vw + (unsigned)((n0 * p.ldw + k0) * 2), 0, 0, 0);
-        if (PL == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rwl, sw + W_PLANE, 16, vw + (unsigned)((n0 * p.ldw + k0) * 2), 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < WR; ++i) {
+            const unsigned off = vw + (unsigned)(((n0 + 128 * i) * p.ldw + k0) * 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rwh, sw + i * 128 * BK * 2, 16, off, 0, 0, 0);
+            if (PL == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rwl, sw + W_PLANE + i * 128 * BK * 2, 16, off, 0, 0, 0);
+        }
     };
 
     // ---- issue cursor: two slices ahead of the compute cursor ----
@@ -85,13 +97,13 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmArgs p, int n_til
     auto issue_next = [&]() {
         const int v = tile_of_round(ir);
         if (v >= n_tiles) return;
-        issue((v / nbn) * RBM, (v % nbn) * RBN, ikt * BK, smem + ibuf * STAGE);
+        if (!(p.ablate & 1) || (ir == 0 && ikt < RST)) issue((v / nbn) * RBM, (v % nbn) * RBN, ikt * BK, smem + ibuf * STAGE);
         ibuf = ibuf == RST - 1 ? 0 : ibuf + 1;
         if (++ikt == KT) { ikt = 0; ++ir; }
         ++ahead;
     };
-    issue_next();
-    issue_next();
+#pragma unroll
+    for (int i = 0; i < RST - 1; ++i) issue_next();
 
     f32x16 acc[TM][TN];
     zero_acc<TM, TN>(acc);
@@ -100,43 +112,11 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmArgs p, int n_til
         const int v = tile_of_round(round);
         if (v >= n_tiles) break;
         const int m0 = (v / nbn) * RBM, n0 = (v % nbn) * RBN;
-        if (ADD != 0) {
-            // additive operands (residual / gathered rows) straight into the accumulators (see gemm_f32.hip)
-            int ldr = p.ldr, ldg0 = p.ldg0, ldg1 = p.ldg1, lv = lane;
-            asm volatile("" : "+s"(ldr), "+s"(ldg0), "+s"(ldg1), "+v"(lv));
-            const int l2 = lv & 31, h2 = lv >> 5;
-            const float* rbase = (ADD & 1) ? p.resid + (size_t)m0 * ldr + n0 : nullptr;
-with_resid_format((ADD & 1) ? p.r_split : 0, [&](auto fmt) {
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn) {
-                int nl = (wn * TN + tn) * 32 + l2;
-                if (n0 + nl >= p.N) nl = p.N - 1 - n0;
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        int ml = (wm * TM + tm) * 32 + crow32(r, h2);
-                        if (m0 + ml >= p.M) ml = p.M - 1 - m0;
-                        float x = 0.f;
-                        if (ADD & 1) {
-                            x = p.resid_scale * load_resid<decltype(fmt)::value>(rbase, ml, nl, ldr, n0);
-                        }
-                        if (ADD & 2) x += p.g0[(unsigned)(p.gi0[m0 + ml] * ldg0 + n0 + nl)];
-                        if (ADD & 4) x += p.g1[(unsigned)(p.gi1[m0 + ml] * ldg1 + n0 + nl)];
-                        acc[tm][tn][r] = x;
-                    }
-            }
-            });
-        }
+        if (ADD != 0) tile_init<TM, TN, ADD>(p, m0, n0, wm, wn, lane, acc);      // additive operands straight into the accumulators
         for (int kt = 0; kt < KT; ++kt) {
             // this wave's part of the current slice has landed (at most one younger slice stays in flight) ...
-            if (ahead >= 2) {
-                if (LPS == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                else if (LPS == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
+            if (ahead >= RST - 1) wait_vmcnt<(RST - 2) * LPS>();
+            else wait_vmcnt<0>();
             // ... everyone's has, and everyone is done with the slot the next issue overwrites
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             --ahead;
@@ -149,142 +129,93 @@ with_resid_format((ADD & 1) ? p.r_split : 0, [&](auto fmt) {
             const int swa = (li >> 1) & 7, sww = (li >> 2) & 3;
             auto slice = [&](auto relu_tag) {
                 constexpr bool RELU = decltype(relu_tag)::value;
+                constexpr int KS = BK / 16;
+                typedef short s16x8 __attribute__((ext_vector_type(8)));
+                // ALL fragment reads of the slice first (both k-steps), then the MFMAs: k-step 0's matrix work runs while
+                // k-step 1's fragments land, and the co-resident wave of the SIMD (same phase: one barrier per slice) finds
+                // the LDS queue free sooner.  Left to itself hipcc emitted read -> wait -> MFMA batches, i.e. the LDS
+                // latency several times per slice (ablation, kv launch: 405 us with the operand loads removed against a
+                // 126 us MFMA bound).  The sched_barriers pin the order.
+                f32x4 ax[KS][TM][2];
+                bf16x8 ah[KS][TM], w[KS][PL][TN];
 #pragma unroll
-                for (int ks = 0; ks < BK / 16; ++ks) {
-                    bf16x8 a[PL][TM], w[PL][TN];
+                for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
                     for (int tm = 0; tm < TM; ++tm) {
                         if (AH) {
-                            a[0][tm] = Frag::template frag_half<RELU>(sAh + tm * 32 * BK * 2 + 16 * ((2 * ks + hi) ^ sww));
+                            ah[ks][tm] = *reinterpret_cast<const bf16x8*>(sAh + tm * 32 * BK * 2 + 16 * ((2 * ks + hi) ^ sww));
                         } else {
                             const int c0 = (4 * ks + 2 * hi) ^ swa;
-                            const f32x4 x0 = *reinterpret_cast<const f32x4*>(sA + tm * 32 * BK + 4 * c0);
-                            const f32x4 x1 = *reinterpret_cast<const f32x4*>(sA + tm * 32 * BK + 4 * (c0 ^ 1));
-                            Frag::template split8<RELU>(x0, x1, a[0][tm], a[PL - 1][tm]);
+                            ax[ks][tm][0] = *reinterpret_cast<const f32x4*>(sA + tm * 32 * BK + 4 * c0);
+                            ax[ks][tm][1] = *reinterpret_cast<const f32x4*>(sA + tm * 32 * BK + 4 * (c0 ^ 1));
                         }
                     }
 #pragma unroll
                     for (int pl = 0; pl < PL; ++pl)
 #pragma unroll
                         for (int tn = 0; tn < TN; ++tn)
-                            w[pl][tn] = *reinterpret_cast<const bf16x8*>(sW + pl * W_PLANE + tn * 32 * BK * 2 + 16 * ((2 * ks + hi) ^ sww));
+                            w[ks][pl][tn] = *reinterpret_cast<const bf16x8*>(sW + pl * W_PLANE + tn * 32 * BK * 2 + 16 * ((2 * ks + hi) ^ sww));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    bf16x8 a[PL][TM];
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm) {
+                        if (AH) {
+                            s16x8 v = __builtin_bit_cast(s16x8, ah[ks][tm]);
+                            if (RELU) v = __builtin_elementwise_max(v, s16x8{0, 0, 0, 0, 0, 0, 0, 0});
+                            a[0][tm] = __builtin_bit_cast(bf16x8, v);
+                        } else {
+                            Frag::template split8<RELU>(ax[ks][tm][0], ax[ks][tm][1], a[0][tm], a[PL - 1][tm]);
+                        }
+                    }
                     // term-major order: the four accumulators take turns (no MFMA waits for its predecessor)
                     if (PL == 2) {
 #pragma unroll
                         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                             for (int tn = 0; tn < TN; ++tn)
-                                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][tm], w[0][tn], acc[tm][tn], 0, 0, 0);
+                                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ks][0][tn], a[1][tm], acc[tm][tn], 0, 0, 0);
 #pragma unroll
                         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                             for (int tn = 0; tn < TN; ++tn)
-                                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][tm], w[PL - 1][tn], acc[tm][tn], 0, 0, 0);
+                                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ks][PL - 1][tn], a[0][tm], acc[tm][tn], 0, 0, 0);
                     }
 #pragma unroll
                     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                         for (int tn = 0; tn < TN; ++tn)
-                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][tm], w[0][tn], acc[tm][tn], 0, 0, 0);
+                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ks][0][tn], a[0][tm], acc[tm][tn], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             };
+            if (p.ablate & 2) continue;                       // (timing experiment: no fragment reads, no MFMAs)
             if (p.relu_a) slice(std::true_type{});
             else slice(std::false_type{});
         }
-        // ---- epilogue (as gemm_f32.hip: straight-line code under wave-uniform flags) ----
-        int ldc = p.ldc, lv = lane;
-        asm volatile("" : "+s"(ldc), "+v"(lv));
-        const int l2 = lv & 31, h2 = lv >> 5;
-        float* cbase = p.C + (size_t)m0 * ldc + n0;
-        if (p.bias) {
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn) {
-                int n = n0 + (wn * TN + tn) * 32 + l2;
-                n = n < p.N ? n : p.N - 1;
-                const float bn = p.bias[n];
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[tm][tn][r] += bn;
-            }
-        }
-        if (p.act == ACT_RELU) {
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[tm][tn][r] = fmaxf(acc[tm][tn][r], 0.f);
-        } else if (p.act == ACT_SIGMOID) {
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 1.f / (1.f + __expf(-acc[tm][tn][r]));
-        }
-        if (p.c_scale != 1.f) {
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[tm][tn][r] *= p.c_scale;
-        }
-        if (p.c_split == 2) {
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int ml = (wm * TM + tm) * 32 + crow32(r, h2), nl = (wn * TN + tn) * 32 + l2;
-                        if (m0 + ml < p.M && n0 + nl < p.N) store_half(cbase, ml, nl, ldc, n0, acc[tm][tn][r]);
-                    }
-        } else {
-        if (p.c_split) {
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[tm][tn][r] = pack_split(acc[tm][tn][r]);
-        }
-        if (m0 + RBM <= p.M && n0 + RBN <= p.N) {
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int ml = (wm * TM + tm) * 32 + crow32(r, h2), nl = (wn * TN + tn) * 32 + l2;
-                        cbase[(unsigned)(ml * ldc + nl)] = acc[tm][tn][r];
-                    }
-        } else {
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int ml = (wm * TM + tm) * 32 + crow32(r, h2), nl = (wn * TN + tn) * 32 + l2;
-                        if (m0 + ml < p.M && n0 + nl < p.N) cbase[(unsigned)(ml * ldc + nl)] = acc[tm][tn][r];
-                    }
-        }
-        }
+        tile_epilogue<TM, TN>(p, m0, n0, RBM, RBN, wm, wn, lane, acc);
         zero_acc<TM, TN>(acc);
     }
 }
 
 }  // namespace
 
+template <int T, int S, int ADD>
+static void ring_launch(bool wide, const GemmArgs& a, int n_tiles, int nbn, int grid, hipStream_t s) {
+    if (!wide) hipLaunchKernelGGL((gemm_ring_kernel<T, S, ADD, 128>), dim3(grid), dim3(512), 0, s, a, n_tiles, nbn);
+    else hipLaunchKernelGGL((gemm_ring_kernel<T, S, ADD, 256>), dim3(grid), dim3(512), 0, s, a, n_tiles, nbn);
+}
+
 // full rounds of a large-M bf16 launch; returns 1 if this operand combination is not built (the caller then uses the
 // 128 x 128 kernel for everything)
-int launch_gemm_ring(const GemmArgs& a, int n_tiles, int grid, hipStream_t s) {
-    const int nbn = (a.N + RBN - 1) / RBN;
+int launch_gemm_ring(const GemmArgs& a, int rbn, int n_tiles, int grid, hipStream_t s) {
     const int add = (a.resid ? 1 : 0) | (a.g0 ? 2 : 0) | (a.g1 ? 4 : 0);
     if (a.rowscale || (add != 0 && add != 1 && add != 6)) return 1;
-#define VLSAT_RING(T, S, ADD) hipLaunchKernelGGL((gemm_ring_kernel<T, S, ADD>), dim3(grid), dim3(512), 0, s, a, n_tiles, nbn)
+    const bool wide = rbn == 256;
+    const int nbn = (a.N + rbn - 1) / rbn;
+#define VLSAT_RING(T, S, ADD) ring_launch<T, S, ADD>(wide, a, n_tiles, nbn, grid, s)
 #define VLSAT_RING_ADD(T, S)                      \
     switch (add) {                                \
         case 0: VLSAT_RING(T, S, 0); break;       \

@@ -24,6 +24,11 @@ constexpr int BK = 32;    // k-slice held in LDS per pipeline stage
 
 // residual element (ml, nl) of the tile whose first element is rbase = resid + m0 * ldr + n0, in the operand's format:
 // 0 fp32, 1 split-pair word, 2 half row (bf16 at byte 2 * column of the fp32-pitched row)
+// ---- accumulator-side access of the GEMM kernels -------------------------------------------------------------------------
+// The GEMM pipes issue the transposed product (mma_slice SWAP): element r of lane (li = lane & 31, hi = lane >> 5) in the
+// 32x32 tile (tm, tn) of wave (wm, wn) is C[(wm*TM + tm)*32 + li][(wn*TN + tn)*32 + crow32(r, hi)] -- one row per lane,
+// columns in four runs of 4 (r = 4g .. 4g+3 -> columns 8g + 4hi .. +3).  Everything below therefore moves 16 bytes per lane
+// and instruction (8 for bf16 half rows) where the untransposed layout needed four scalar accesses.
 template <int FMT>
 __device__ __forceinline__ float load_resid(const float* rbase, int ml, int nl, int ldr, int n0) {
     if (FMT == 2) {
@@ -33,19 +38,207 @@ __device__ __forceinline__ float load_resid(const float* rbase, int ml, int nl, 
     const float rv = rbase[(unsigned)(ml * ldr + nl)];
     return FMT == 1 ? unpack_split(rv) : rv;
 }
-// The format is a launch constant but a per-element branch on it keeps hipcc from batching the 64 loads of a lane
-// (measured: out-proj + residual 97 -> 79 TFLOP/s in fp32, 445 -> 161 in bf16): callers hoist it with this dispatcher and
-// run their whole unrolled loop nest under one constant.
+// four consecutive elements starting at column `col` (multiple of 4) of the fp32-pitched row `row`, in storage format FMT
+// (0 fp32, 1 split-pair words, 2 half row: bf16 at byte 2 * column)
+template <int FMT>
+__device__ __forceinline__ f32x4 load_row4(const float* row, int col) {
+    if (FMT == 2) {
+        const uint2 w = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(row) + col);
+        return f32x4{__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16), __uint_as_float(w.y & 0xffff0000u)};
+    }
+    f32x4 v = *reinterpret_cast<const f32x4*>(row + col);
+    if (FMT == 1) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = unpack_split(v[c]);
+    }
+    return v;
+}
+// The storage format is a launch constant, but a per-element branch on it keeps hipcc from batching a lane's loads
+// (measured: out-proj + residual 97 -> 79 TFLOP/s in fp32, 445 -> 161 in bf16): callers hoist it with this dispatcher.
 template <class F>
-__device__ __forceinline__ void with_resid_format(int r_split, F&& f) {
-    if (r_split == 2) f(std::integral_constant<int, 2>{});
-    else if (r_split == 1) f(std::integral_constant<int, 1>{});
+__device__ __forceinline__ void with_format(int fmt, F&& f) {
+    if (fmt == 2) f(std::integral_constant<int, 2>{});
+    else if (fmt == 1) f(std::integral_constant<int, 1>{});
     else f(std::integral_constant<int, 0>{});
 }
-// store of a finished accumulator element in the half-row format
-__device__ __forceinline__ void store_half(float* c_tile_row0, int ml, int nl, int ldc, int n0, float v) {
-    unsigned short* row = reinterpret_cast<unsigned short*>(c_tile_row0 - n0 + (size_t)ml * ldc);
-    row[n0 + nl] = __builtin_bit_cast(unsigned short, (__bf16)v);
+__device__ __forceinline__ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// Accumulator init of a tile = its additive operands: resid_scale * resid + g0[gi0[row]] + g1[gi1[row]] (ADD bits 0 / 1 / 2;
+// compile time, so the loads of a lane are branch-free and batched).  The first MFMA of the tile takes them as C-in.
+template <int TM, int TN, int ADD>
+__device__ __forceinline__ void tile_init(const GemmArgs& p, int m0, int n0, int wm, int wn, int lane, f32x16 (&acc)[TM][TN]) {
+    // 32-bit offsets from wave-uniform bases; the asm makes the lane id and pitches opaque per tile (otherwise LICM hoists
+    // all the per-lane offsets out of a persistent kernel's tile loop and it spills)
+    int ldr = p.ldr, ldg0 = p.ldg0, ldg1 = p.ldg1, lv = lane;
+    asm volatile("" : "+s"(ldr), "+s"(ldg0), "+s"(ldg1), "+v"(lv));
+    const int li = lv & 31, hi = lv >> 5;
+    const bool vec = n0 + (wn * TN + TN) * 32 <= p.N && ((ldr | ldg0 | ldg1) & 3) == 0 &&
+                     (!(ADD & 1) || aligned16(p.resid)) && (!(ADD & 2) || aligned16(p.g0)) && (!(ADD & 4) || aligned16(p.g1));
+    if (vec) {
+        with_format((ADD & 1) ? p.r_split : 0, [&](auto fmt) {
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                int m = m0 + (wm * TM + tm) * 32 + li;
+                m = m < p.M ? m : p.M - 1;
+                const float* rrow = (ADD & 1) ? p.resid + (size_t)m * ldr : nullptr;
+                const float* g0row = (ADD & 2) ? p.g0 + (size_t)p.gi0[m] * ldg0 : nullptr;
+                const float* g1row = (ADD & 4) ? p.g1 + (size_t)p.gi1[m] * ldg1 : nullptr;
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int col = n0 + (wn * TN + tn) * 32 + 8 * g + 4 * hi;
+                        f32x4 x = {0.f, 0.f, 0.f, 0.f};
+                        if (ADD & 1) x = load_row4<decltype(fmt)::value>(rrow, col) * p.resid_scale;
+                        if (ADD & 2) x += *reinterpret_cast<const f32x4*>(g0row + col);
+                        if (ADD & 4) x += *reinterpret_cast<const f32x4*>(g1row + col);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) acc[tm][tn][4 * g + c] = x[c];
+                    }
+            }
+        });
+        return;
+    }
+    // tiles cut by N (or operands that are not 16-byte addressable): element by element, clamped
+    with_format((ADD & 1) ? p.r_split : 0, [&](auto fmt) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            int m = m0 + (wm * TM + tm) * 32 + li;
+            m = m < p.M ? m : p.M - 1;
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int n = n0 + (wn * TN + tn) * 32 + crow32(r, hi);
+                    n = n < p.N ? n : p.N - 1;
+                    float x = 0.f;
+                    if (ADD & 1) x = p.resid_scale * load_resid<decltype(fmt)::value>(p.resid + (size_t)m * ldr, 0, n, 0, 0);
+                    if (ADD & 2) x += p.g0[(size_t)p.gi0[m] * ldg0 + n];
+                    if (ADD & 4) x += p.g1[(size_t)p.gi1[m] * ldg1 + n];
+                    acc[tm][tn][r] = x;
+                }
+        }
+    });
+}
+
+// Epilogue of a finished tile: row scale, bias, activation, final scale, store in the output format (c_split).  Everything
+// is straight-line code under WAVE-UNIFORM branches (per-element branches on the runtime flags cost ~30 % of the tile
+// time in the first version of the kernel).  BM / BN: the block tile (for the interior test).
+template <int TM, int TN>
+__device__ __forceinline__ void tile_epilogue(const GemmArgs& p, int m0, int n0, int BM, int BN, int wm, int wn, int lane,
+                                              f32x16 (&acc)[TM][TN]) {
+    int ldc = p.ldc, lv = lane;
+    asm volatile("" : "+s"(ldc), "+v"(lv));                          // see tile_init: no LICM of the store offsets
+    const int li = lv & 31, hi = lv >> 5;
+    const bool cols_in = n0 + (wn * TN + TN) * 32 <= p.N;            // this wave's columns are all inside N
+    if (p.rowscale) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            int m = m0 + (wm * TM + tm) * 32 + li;
+            m = m < p.M ? m : p.M - 1;
+            const float rs = p.rowscale[m];
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[tm][tn][r] *= rs;
+        }
+    }
+    if (p.bias) {
+        if (cols_in && aligned16(p.bias)) {
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n0 + (wn * TN + tn) * 32 + 8 * g + 4 * hi);
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) acc[tm][tn][4 * g + c] += b[c];
+                }
+        } else {
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int n = n0 + (wn * TN + tn) * 32 + crow32(r, hi);
+                    n = n < p.N ? n : p.N - 1;
+                    const float b = p.bias[n];
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm) acc[tm][tn][r] += b;
+                }
+        }
+    }
+    if (p.act == ACT_RELU) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[tm][tn][r] = fmaxf(acc[tm][tn][r], 0.f);
+    } else if (p.act == ACT_SIGMOID) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 1.f / (1.f + __expf(-acc[tm][tn][r]));
+    }
+    if (p.c_scale != 1.f) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[tm][tn][r] *= p.c_scale;
+    }
+    const bool interior = m0 + BM <= p.M && cols_in && (ldc & 3) == 0 && aligned16(p.C);
+    if (interior) {
+        with_format(p.c_split, [&](auto fmt) {
+            constexpr int FMT = decltype(fmt)::value;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                float* crow = p.C + (size_t)(m0 + (wm * TM + tm) * 32 + li) * ldc;
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int col = n0 + (wn * TN + tn) * 32 + 8 * g + 4 * hi;
+                        f32x4 v;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) v[c] = acc[tm][tn][4 * g + c];
+                        if (FMT == 2) {               // half rows: four bf16 = one 8-byte store
+                            uint2 w;
+                            w.x = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v[0]) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)v[1]) << 16);
+                            w.y = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v[2]) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)v[3]) << 16);
+                            *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(crow) + col) = w;
+                        } else {
+                            if (FMT == 1) {
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) v[c] = pack_split(v[c]);
+                            }
+                            *reinterpret_cast<f32x4*>(crow + col) = v;
+                        }
+                    }
+            }
+        });
+        return;
+    }
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        const int m = m0 + (wm * TM + tm) * 32 + li;
+        float* crow = p.C + (size_t)(m < p.M ? m : 0) * ldc;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + (wn * TN + tn) * 32 + crow32(r, hi);
+                if (m < p.M && n < p.N) {
+                    const float v = acc[tm][tn][r];
+                    if (p.c_split == 2) reinterpret_cast<unsigned short*>(crow)[n] = __builtin_bit_cast(unsigned short, (__bf16)v);
+                    else crow[n] = p.c_split ? pack_split(v) : v;
+                }
+            }
+    }
 }
 constexpr int LDT = 36;   // LDS row pitch in floats (BK + 4 pad)
 
@@ -83,7 +276,11 @@ __device__ __forceinline__ void stage_store(float* __restrict__ lds, const f32x4
 
 // One BK=32 slice of C[TM*32][TN*32] += A . B^T for one wave.
 // sA: LDS row 0 of this wave's A rows ([TM*32][LDT]); sB likewise for its B rows.
-template <int TM, int TN, int PITCH_A = LDT, int PITCH_B = LDT>
+// SWAP = false: lane holds C column (lane & 31) and 16 rows crow32(r, lane >> 5) of each 32x32 tile (PointNet kernel);
+// SWAP = true: the transposed product B.A^T -- lane holds C ROW (lane & 31) and 16 COLUMNS crow32(r, lane >> 5), i.e. four
+// runs of 4 consecutive columns, so every accumulator-side access of the GEMM kernels (residual, gathered rows, bias,
+// stores) is a 16-byte one (tile_init / tile_epilogue below).
+template <int TM, int TN, int PITCH_A = LDT, int PITCH_B = LDT, bool SWAP = false>
 __device__ __forceinline__ void mma_slice(const float* __restrict__ sA, const float* __restrict__ sB,
                                           f32x16 (&acc)[TM][TN], int lane) {
     const int li = lane & 31, hi = lane >> 5;
@@ -112,7 +309,8 @@ __device__ __forceinline__ void mma_slice(const float* __restrict__ sA, const fl
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[set][tm][s], b[set][tn][s], acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(b[set][tn][s], a[set][tm][s], acc[tm][tn], 0, 0, 0)
+                                       : __builtin_amdgcn_mfma_f32_32x32x2f32(a[set][tm][s], b[set][tn][s], acc[tm][tn], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         if (kg + 2 < BK / 8) {
             load(set, kg + 2);
@@ -158,7 +356,7 @@ struct PipeF32 {
     }
     static __device__ __forceinline__ void mma(const char* stage, int wm, int wn, f32x16 (&acc)[TM][TN], int lane, int = 0) {
         const float* s = reinterpret_cast<const float*>(stage);
-        mma_slice<TM, TN>(s + (wm * TM * 32) * LDT, s + BM * LDT + (wn * TN * 32) * LDT, acc, lane);
+        mma_slice<TM, TN, LDT, LDT, true>(s + (wm * TM * 32) * LDT, s + BM * LDT + (wn * TN * 32) * LDT, acc, lane);
     }
 };
 
@@ -239,7 +437,7 @@ struct PipeF32Dma {
                 for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn)
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[set][tm][s], b[set][tn][s], acc[tm][tn], 0, 0, 0);
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[set][tn][s], a[set][tm][s], acc[tm][tn], 0, 0, 0);   // transposed: see mma_slice
             __builtin_amdgcn_sched_barrier(0);
             if (kg + 2 < BK / 8) {
                 load(set, kg + 2);
@@ -326,18 +524,18 @@ struct PipeBF16 {
                 for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn)
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][tm], w[0][tn], acc[tm][tn], 0, 0, 0);
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0][tn], a[1][tm], acc[tm][tn], 0, 0, 0);
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn)
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][tm], w[PL - 1][tn], acc[tm][tn], 0, 0, 0);
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[PL - 1][tn], a[0][tm], acc[tm][tn], 0, 0, 0);
             }
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][tm], w[0][tn], acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0][tn], a[0][tm], acc[tm][tn], 0, 0, 0);
         }
     }
 };
@@ -499,18 +697,18 @@ struct PipeSplitDma {
                 for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn)
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][tm], w[0][tn], acc[tm][tn], 0, 0, 0);
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0][tn], a[1][tm], acc[tm][tn], 0, 0, 0);
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn)
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][tm], w[PL - 1][tn], acc[tm][tn], 0, 0, 0);
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[PL - 1][tn], a[0][tm], acc[tm][tn], 0, 0, 0);
             }
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][tm], w[0][tn], acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0][tn], a[0][tm], acc[tm][tn], 0, 0, 0);
         }
     }
 };

@@ -117,39 +117,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int n_tile
                     touched = true;
                 }
             }
-            if (ADD != 0 && kt == 0) {
-                // additive epilogue operands (residual / gathered rows) are loaded straight into
-                // the accumulators at the start of a tile (C-in of the first MFMA): no extra
-                // registers, and the wait overlaps the co-resident block's MFMAs.
-                // 32-bit offsets from wave-uniform bases keep the address math in SGPR+VGPR form.
-                // (the asm makes the lane id and pitches opaque per tile: otherwise LICM hoists all
-                //  the per-lane offsets/predicates out of the persistent loop and the kernel spills)
-                int ldr = p.ldr, ldg0 = p.ldg0, ldg1 = p.ldg1, lv = lane;
-                asm volatile("" : "+s"(ldr), "+s"(ldg0), "+s"(ldg1), "+v"(lv));
-                const int li = lv & 31, hi = lv >> 5;
-                const float* rbase = (ADD & 1) ? p.resid + (size_t)m0 * ldr + n0 : nullptr;
-                with_resid_format((ADD & 1) ? p.r_split : 0, [&](auto fmt) {
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn) {
-                    int nl = (wn * TN + tn) * 32 + li;                    // column inside the tile
-                    if (n0 + nl >= p.N) nl = p.N - 1 - n0;
-#pragma unroll
-                    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            int ml = (wm * TM + tm) * 32 + crow32(r, hi);   // row inside the tile
-                            if (m0 + ml >= p.M) ml = p.M - 1 - m0;
-                            float x = 0.f;
-                            if (ADD & 1) {
-                                x = p.resid_scale * load_resid<decltype(fmt)::value>(rbase, ml, nl, ldr, n0);
-                            }
-                            if (ADD & 2) x += p.g0[(unsigned)(p.gi0[m0 + ml] * ldg0 + n0 + nl)];
-                            if (ADD & 4) x += p.g1[(unsigned)(p.gi1[m0 + ml] * ldg1 + n0 + nl)];
-                            acc[tm][tn][r] = x;
-                        }
-                }
-                });
-            }
+            // additive epilogue operands (residual / gathered rows) are loaded straight into the accumulators at the start
+            // of a tile (C-in of the first MFMA): no extra registers, and the wait overlaps the co-resident block's MFMAs
+            if (ADD != 0 && kt == 0) tile_init<TM, TN, ADD>(p, m0, n0, wm, wn, lane, acc);
 #pragma unroll
             for (int ks = 0; ks < KSL; ++ks) Pipe::mma(cur + ks * SLICE, wm, wn, acc, lane, p.relu_a);
             if constexpr (Pipe::PREFETCH) {
@@ -165,101 +135,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int n_tile
                 __syncthreads();
             }
             if (last) {
-                // ---- epilogue: lane holds column n, 16 rows per 32x32 tile ----
-                int ldc = p.ldc, lv = lane;
-                asm volatile("" : "+s"(ldc), "+v"(lv));              // see above: no LICM of the store offsets
-                const int li = lv & 31, hi = lv >> 5;
-                float* cbase = p.C + (size_t)m0 * ldc + n0;
-                // Everything below is straight-line code under WAVE-UNIFORM branches: per-element
-                // branches on the runtime flags cost ~30 % of the tile time in the first version.
-                if (p.rowscale) {
-#pragma unroll
-                    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            int m = m0 + (wm * TM + tm) * 32 + crow32(r, hi);
-                            m = m < p.M ? m : p.M - 1;
-                            const float rs = p.rowscale[m];
-#pragma unroll
-                            for (int tn = 0; tn < TN; ++tn) acc[tm][tn][r] *= rs;
-                        }
-                }
-                if (p.bias) {
-#pragma unroll
-                    for (int tn = 0; tn < TN; ++tn) {
-                        int n = n0 + (wn * TN + tn) * 32 + li;
-                        n = n < p.N ? n : p.N - 1;
-                        const float bn = p.bias[n];
-#pragma unroll
-                        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) acc[tm][tn][r] += bn;
-                    }
-                }
-                if (p.act == ACT_RELU) {
-#pragma unroll
-                    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                        for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = fmaxf(acc[tm][tn][r], 0.f);
-                } else if (p.act == ACT_SIGMOID) {
-#pragma unroll
-                    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                        for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 1.f / (1.f + __expf(-acc[tm][tn][r]));
-                }
-                if (p.c_scale != 1.f) {
-#pragma unroll
-                    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                        for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) acc[tm][tn][r] *= p.c_scale;
-                }
-                if (p.c_split == 2) {                             // half rows: bf16 at byte 2 * column of the fp32-pitched row
-#pragma unroll
-                    for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) {
-                                const int ml = (wm * TM + tm) * 32 + crow32(r, hi), nl = (wn * TN + tn) * 32 + li;
-                                if (m0 + ml < p.M && n0 + nl < p.N) store_half(cbase, ml, nl, ldc, n0, acc[tm][tn][r]);
-                            }
-                } else {
-                if (p.c_split) {                                  // bf16 modes: the consumer reads hi/lo bf16 pairs
-#pragma unroll
-                    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                        for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = pack_split(acc[tm][tn][r]);
-                }
-                if (m0 + BM <= p.M && n0 + BN <= p.N) {          // interior tile: unguarded stores
-#pragma unroll
-                    for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) {
-                                const int ml = (wm * TM + tm) * 32 + crow32(r, hi), nl = (wn * TN + tn) * 32 + li;
-                                cbase[(unsigned)(ml * ldc + nl)] = acc[tm][tn][r];
-                            }
-                } else {
-#pragma unroll
-                    for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) {
-                                const int ml = (wm * TM + tm) * 32 + crow32(r, hi), nl = (wn * TN + tn) * 32 + li;
-                                if (m0 + ml < p.M && n0 + nl < p.N) cbase[(unsigned)(ml * ldc + nl)] = acc[tm][tn][r];
-                            }
-                }
-                }
+                tile_epilogue<TM, TN>(p, m0, n0, BM, BN, wm, wn, lane, acc);
                 zero_acc<TM, TN>(acc);
             }
             buf ^= 1;
@@ -397,18 +273,22 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
     if ((a.prec == 1 || a.prec == 3) && !a.no_dma && !a.no_ring && a.N > 64 && !a.rowscale &&
         ((size_t)a.M + 256) * a.lda * 4 < (1ull << 32) && ((size_t)a.N + 256) * a.ldw * 4 < (1ull << 32)) {
         const int G1 = G / 2;
-        const long nbm = (a.M + 255) / 256, nbn = (a.N + 127) / 128;
-        const long rounds = nbm * nbn / G1;
-        const long main_panels = rounds * G1 / nbn;
-        if (main_panels > 0) {
+        // 128 x 256 tiles when N is a multiple of 256 and they still make full rounds (half the A bytes per flop), else 256 x 128
+        for (int rbn = (a.ring_wide && a.N % 256 == 0) ? 256 : 128; rbn >= 128; rbn -= 128) {
+            const int rbm = 32768 / rbn;
+            const long nbm = (a.M + rbm - 1) / rbm, nbn = (a.N + rbn - 1) / rbn;
+            const long rounds = nbm * nbn / G1;
+            const long main_panels = rounds * G1 / nbn;
+            if (main_panels <= 0) continue;
             GemmArgs m = a;
-            m.M = (int)std::min<long>(main_panels * 256, a.M);
-            const int r = launch_gemm_ring(m, (int)(main_panels * nbn), G1, s);
+            m.M = (int)std::min<long>(main_panels * rbm, a.M);
+            const int r = launch_gemm_ring(m, rbn, (int)(main_panels * nbn), G1, s);
             if (r < 0) return r;
             if (r == 0) {
                 if (m.M == a.M) return 0;
                 return launch_gemm(tail_of(a, m.M), s);
             }
+            break;
         }
     }
     // Largest tile that still gives every resident slot a tile; small problems (and the tails

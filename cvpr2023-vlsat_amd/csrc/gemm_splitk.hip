@@ -54,7 +54,6 @@ __global__ __launch_bounds__(256, 2) void gemm_splitk_kernel(GemmArgs p, int n_t
             if (c0 + i < n_sl) Pipe::mma(smem + i * SLICE, wm, wn, acc, lane, p.relu_a);
     }
 
-    const int li = lane & 31, hi = lane >> 5;
     if (ks > 1) {
         // partial sums in accumulator order: element (wave, r, lane) -> one coalesced 256-byte store per wave and r
         float* mine = ws + ((size_t)tile * ks + part) * 4096 + wave * 1024 + lane;
@@ -71,50 +70,29 @@ __global__ __launch_bounds__(256, 2) void gemm_splitk_kernel(GemmArgs p, int n_t
         if (tid == 0) __hip_atomic_store(&counters[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
     }
 
-    // ---- accumulator init (the persistent kernel's ADD operands), then the parts in order ----
-    const int nl = wn * 32 + li;
-    const int ncl = n0 + nl < p.N ? nl : p.N - 1 - n0;               // clamped column for the loads
-    float out[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        int ml = wm * 32 + crow32(r, hi);
-        if (m0 + ml >= p.M) ml = p.M - 1 - m0;
-        float x = 0.f;
-        if (p.resid) {
-            const float* rb = p.resid + (size_t)m0 * p.ldr + n0;
-            x = p.resid_scale * (p.r_split == 2 ? load_resid<2>(rb, ml, ncl, p.ldr, n0) : p.r_split == 1 ? load_resid<1>(rb, ml, ncl, p.ldr, n0)
-                                                                                                      : load_resid<0>(rb, ml, ncl, p.ldr, n0));
-        }
-        if (p.g0) x += p.g0[(size_t)p.gi0[m0 + ml] * p.ldg0 + n0 + ncl];
-        if (p.g1) x += p.g1[(size_t)p.gi1[m0 + ml] * p.ldg1 + n0 + ncl];
-        out[r] = x;
+    // ---- accumulator init (the persistent kernel's additive operands), then the parts in order, then its epilogue ----
+    f32x16 out[1][1];
+    const int add = (p.resid ? 1 : 0) | (p.g0 ? 2 : 0) | (p.g1 ? 4 : 0);
+    switch (add) {                                   // (the combinations the launcher of the persistent kernel knows too)
+        case 1: tile_init<1, 1, 1>(p, m0, n0, wm, wn, lane, out); break;
+        case 2: tile_init<1, 1, 2>(p, m0, n0, wm, wn, lane, out); break;
+        case 3: tile_init<1, 1, 3>(p, m0, n0, wm, wn, lane, out); break;
+        case 4: tile_init<1, 1, 4>(p, m0, n0, wm, wn, lane, out); break;
+        case 5: tile_init<1, 1, 5>(p, m0, n0, wm, wn, lane, out); break;
+        case 6: tile_init<1, 1, 6>(p, m0, n0, wm, wn, lane, out); break;
+        case 7: tile_init<1, 1, 7>(p, m0, n0, wm, wn, lane, out); break;
+        default: zero_acc<1, 1>(out);
     }
     if (ks > 1) {
         const float* parts = ws + (size_t)tile * ks * 4096 + wave * 1024 + lane;
         for (int s = 0; s < ks; ++s)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) out[r] += __hip_atomic_load(parts + (size_t)s * 4096 + r * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int r = 0; r < 16; ++r) out[0][0][r] += __hip_atomic_load(parts + (size_t)s * 4096 + r * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) out[r] += acc[0][0][r];
+        for (int r = 0; r < 16; ++r) out[0][0][r] += acc[0][0][r];
     }
-    // ---- epilogue (same order of operations as gemm_f32.hip) ----
-    const float bn = p.bias ? p.bias[n0 + ncl] : 0.f;
-    float* cbase = p.C + (size_t)m0 * p.ldc + n0;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int ml = wm * 32 + crow32(r, hi);
-        const bool ok = m0 + ml < p.M && n0 + nl < p.N;
-        float v = out[r];
-        if (p.rowscale) v *= p.rowscale[ok ? m0 + ml : p.M - 1];
-        v += bn;
-        if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
-        else if (p.act == ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
-        if (p.c_scale != 1.f) v *= p.c_scale;
-        if (!ok) continue;
-        if (p.c_split == 2) store_half(cbase, ml, nl, p.ldc, n0, v);
-        else cbase[(size_t)ml * p.ldc + nl] = p.c_split ? pack_split(v) : v;
-    }
+    tile_epilogue<1, 1>(p, m0, n0, 64, 64, wm, wn, lane, out);
 }
 
 }  // namespace

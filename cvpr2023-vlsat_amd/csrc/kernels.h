@@ -30,6 +30,8 @@ struct GemmArgs {
     // 2 half rows (bf16 values at byte 2 * column of an fp32-pitched row; single-rounding modes)
     int a_split = 0, r_split = 0, c_split = 0;
     float c_scale = 1.f;                        // final multiplier of C (after bias / activation)
+    int ablate = 0;                             // timing experiments on the ring kernel: bit 0 no operand loads after the first slices, bit 1 no MFMAs (results are garbage)
+    int ring_wide = 0;                          // experiment: bf16 ring kernel with 128 x 256 tiles where N allows (measured equal)
     int no_ring = 0;                            // debug: keep large bf16 launches on the two-stage 128 x 128 kernel
     int k_rotate = 0;                           // (experiment, no gain measured) start each row panel's k loop at a different slice (L2 channel spreading)
     int prefetch = -1;                          // bf16 LDS-direct pipe: slices of look-ahead of the A-panel prefetch (0 off, -1 default)
@@ -47,7 +49,7 @@ constexpr size_t SPLITK_WS_FLOATS = (size_t)768 * 4096;    // room for 768 parti
 constexpr size_t SPLITK_COUNTERS = 512;
 // bf16 modes, full rounds of large-M launches: 3-stage LDS ring, 256 x 128 tiles, one 8-wave block per CU
 // (gemm_bf16_ring.hip); returns 1 if the operand combination is not built
-int launch_gemm_ring(const GemmArgs& a, int n_tiles, int grid, hipStream_t s);
+int launch_gemm_ring(const GemmArgs& a, int rbn, int n_tiles, int grid, hipStream_t s);   // rbn: tile width 128 | 256
 double gemm_flops(const GemmArgs& a);
 void gemm_set_clock_probe(long long* buf);
 
