@@ -25,6 +25,17 @@ python tools/gemm_bench.py --prec 3 --only E --fmt 21 --prefetch 6 > "$OUT/gemm_
 python tools/gemm_bench.py --prec 3 --only E --no-dma > "$OUT/gemm_bf16x3_vgpr.txt" 2>&1
 python tools/gemm_bench.py --prec 1 --only E --fmt 5 > "$OUT/gemm_bf16.txt" 2>&1
 python tools/gemm_bench.py --prec 1 --only E --fmt 37 > "$OUT/gemm_bf16_half.txt" 2>&1
+{ echo "ring kernel, kv launch (E x 1024 x 512): full | no operand loads after the first slices | no MFMAs | neither"
+  for f in 5 261 517 773; do python tools/gemm_bench.py --prec 3 --only "kv E" --fmt $f 2>&1 | grep " E x"; done
+  for f in 37 293 549 805; do python tools/gemm_bench.py --prec 1 --only "kv E" --fmt $f 2>&1 | grep " E x"; done
+  echo "128 x 256 tiles instead of 256 x 128 (fmt bit 7)"
+  python tools/gemm_bench.py --prec 3 --only "kv E" --fmt 133 2>&1 | grep " E x"
+  python tools/gemm_bench.py --prec 1 --only "kv E" --fmt 165 2>&1 | grep " E x"; } > "$OUT/gemm_ablation.txt" 2>&1
+python tools/gemm_clock_probe.py > "$OUT/gemm_clock_fp32.txt" 2>&1
+python tools/gemm_clock_probe.py --prec 3 > "$OUT/gemm_clock_bf16x3.txt" 2>&1
+python tools/gemm_clock_probe.py --prec 1 > "$OUT/gemm_clock_bf16.txt" 2>&1
+tools/forward_timeline.sh r02 40 > /dev/null 2>&1
+tools/forward_timeline.sh r02 40 bf16x3 > /dev/null 2>&1 && mv "$OUT/timeline_40.txt" "$OUT/timeline_40_bf16x3.txt"; tools/forward_timeline.sh r02 40 > /dev/null 2>&1
 tools/bin/l2_fill_probe > "$OUT/l2_fill.txt" 2>&1
 tools/bin/tr_read_probe > "$OUT/tr_read.txt" 2>&1
 python tools/eval_synth.py > "$OUT/eval_synth.txt" 2>&1

@@ -30,10 +30,10 @@ out, n, prec = sys.argv[1:4]
 db = glob.glob(f"{out}/kt_{n}/**/*.db", recursive=True)[0]
 c = sqlite3.connect(db)
 rows = [(s, e, nm) for s, e, nm in c.execute("select start, end, name from kernels order by start") if "vlsat::" in nm]
-# split into forwards: gap > 150 us between consecutive kernel starts
+# split into forwards: the script synchronises between calls -> the device idles for tens of microseconds
 fw, cur = [], []
 for r in rows:
-    if cur and r[0] - max(x[1] for x in cur) > 150_000:
+    if cur and r[0] - max(x[1] for x in cur) > 40_000:
         fw.append(cur); cur = []
     cur.append(r)
 fw.append(cur)
