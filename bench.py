@@ -172,7 +172,7 @@ def main():
         achieved = c["flops"] / (c["ms"] * 1e-3) / 1e12 if c["ms"] > 0 else 0.0
         traffic, traffic_src = None, None
         default_wl = (args.scenes, args.objects, args.points, args.layers) == (64, 40, 256, 3)
-        tag = {"fp32": "_bench_pmc.json", "bf16x3": "_cfg3_pmc.json"}.get(args.gemm_precision, "_none_")
+        tag = {"fp32": "_bench_pmc.json", "bf16x3": "_cfg3_bf16x3_pmc.json", "bf16_mixed": "_cfg3_bf16_mixed_pmc.json"}.get(args.gemm_precision, "_none_")
         pmc = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith(tag)) \
             if os.path.isdir(os.path.join(ROOT, "profiles")) else []
         if default_wl and pmc:

@@ -12,6 +12,7 @@ j $S/bench_cfg3_bf16.json $D/r02_cfg3_bf16_bench.json
 j $S/bench_cfg5_fp32.json $D/r02_cfg5_fp32_bench.json
 j $S/bench_cfg5_bf16x3.json $D/r02_cfg5_bf16x3_bench.json
 cp $S/prof_fp32/kernel_stats.md $D/r02_bench_kernel_stats.md;        cp $S/prof_fp32/pmc.md $D/r02_bench_pmc.md
+cp $S/prof_fp32/pmc.json $D/r02_bench_pmc.json; cp $S/prof_cfg3/pmc.json $D/r02_cfg3_bf16x3_pmc.json; cp $S/prof_cfg3_mixed/pmc.json $D/r02_cfg3_bf16_mixed_pmc.json
 cp $S/prof_cfg3/kernel_stats.md $D/r02_cfg3_bf16x3_kernel_stats.md;  cp $S/prof_cfg3/pmc.md $D/r02_cfg3_bf16x3_pmc.md
 cp $S/prof_cfg3_mixed/kernel_stats.md $D/r02_cfg3_bf16_mixed_kernel_stats.md; cp $S/prof_cfg3_mixed/pmc.md $D/r02_cfg3_bf16_mixed_pmc.md
 for m in fp32 bf16x3; do
