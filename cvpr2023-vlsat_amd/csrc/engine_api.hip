@@ -113,7 +113,7 @@ int vlsat_k_gemm_planes(const float* A, int32_t lda, const float* W, const uint1
     a.prec = prec; a.Whi = Whi; a.Wlo = Wlo; a.no_dma = no_dma; a.prefetch = prefetch;
     const int code = (fmt >> 5) & 1 ? 2 : 1;   // (bit 5: the flagged operands are half rows instead of split pairs)
     a.a_split = (fmt & 1) * code; a.r_split = ((fmt >> 1) & 1) * code; a.c_split = ((fmt >> 2) & 1) * code; a.c_scale = c_scale;
-    a.k_rotate = (fmt >> 3) & 1;               // (bit 3: k rotation, bit 4: no ring kernel -- benchmarking)
+    // (bit 3 was the k-rotation experiment: removed; bit 4: no ring kernel -- benchmarking)
     a.no_ring = (fmt >> 4) & 1;
     a.ring_wide = (fmt >> 7) & 1;              // (bit 7: ring kernel with 128 x 256 tiles where N allows)
     a.ablate = (fmt >> 8) & 3;                 // (bits 8, 9: timing experiments, see GemmArgs::ablate)

@@ -65,7 +65,8 @@ __device__ __forceinline__ bool aligned16(const void* p) { return (reinterpret_c
 
 // Accumulator init of a tile = its additive operands: resid_scale * resid + g0[gi0[row]] + g1[gi1[row]] (ADD bits 0 / 1 / 2;
 // compile time, so the loads of a lane are branch-free and batched).  The first MFMA of the tile takes them as C-in.
-template <int TM, int TN, int ADD>
+// PLAIN (the exact-fp32 kernels): operands and output are fp32 and c_scale is 1 -- the format dispatch folds away.
+template <int TM, int TN, int ADD, bool PLAIN = false>
 __device__ __forceinline__ void tile_init(const GemmArgs& p, int m0, int n0, int wm, int wn, int lane, f32x16 (&acc)[TM][TN]) {
     // 32-bit offsets from wave-uniform bases; the asm makes the lane id and pitches opaque per tile (otherwise LICM hoists
     // all the per-lane offsets out of a persistent kernel's tile loop and it spills)
@@ -75,7 +76,7 @@ __device__ __forceinline__ void tile_init(const GemmArgs& p, int m0, int n0, int
     const bool vec = n0 + (wn * TN + TN) * 32 <= p.N && ((ldr | ldg0 | ldg1) & 3) == 0 &&
                      (!(ADD & 1) || aligned16(p.resid)) && (!(ADD & 2) || aligned16(p.g0)) && (!(ADD & 4) || aligned16(p.g1));
     if (vec) {
-        with_format((ADD & 1) ? p.r_split : 0, [&](auto fmt) {
+        with_format((ADD & 1) && !PLAIN ? p.r_split : 0, [&](auto fmt) {
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) {
                 int m = m0 + (wm * TM + tm) * 32 + li;
@@ -100,7 +101,7 @@ __device__ __forceinline__ void tile_init(const GemmArgs& p, int m0, int n0, int
         return;
     }
     // tiles cut by N (or operands that are not 16-byte addressable): element by element, clamped
-    with_format((ADD & 1) ? p.r_split : 0, [&](auto fmt) {
+    with_format((ADD & 1) && !PLAIN ? p.r_split : 0, [&](auto fmt) {
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
             int m = m0 + (wm * TM + tm) * 32 + li;
@@ -124,9 +125,10 @@ __device__ __forceinline__ void tile_init(const GemmArgs& p, int m0, int n0, int
 // Epilogue of a finished tile: row scale, bias, activation, final scale, store in the output format (c_split).  Everything
 // is straight-line code under WAVE-UNIFORM branches (per-element branches on the runtime flags cost ~30 % of the tile
 // time in the first version of the kernel).  BM / BN: the block tile (for the interior test).
-template <int TM, int TN>
+template <int TM, int TN, bool PLAIN = false>
 __device__ __forceinline__ void tile_epilogue(const GemmArgs& p, int m0, int n0, int BM, int BN, int wm, int wn, int lane,
                                               f32x16 (&acc)[TM][TN]) {
+    const int c_split = PLAIN ? 0 : p.c_split;
     int ldc = p.ldc, lv = lane;
     asm volatile("" : "+s"(ldc), "+v"(lv));                          // see tile_init: no LICM of the store offsets
     const int li = lv & 31, hi = lv >> 5;
@@ -183,7 +185,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& p, int m0, int n0,
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 1.f / (1.f + __expf(-acc[tm][tn][r]));
     }
-    if (p.c_scale != 1.f) {
+    if (!PLAIN && p.c_scale != 1.f) {
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -193,7 +195,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& p, int m0, int n0,
     }
     const bool interior = m0 + BM <= p.M && cols_in && (ldc & 3) == 0 && aligned16(p.C);
     if (interior) {
-        with_format(p.c_split, [&](auto fmt) {
+        with_format(c_split, [&](auto fmt) {
             constexpr int FMT = decltype(fmt)::value;
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) {
@@ -234,8 +236,8 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& p, int m0, int n0,
                 const int n = n0 + (wn * TN + tn) * 32 + crow32(r, hi);
                 if (m < p.M && n < p.N) {
                     const float v = acc[tm][tn][r];
-                    if (p.c_split == 2) reinterpret_cast<unsigned short*>(crow)[n] = __builtin_bit_cast(unsigned short, (__bf16)v);
-                    else crow[n] = p.c_split ? pack_split(v) : v;
+                    if (c_split == 2) reinterpret_cast<unsigned short*>(crow)[n] = __builtin_bit_cast(unsigned short, (__bf16)v);
+                    else crow[n] = c_split ? pack_split(v) : v;
                 }
             }
     }

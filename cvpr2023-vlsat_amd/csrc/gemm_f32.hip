@@ -55,12 +55,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int n_tile
     const int wm = wave >> 1, wn = wave & 1;
     const int g8 = gridDim.x >> 3, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int KT = p.K / (BK * KSL);
-    // k rotation: the blocks of an XCD run in near lock-step, so at any moment they would all fetch the SAME k-slice of their
-    // rows -- addresses a whole row pitch (a power of two) apart, which lands them on a couple of the XCD's 16 L2 channels
-    // (the bf16 kernels, 5x shorter slices, plateaued at ~29 GB/s per CU from L2 whatever the staging method).  Tile row
-    // panel i therefore starts its k loop at slice i mod KT: same sum, other order; the N-tile neighbours that share an
-    // A panel keep the same rotation, so they still meet in L2.
-    auto kslice = [&](int m_first, int kt) { int j = kt + (p.k_rotate ? (m_first / BM) % KT : 0); return (j >= KT ? j - KT : j) * (BK * KSL); };
+    // (an experiment that started each row panel's k loop at a different slice, against L2 channel camping, measured no
+    //  gain in any mode and cost the fp32 kernel 2 %: removed)
+    auto kslice = [&](int, int kt) { return kt * (BK * KSL); };
 
     int round = 0;
     int v = xcd * g8 + slot;                 // tile of round r: (r*8 + xcd)*g8 + slot
@@ -119,7 +116,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int n_tile
             }
             // additive epilogue operands (residual / gathered rows) are loaded straight into the accumulators at the start
             // of a tile (C-in of the first MFMA): no extra registers, and the wait overlaps the co-resident block's MFMAs
-            if (ADD != 0 && kt == 0) tile_init<TM, TN, ADD>(p, m0, n0, wm, wn, lane, acc);
+            if (ADD != 0 && kt == 0) tile_init<TM, TN, ADD, (PREC == 0 || PREC == 4)>(p, m0, n0, wm, wn, lane, acc);
 #pragma unroll
             for (int ks = 0; ks < KSL; ++ks) Pipe::mma(cur + ks * SLICE, wm, wn, acc, lane, p.relu_a);
             if constexpr (Pipe::PREFETCH) {
@@ -135,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int n_tile
                 __syncthreads();
             }
             if (last) {
-                tile_epilogue<TM, TN>(p, m0, n0, BM, BN, wm, wn, lane, acc);
+                tile_epilogue<TM, TN, (PREC == 0 || PREC == 4)>(p, m0, n0, BM, BN, wm, wn, lane, acc);
                 zero_acc<TM, TN>(acc);
             }
             buf ^= 1;
@@ -188,6 +185,8 @@ static int launch_t(const GemmArgs& a, int n_tiles, int grid, hipStream_t s) {
     int prec = a.prec;
     const bool dma_ok = !a.no_dma && (add == 0 || add == 1 || add == 6) &&
                         ((size_t)a.M + 256) * a.lda * 4 < (1ull << 32) && ((size_t)a.N + 256) * a.ldw * 4 < (1ull << 32);
+    if (prec == 0 && (a.a_split || a.r_split || a.c_split || a.c_scale != 1.f))
+        return fail(-1, "gemm: operand formats and c_scale exist in the bf16 modes only");      // (the fp32 kernels fold them away)
     if (prec == 0 && dma_ok && !a.relu_a) prec = 4;
     if (a.a_split == 2 && !(prec == 1 && dma_ok)) return fail(-1, "gemm: half-row A needs the single-rounding bf16 precision and the LDS-direct pipe");
     if ((prec == 1 || prec == 3) && dma_ok) prec += a.a_split == 2 ? 12 : a.a_split ? 8 : 4;   // bf16 modes: A split on the fragment-read side, so ReLU-on-A is fine

@@ -33,7 +33,6 @@ struct GemmArgs {
     int ablate = 0;                             // timing experiments on the ring kernel: bit 0 no operand loads after the first slices, bit 1 no MFMAs (results are garbage)
     int ring_wide = 0;                          // experiment: bf16 ring kernel with 128 x 256 tiles where N allows (measured equal)
     int no_ring = 0;                            // debug: keep large bf16 launches on the two-stage 128 x 128 kernel
-    int k_rotate = 0;                           // (experiment, no gain measured) start each row panel's k loop at a different slice (L2 channel spreading)
     int prefetch = -1;                          // bf16 LDS-direct pipe: slices of look-ahead of the A-panel prefetch (0 off, -1 default)
     int no_dma = 0;                             // debug: VGPR-staged fp32 operands instead of LDS-direct (vlsat_debug_option "gemm_dma")
     long* launches = nullptr;                   // optional host counter, +1 per kernel launched (profiling)

@@ -171,7 +171,7 @@ int vlsat_k_split_bf16(const float* w, size_t n, uint16_t* hi, uint16_t* lo, voi
  * look-ahead of the A-panel prefetch (0 = off, -1 = default).  fmt: bit 0 = A, bit 1 = resid, bit 2 = C are in the
  * split-pair format of the split-bf16 mode (one 32-bit word per element: bf16 hi = rne(x) in the upper half, bf16 lo =
  * rne(x - hi) in the lower half) or, with bit 5 set, in the half-row format of the single-rounding modes (bf16 values
- * at byte 2 * column of the fp32-pitched row; prec 1 only); bits 3 / 4 / 6 / 7 are benchmarking switches (k rotation,
+ * at byte 2 * column of the fp32-pitched row; prec 1 only); bits 4 / 6 / 7 are benchmarking switches (
  * no ring kernel, small launches on the split-K kernel, ring kernel with 128 x 256 tiles) and bits 8 / 9 timing
  * ablations (no operand loads / no MFMAs: garbage results); c_scale multiplies C
  * last.  Asynchronous. */
