@@ -41,6 +41,7 @@ int vlsat_set_edge_attention_scope(vlsat_handle h, int32_t scope) {
 //   "node_attn_split" n  node attention with sixteen lanes per query for plans of fewer than n one-query-per-lane waves
 //   "gemm_splitk" 0|1   small GEMM launches on the split-K kernel (0: everything on the persistent kernel)
 //   "split_fmt"   0|1   bf16 modes: edge tensors between matrix kernels as bf16 hi/lo pairs (0: plain fp32, split on read)
+//   "ln_resid"    0|1   split-bf16 mode: edge-attention residual added by the LayerNorm kernel (0: in the out-projection GEMM)
 //   "half_fmt"    0|1   single-rounding modes: those tensors as plain bf16 at half the traffic (0: split pairs)
 //   "flash_bf16"  0|1   bf16 modes: edge attention on the bf16 matrix cores (0: keep the fp32 kernel)
 //   "pointnet_bf16", "gate_bf16" 0|1   bf16 modes: object encoder / edge gate on the bf16 matrix cores (0: fp32 kernels)
@@ -56,6 +57,7 @@ int vlsat_debug_option(vlsat_handle h, const char* name, int32_t value) {
     else if (k == "node_attn_split") h->node_attn_split = value;
     else if (k == "split_fmt") h->split_fmt = value != 0;
     else if (k == "half_fmt") h->half_fmt = value != 0;
+    else if (k == "ln_resid") h->ln_resid = value != 0;
     else if (k == "flash_bf16") h->flash_bf16 = value != 0;
     else if (k == "pointnet_bf16") h->pointnet_bf16 = value != 0;
     else if (k == "gate_bf16") h->gate_bf16 = value != 0;

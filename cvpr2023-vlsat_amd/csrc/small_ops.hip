@@ -81,15 +81,28 @@ int launch_desc_tail(const float* desc, int n_nodes, float* x, int ldx, int col0
 // In-place LayerNorm over rows of 512 (eps 1e-5, biased variance = torch.nn.LayerNorm), optional
 // ReLU.  One wave per row, 8 values per lane as two float4 (columns 4*lane and 256 + 4*lane).
 // reference transformer/attention.py:122 (post-LN residual) and network_MMG.py:236-248 (ReLU).
+// Optional residual (rows of `resid`, split-pair words if r_split): y = LN(x + resid) -- the post-LN residual of the edge
+// attention in the split-bf16 mode, where adding it here is cheaper than as an accumulator init of the out-projection.
 __global__ __launch_bounds__(256) void layernorm512_kernel(const float* __restrict__ x, int ld, float* __restrict__ y, int ldy,
                                                            int rows, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, int relu, int out_split) {
+                                                           const float* __restrict__ beta, int relu, int out_split,
+                                                           const float* __restrict__ resid, int ldr, int r_split) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float* p = x + (size_t)row * ld;
     f32x4 a = *reinterpret_cast<const f32x4*>(p + 4 * lane);
     f32x4 b = *reinterpret_cast<const f32x4*>(p + 256 + 4 * lane);
+    if (resid) {
+        const float* r = resid + (size_t)row * ldr;
+        f32x4 ra = *reinterpret_cast<const f32x4*>(r + 4 * lane), rb = *reinterpret_cast<const f32x4*>(r + 256 + 4 * lane);
+        if (r_split) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { ra[c] = unpack_split(ra[c]); rb[c] = unpack_split(rb[c]); }
+        }
+        a += ra;
+        b += rb;
+    }
     float s = a[0] + a[1] + a[2] + a[3] + b[0] + b[1] + b[2] + b[3];
     const float mean = wave_sum(s) * (1.f / 512.f);
     float v = 0.f;
@@ -126,10 +139,12 @@ int launch_layernorm(float* x, int ld, int rows, int dim, const float* gamma, co
     return launch_layernorm_to(x, ld, x, ld, rows, dim, gamma, beta, relu, 0, s);
 }
 int launch_layernorm_to(const float* x, int ld, float* y, int ldy, int rows, int dim, const float* gamma, const float* beta,
-                        int relu, int out_split, hipStream_t s) {
+                        int relu, int out_split, hipStream_t s, const float* resid, int ldr, int r_split) {
     if (rows <= 0) return 0;
-    if (dim != 512 || (ld & 3) || (ldy & 3)) return fail(-1, "layernorm: dim must be 512 and ld a multiple of 4");
-    hipLaunchKernelGGL(layernorm512_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, ld, y, ldy, rows, gamma, beta, relu, out_split);
+    if (dim != 512 || (ld & 3) || (ldy & 3) || (resid && ((ldr & 3) || r_split > 1)))
+        return fail(-1, "layernorm: dim must be 512, ld a multiple of 4, residual fp32 or split pairs");
+    hipLaunchKernelGGL(layernorm512_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, ld, y, ldy, rows, gamma, beta, relu, out_split,
+                       resid, ldr, r_split);
     VLSAT_LAUNCH_CHECK("layernorm512");
     return 0;
 }

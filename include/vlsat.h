@@ -275,6 +275,9 @@ int vlsat_debug_gemm_clock_probe(int64_t* buf);
  * LDS-direct staging of fp32 GEMM operands; "gate_grid" n: persistent grid of the gate kernel (0 = default);
  * "split_fmt" 0|1: in the bf16 modes, edge tensors between matrix kernels as bf16 hi/lo pairs (0: fp32, split on read);
  * "half_fmt" 0|1: in the single-rounding modes, those tensors as plain bf16 at half the traffic (0: hi/lo pairs);
+ * "ln_resid" 0|1: split-bf16 mode, residual of the edge attention added by the LayerNorm kernel (0: by the out-projection);
+ * "gemm_splitk" 0|1: small GEMM launches on the split-K kernel; "node_attn_split" n: node attention with sixteen lanes per
+ * query for plans with fewer than n one-query-per-lane waves;
  * "flash_bf16" / "pointnet_bf16" / "gate_bf16" 0|1: in the bf16 modes, edge attention / object encoder / edge gate on
  * the bf16 matrix cores (0: the fp32 kernels); "flash_tr" 0|1: its V operand by
  * ds_read_b64_tr_b16 (0: ds_read_u16 gather). */
