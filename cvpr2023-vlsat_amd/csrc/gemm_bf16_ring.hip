@@ -37,14 +37,21 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // 64 x 64 either way.  The second shape halves the bytes of A (read once, from HBM / Infinity Cache) per flop and doubles
 // those of the weights (re-read from L2); it measured the same time on every launch of the forward -- the fill path does
 // not care where the bytes come from -- and is kept as an experiment switch only.
-template <int TERMS, int AFMT, int ADD, int RBN>
+// RBK: k per slice, 32 or -- half-row A with one weight plane only -- 64: the single-rounding modes issue just 8 MFMAs per
+// wave between two barriers at 32 (ablation: 0.58 us per step of pure synchronisation against 0.2 us of MFMAs), and their
+// 24 KB stages leave room for slices twice as long.  With 64 both operands have 128-byte rows in LDS, laid out like the
+// fp32 A rows (XOR swizzle (row >> 1) & 7 over eight 16-byte chunks).
+template <int TERMS, int AFMT, int ADD, int RBN, int RBK = 32>
 __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmArgs p, int n_tiles, int nbn) {
+    static_assert(RBK == 32 || (RBK == 64 && AFMT == 2 && TERMS == 1), "64-wide slices: half-row A, one plane");
+    constexpr int BK = RBK;                                  // (shadows the library-wide slice length inside this kernel)
+    constexpr bool LR = RBK == 64;                           // long rows: 128 bytes per operand row and slice
     constexpr int RBM = 32768 / RBN;
     using Frag = PipeSplitDma<128, 128, TERMS, AFMT>;        // fragment-side helpers only (split8 / frag_half)
     constexpr bool AH = AFMT == 2;                           // A as half rows (bf16): 64-byte slices like the weight planes
     constexpr int PL = TERMS == 1 ? 1 : 2;
-    constexpr int TM = 2, TN = 2, WR = RBN / 128;            // (WR: 128-row rounds of a weight-plane slice)
-    constexpr int AR = AFMT == 2 ? RBM / 128 : RBM / 64;     // instruction rounds of an A slice (128 | 64 rows each)
+    constexpr int TM = 2, TN = 2, WR = LR ? RBN / 64 : RBN / 128;      // (WR: instruction rounds of a weight-plane slice)
+    constexpr int AR = (AFMT == 2 && !LR) ? RBM / 128 : RBM / 64;      // instruction rounds of an A slice (128 | 64 rows each)
     constexpr int A_BYTES = AH ? RBM * BK * 2 : RBM * BK * 4, W_PLANE = RBN * BK * 2;
     constexpr int STAGE = A_BYTES + PL * W_PLANE;            // 48 KB (40 KB with one plane, 24 KB with half-row A)
     constexpr int LPS = AR + PL * WR;                        // LDS-direct loads per wave per slice
@@ -65,13 +72,25 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmArgs p, int n_til
     const int na = AH ? (int)((size_t)(p.M - 1) * p.lda * 4 + (size_t)p.K * 2) : (int)(((size_t)(p.M - 1) * p.lda + p.K) * 4);
     const int arow = 8 * wave + (lane >> 3);                                  // row inside a 64-row instruction group
     const int wrow = 16 * wave + (lane >> 2);                                 // (wrow >> 2) & 3 == (lane >> 4) & 3
-    const unsigned va = AH ? (unsigned)(wrow * p.lda * 4 + 16 * ((lane & 3) ^ ((lane >> 4) & 3)))
-                           : (unsigned)(arow * p.lda + 4 * ((lane & 7) ^ ((arow >> 1) & 7))) * 4u;
-    const unsigned vw = (unsigned)(wrow * p.ldw + 8 * ((lane & 3) ^ ((lane >> 4) & 3))) * 2u;
+    const unsigned va = (AH && !LR) ? (unsigned)(wrow * p.lda * 4 + 16 * ((lane & 3) ^ ((lane >> 4) & 3)))
+                                    : (unsigned)(arow * p.lda + 4 * ((lane & 7) ^ ((arow >> 1) & 7))) * 4u;
+    const unsigned vw = LR ? (unsigned)(arow * p.ldw * 2 + 16 * ((lane & 7) ^ ((arow >> 1) & 7)))
+                           : (unsigned)(wrow * p.ldw + 8 * ((lane & 3) ^ ((lane >> 4) & 3))) * 2u;
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, na, 0x00020000);
     const __amdgpu_buffer_rsrc_t rwh = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.Whi), 0, nw, 0x00020000);
     const __amdgpu_buffer_rsrc_t rwl = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(PL == 2 ? p.Wlo : p.Whi), 0, nw, 0x00020000);
     auto issue = [&](int m0, int n0, int k0, char* stage) {
+        if (LR) {                     // 128-byte rows: 8 rows per instruction, 8 waves -> 64 rows per round
+            char* sa = stage + wave * 8 * 128;
+#pragma unroll
+            for (int i = 0; i < AR; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, sa + i * 64 * 128, 16, va + (unsigned)((m0 + 64 * i) * p.lda * 4 + k0 * 2), 0, 0, 0);
+            char* sw = stage + A_BYTES + wave * 8 * 128;
+#pragma unroll
+            for (int i = 0; i < WR; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rwh, sw + i * 64 * 128, 16, vw + (unsigned)(((n0 + 64 * i) * p.ldw + k0) * 2), 0, 0, 0);
+            return;
+        }
         if (AH) {                     // 256 rows x 64 B: 16 rows per instruction, 8 waves -> 128 rows per round, two rounds
             char* sa = stage + wave * 16 * BK * 2;
 #pragma unroll
@@ -142,7 +161,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmArgs p, int n_til
                 for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
                     for (int tm = 0; tm < TM; ++tm) {
-                        if (AH) {
+                        if (LR) {
+                            ah[ks][tm] = *reinterpret_cast<const bf16x8*>(sAh + tm * 32 * 128 + 16 * ((2 * ks + hi) ^ swa));
+                        } else if (AH) {
                             ah[ks][tm] = *reinterpret_cast<const bf16x8*>(sAh + tm * 32 * BK * 2 + 16 * ((2 * ks + hi) ^ sww));
                         } else {
                             const int c0 = (4 * ks + 2 * hi) ^ swa;
@@ -154,7 +175,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmArgs p, int n_til
                     for (int pl = 0; pl < PL; ++pl)
 #pragma unroll
                         for (int tn = 0; tn < TN; ++tn)
-                            w[ks][pl][tn] = *reinterpret_cast<const bf16x8*>(sW + pl * W_PLANE + tn * 32 * BK * 2 + 16 * ((2 * ks + hi) ^ sww));
+                            w[ks][pl][tn] = *reinterpret_cast<const bf16x8*>(sW + pl * W_PLANE + tn * 32 * BK * 2 + 16 * ((2 * ks + hi) ^ (LR ? swa : sww)));
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -204,6 +225,12 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmArgs p, int n_til
 
 template <int T, int S, int ADD>
 static void ring_launch(bool wide, const GemmArgs& a, int n_tiles, int nbn, int grid, hipStream_t s) {
+    if constexpr (T == 1 && S == 2) {          // half-row A, one plane: 64-wide slices whenever K allows
+        if (!wide && a.K % 64 == 0 && !a.ring_bk32) {
+            hipLaunchKernelGGL((gemm_ring_kernel<T, S, ADD, 128, 64>), dim3(grid), dim3(512), 0, s, a, n_tiles, nbn);
+            return;
+        }
+    }
     if (!wide) hipLaunchKernelGGL((gemm_ring_kernel<T, S, ADD, 128>), dim3(grid), dim3(512), 0, s, a, n_tiles, nbn);
     else hipLaunchKernelGGL((gemm_ring_kernel<T, S, ADD, 256>), dim3(grid), dim3(512), 0, s, a, n_tiles, nbn);
 }
