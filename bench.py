@@ -102,6 +102,9 @@ def main():
     ap.add_argument("--layers", type=int, default=3)
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--native-allreduce", action="store_true",
+                    help="sum the metrics vector with the library's own RCCL entry point (vlsat_metrics_allreduce) "
+                         "instead of torch.distributed.all_reduce")
     ap.add_argument("--debug-option", action="append", default=[], metavar="NAME=VALUE",
                     help="experiment switch of the library (vlsat_debug_option), e.g. node_attn_split=0; repeatable")
     ap.add_argument("--gemm-precision", default="fp32", choices=["fp32", "bf16x3", "bf16_mixed", "bf16"],
@@ -121,6 +124,8 @@ def main():
     local = local % torch.cuda.device_count()          # (a 2-rank gloo dry run may share one GPU)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if args.native_allreduce:
+        vdist.use_native_allreduce(rank, world)
     from vlsat_amd.model import VLSATModel
 
     cfg = VLSATConfig(N_LAYERS=args.layers)
@@ -218,6 +223,7 @@ def main():
                    "scenes_per_gpu": args.scenes, "parallelism": f"scene-sharded x{world}"},
         "flop_per_scene_alg": falg,
         "metrics_allreduced": {k: float(v) for k, v in zip(vdist.METRIC_FIELDS, metrics.tolist())},
+        "allreduce": "vlsat_metrics_allreduce (RCCL via the C ABI)" if args.native_allreduce else "torch.distributed.all_reduce",
         "roofline": roofline, "cpu_baseline": cpu, "max_abs_err_vs_cpu_oracle": err,
         "speedup_vs_cpu": round(value / cpu["value"], 1) if cpu else None,
     }

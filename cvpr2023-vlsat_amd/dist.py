@@ -65,8 +65,56 @@ def scene_metrics(outputs, n_scenes: int) -> torch.Tensor:
     return v
 
 
+class NativeComm:
+    """The library's own RCCL communicator (``vlsat_comm_*`` / ``vlsat_metrics_allreduce``, include/vlsat.h): what a host
+    without PyTorch would use for the one collective of the path.  Bootstrap: rank 0 makes the 128-byte unique id and
+    the ranks exchange it -- here through the already initialised ``torch.distributed`` group (any backend), a file or
+    a pipe does as well.  One communicator per process, on the current GPU."""
+
+    def __init__(self, rank: int, world: int):
+        import ctypes as C
+        from . import lib as L
+        self._L, self._lib, self.world = L, L.load(), world
+        ident = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            L.check(self._lib.vlsat_comm_unique_id(C.c_void_p(ident.data_ptr())))
+        if world > 1:
+            if not dist.is_initialized():
+                raise L.VlsatError("NativeComm: the ranks need a torch.distributed group (or another channel) to share the id")
+            if dist.get_backend() == "gloo":
+                dist.broadcast(ident, src=0)
+            else:
+                d = ident.cuda()
+                dist.broadcast(d, src=0)
+                ident = d.cpu()
+        self._comm = C.c_void_p()
+        L.check(self._lib.vlsat_comm_init(C.c_void_p(ident.data_ptr()), world, rank, C.byref(self._comm)))
+
+    def allreduce(self, v: torch.Tensor) -> torch.Tensor:
+        if not (v.is_cuda and v.dtype == torch.float64 and v.is_contiguous()):
+            raise self._L.VlsatError("NativeComm.allreduce: contiguous fp64 CUDA tensor expected")
+        self._L.check(self._lib.vlsat_metrics_allreduce(self._comm, v.data_ptr(), v.numel(), self._L.stream_ptr()))
+        return v
+
+    def close(self):
+        if self._comm:
+            self._lib.vlsat_comm_destroy(self._comm)
+            self._comm = None
+
+
+_native: "NativeComm | None" = None
+
+
+def use_native_allreduce(rank: int, world: int) -> None:
+    """Route allreduce_metrics through the library's RCCL entry point (bench.py --native-allreduce)."""
+    global _native
+    _native = NativeComm(rank, world)
+
+
 def allreduce_metrics(v: torch.Tensor) -> torch.Tensor:
     """The single collective of the path: sum of the metrics vector over ranks."""
+    if _native is not None and v.is_cuda:
+        return _native.allreduce(v)
     if dist.is_initialized() and dist.get_world_size() > 1:
         if v.is_cuda and dist.get_backend() == "gloo":      # test rigs without RCCL: reduce on the host
             h = v.cpu()

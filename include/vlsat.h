@@ -284,6 +284,18 @@ int vlsat_debug_gemm_clock_probe(int64_t* buf);
  * ds_read_b64_tr_b16 (0: ds_read_u16 gather). */
 int vlsat_debug_option(vlsat_handle h, const char* name, int32_t value);
 
+/* ---- the one collective of the path: sum of a short fp64 metrics vector over ranks, on RCCL ---------------
+ * Scenes are sharded over ranks with no data-path exchange; a sharded evaluation ends with one all-reduce of additive
+ * counts (what the reference's validation() computes its percentages from, src/model/model.py:214-242).  RCCL is
+ * resolved at run time (the copy already in the process, e.g. PyTorch's, else librccl.so.1): no link-time dependency.
+ * Bootstrap: rank 0 calls vlsat_comm_unique_id (128 bytes), the host shares them with the other ranks (file, pipe,
+ * any launcher), every rank calls vlsat_comm_init with its GPU current. */
+int vlsat_comm_unique_id(void* out128);
+int vlsat_comm_init(const void* id128, int32_t n_ranks, int32_t rank, void** comm);
+/* buf: device fp64[n], summed over ranks in place; asynchronous on `stream`. */
+int vlsat_metrics_allreduce(void* comm, double* buf, int32_t n, void* stream);
+void vlsat_comm_destroy(void* comm);
+
 #ifdef __cplusplus
 }
 #endif

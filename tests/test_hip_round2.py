@@ -214,3 +214,34 @@ def test_num_heads_and_dim_atten_golden(golden_dir, h, a, mode):
     m = _model(cfg, synth.make_weights(cfg)).set_gemm_precision(mode)
     _check(_run(m, RAGGED()), [z[n] for n in NAMES], TIGHT if mode == "fp32" else TOL, f"H={h} A={a} {mode} vs reference golden")
     m.close()
+
+
+def test_native_rccl_allreduce_single_rank():
+    """vlsat_comm_* / vlsat_metrics_allreduce (include/vlsat.h): the library's own RCCL entry point for the one
+    collective of the path.  One GPU here, so a communicator of one rank: the call chain (run-time RCCL resolution, unique
+    id, init, all-reduce on the caller's stream, destroy) runs for real and the sum over one rank is the input itself.
+    The same through bench.py's switch: checksums must equal the torch.distributed route."""
+    import json
+    import subprocess
+    import sys
+    from vlsat_amd import dist as vdist
+    comm = vdist.NativeComm(0, 1)
+    try:
+        v = torch.arange(1, 488, dtype=torch.float64, device=DEV) * 0.5
+        ref = v.clone()
+        out = comm.allreduce(v)
+        torch.cuda.synchronize()
+        assert out.data_ptr() == v.data_ptr() and torch.equal(v, ref)
+        with pytest.raises(Exception):
+            comm.allreduce(torch.zeros(4, device=DEV))                       # fp32: rejected, not reinterpreted
+    finally:
+        comm.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for extra in ([], ["--native-allreduce"]):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--scenes", "4", "--steps", "1", "--warmup", "1", "--no-cpu",
+                            "--no-profile", *extra], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1]))
+    assert outs[1]["allreduce"].startswith("vlsat_metrics_allreduce")
+    assert outs[0]["metrics_allreduced"] == outs[1]["metrics_allreduced"]
