@@ -26,7 +26,9 @@
  *     vlsat_debug_* readers.
  *   - a handle (weights) may be shared by several plans; a plan owns its workspace and is NOT
  *     re-entrant (one forward at a time per plan), mirroring one nn.Module instance; a handle is driven from one
- *     host thread at a time.
+ *     host thread at a time, and its forwards are ordered on ONE stream at a time (small scratch buffers -- the split-K
+ *     workspace of small GEMM launches -- belong to the handle: moving to another stream needs an event / sync between
+ *     the last forward on the old stream and the first on the new one; separate handles are independent).
  */
 #ifndef VLSAT_H
 #define VLSAT_H
