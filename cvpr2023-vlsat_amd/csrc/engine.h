@@ -86,6 +86,7 @@ struct vlsat_ctx {
     int gemm_splitk = 1;                     // small GEMM launches take the split-K kernel (gemm_splitk.hip)
     float* sk_ws[2] = {nullptr, nullptr};    // its workspace + counters: [0] launch stream, [1] the side stream of two-stream plans
     unsigned* sk_cnt[2] = {nullptr, nullptr};
+    int flash_pv_terms = 3;                  // split-bf16 edge attention: MFMAs per P.V product (3, or 2 = probabilities single-rounded)
     int ln_resid = 1;                        // split-pair mode: post-attention residual added in the LayerNorm kernel
     int half_fmt = 1;                        // single-rounding modes: those tensors as plain bf16 (half rows) instead of split pairs
     int split_fmt = 1;                       // bf16 modes: edge tensors between matrix kernels in the split-pair format

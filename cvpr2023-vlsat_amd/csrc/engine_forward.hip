@@ -415,7 +415,7 @@ static int forward_impl(vlsat_handle h, vlsat_plan p, const float* pts, const fl
                                          1.f / std::sqrt((float)(D / h->H)), s, h->node_attn_split));
                 else if (h->prec_edge && h->flash_bf16)
                     RUN(launch_flash_attn_bf16(p->Qe, D, p->KVe, p->KVe + (S == 2 ? D / 2 : D), 2 * D, p->Oe, D, p->d_tiles, p->n_tiles,
-                                               sc2e, h->prec_edge == 3 ? 3 : 1, h->flash_tr, S, s, &sp));    // (half rows: V starts at byte 2 D)
+                                               sc2e, h->prec_edge == 3 ? 3 : 1, h->flash_tr, S, s, &sp, h->flash_pv_terms));    // (half rows: V starts at byte 2 D)
                 else
                     RUN(launch_flash_attn(p->Qe, D, p->KVe, p->KVe + D, 2 * D, p->Oe, D, p->d_tiles, p->n_tiles, sc2e, s, &sp));
             }

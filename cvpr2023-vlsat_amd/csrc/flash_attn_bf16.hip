@@ -85,7 +85,9 @@ __device__ __forceinline__ void planes_of(const f32x4& x, bf16x4& hi, bf16x4& lo
 
 // IO = 1 / 2: Q, K, V arrive and O leaves in the split-pair / half-row format; Q is then already multiplied by
 // scale * log2 e (the projection GEMM's epilogue did it)
-template <int TERMS, bool TR, int IO>
+// PVT (split-bf16 mode only): MFMAs per P.V product.  3 = V_hi.P_hi + V_lo.P_hi + V_hi.P_lo; 2 drops the last term, i.e. the
+// probabilities enter the second product single-rounded (V stays exact) -- an experiment switch (flash_pv_terms).
+template <int TERMS, bool TR, int IO, int PVT = 3>
 __global__ __launch_bounds__(256, 2) void flash_attn_bf16_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
     float* __restrict__ O, int ldq, int ldkv, int ldo, const int4* __restrict__ tiles, int n_tiles,
@@ -278,8 +280,10 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bf16_kernel(
                 if (PL == 2) {
                     o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0][PL - 1], ph, o0, 0, 0, 0);
                     o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1][PL - 1], ph, o1, 0, 0, 0);
-                    o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0][0], pl, o0, 0, 0, 0);
-                    o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1][0], pl, o1, 0, 0, 0);
+                    if (PVT == 3) {
+                        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0][0], pl, o0, 0, 0, 0);
+                        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1][0], pl, o1, 0, 0, 0);
+                    }
                 }
                 o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0][0], ph, o0, 0, 0, 0);
                 o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1][0], ph, o1, 0, 0, 0);
@@ -330,7 +334,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bf16_kernel(
 
 int launch_flash_attn_bf16(const float* Q, int ldq, const float* K, const float* V, int ldkv, float* O, int ldo,
                            const int4* tiles, int n_tiles, float scale_log2e, int terms, int use_tr, int io_split,
-                           hipStream_t s, const FlashSplit* split) {
+                           hipStream_t s, const FlashSplit* split, int pv_terms) {
     if (n_tiles <= 0) return 0;
     if ((ldq | ldkv | ldo) & 3) return fail(-1, "flash_attn: leading dims must be multiples of 4");
     if (terms != 1 && terms != 3) return fail(-1, "flash_attn_bf16: terms must be 1 or 3");
@@ -346,7 +350,9 @@ int launch_flash_attn_bf16(const float* Q, int ldq, const float* K, const float*
         VLSAT_FA(1, true, 2);
     } else if (io_split) {
         if (!use_tr) return fail(-1, "flash_attn_bf16: the split-pair format is built for the transpose-read path only");
-        if (terms == 3) VLSAT_FA(3, true, 1); else VLSAT_FA(1, true, 1);
+        if (terms == 3 && pv_terms == 2)
+            hipLaunchKernelGGL((flash_attn_bf16_kernel<3, true, 1, 2>), dim3(n_tiles), dim3(256), 0, s, Q, K, V, O, ldq, ldkv, ldo, tiles, n_tiles, scale_log2e, sp);
+        else if (terms == 3) VLSAT_FA(3, true, 1); else VLSAT_FA(1, true, 1);
     } else if (terms == 3) { if (use_tr) VLSAT_FA(3, true, 0); else VLSAT_FA(3, false, 0); }
     else                   { if (use_tr) VLSAT_FA(1, true, 0); else VLSAT_FA(1, false, 0); }
 #undef VLSAT_FA

@@ -279,6 +279,8 @@ int vlsat_debug_gemm_clock_probe(int64_t* buf);
  * "split_fmt" 0|1: in the bf16 modes, edge tensors between matrix kernels as bf16 hi/lo pairs (0: fp32, split on read);
  * "half_fmt" 0|1: in the single-rounding modes, those tensors as plain bf16 at half the traffic (0: hi/lo pairs);
  * "ln_resid" 0|1: split-bf16 mode, residual of the edge attention added by the LayerNorm kernel (0: by the out-projection);
+ * "flash_pv_terms" 3|2: split-bf16 edge attention, MFMAs per P.V product (2: probabilities single-rounded; +3 % scenes/s,
+ * twice the error on weights that make the attention peaked -- left at 3);
  * "gemm_splitk" 0|1: small GEMM launches on the split-K kernel; "node_attn_split" n: node attention with sixteen lanes per
  * query for plans with fewer than n one-query-per-lane waves;
  * "flash_bf16" / "pointnet_bf16" / "gate_bf16" 0|1: in the bf16 modes, edge attention / object encoder / edge gate on
