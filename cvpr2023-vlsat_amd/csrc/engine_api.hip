@@ -121,6 +121,7 @@ int vlsat_k_gemm_planes(const float* A, int32_t lda, const float* W, const uint1
     a.ring_wide = (fmt >> 7) & 1;              // (bit 7: ring kernel with 128 x 256 tiles where N allows)
     a.ablate = (fmt >> 8) & 3;                 // (bits 8, 9: timing experiments, see GemmArgs::ablate)
     a.ring_bk32 = (fmt >> 10) & 1;             // (bit 10: half-row ring kernel with 32-wide k slices)
+    a.ring_nodb = (fmt >> 11) & 1;             // (bit 11: ... without the double-buffered fragment sets)
     if ((fmt >> 6) & 1) RUN(test_splitk_ws(a));    // (bit 6: small launches may take the split-K kernel)
     return launch_gemm(a, static_cast<hipStream_t>(stream));
 }

@@ -41,9 +41,14 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // wave between two barriers at 32 (ablation: 0.58 us per step of pure synchronisation against 0.2 us of MFMAs), and their
 // 24 KB stages leave room for slices twice as long.  With 64 both operands have 128-byte rows in LDS, laid out like the
 // fp32 A rows (XOR swizzle (row >> 1) & 7 over eight 16-byte chunks).
-template <int TERMS, int AFMT, int ADD, int RBN, int RBK = 32>
+// DB (with RBK = 64, K a multiple of 128): the fragments of a slice are read from LDS one pipeline step EARLY, into a second
+// register set, while the matrix pipe works on the previous slice's set -- LDS reads and MFMAs of a wave overlap across
+// the barrier instead of alternating (ablation: either phase alone takes ~45 % of the full kernel's time above the store
+// floor, together 60 %).  The loop is unrolled by two so that the two sets are compile-time registers.
+template <int TERMS, int AFMT, int ADD, int RBN, int RBK = 32, bool DB = false>
 __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmArgs p, int n_tiles, int nbn) {
     static_assert(RBK == 32 || (RBK == 64 && AFMT == 2 && TERMS == 1), "64-wide slices: half-row A, one plane");
+    static_assert(!DB || RBK == 64, "double-buffered fragments: built for the 64-wide slices");
     constexpr int BK = RBK;                                  // (shadows the library-wide slice length inside this kernel)
     constexpr bool LR = RBK == 64;                           // long rows: 128 bytes per operand row and slice
     constexpr int RBM = 32768 / RBN;
@@ -127,6 +132,80 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmArgs p, int n_til
     f32x16 acc[TM][TN];
     zero_acc<TM, TN>(acc);
     int cbuf = 0;
+    if constexpr (DB) {
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        struct Frags { bf16x8 a[4][TM], w[4][TN]; };
+        const int swa = (li >> 1) & 7;
+        auto read = [&](const char* stage, Frags& f) {
+            const char* sAh = stage + (wm * 64 + li) * 128;
+            const char* sW = stage + A_BYTES + (wn * 64 + li) * 128;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) f.a[ks][tm] = *reinterpret_cast<const bf16x8*>(sAh + tm * 32 * 128 + 16 * ((2 * ks + hi) ^ swa));
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) f.w[ks][tn] = *reinterpret_cast<const bf16x8*>(sW + tn * 32 * 128 + 16 * ((2 * ks + hi) ^ swa));
+            }
+        };
+        auto mma = [&](const Frags& f) {
+            if (p.ablate & 2) return;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                bf16x8 a[TM];
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) {
+                    s16x8 v = __builtin_bit_cast(s16x8, f.a[ks][tm]);
+                    if (p.relu_a) v = __builtin_elementwise_max(v, s16x8{0, 0, 0, 0, 0, 0, 0, 0});
+                    a[tm] = __builtin_bit_cast(bf16x8, v);
+                }
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.w[ks][tn], a[tm], acc[tm][tn], 0, 0, 0);
+            }
+        };
+        // one pipeline step: the slice that goes into `fill` has landed -> barrier (everyone is done reading the slice
+        // in `use`, whose stage the next issue overwrites) -> issue -> start the reads into `fill` -> MFMAs on `use`
+        auto step = [&](const Frags& use, Frags& fill, bool more) {
+            if (more) {
+                if (ahead >= RST - 1) wait_vmcnt<(RST - 2) * LPS>();
+                else wait_vmcnt<0>();
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                --ahead;
+                issue_next();
+                read(smem + cbuf * STAGE, fill);
+                cbuf = cbuf == RST - 1 ? 0 : cbuf + 1;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mma(use);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        Frags f0, f1;
+        {   // prologue: the first slice of the first tile into f0
+            if (ahead >= RST - 1) wait_vmcnt<(RST - 2) * LPS>();
+            else wait_vmcnt<0>();
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            --ahead;
+            issue_next();
+            read(smem + cbuf * STAGE, f0);
+            cbuf = cbuf == RST - 1 ? 0 : cbuf + 1;
+        }
+        for (int round = 0;; ++round) {
+            const int v = tile_of_round(round);
+            if (v >= n_tiles) break;
+            const int m0 = (v / nbn) * RBM, n0 = (v % nbn) * RBN;
+            const bool next_tile = tile_of_round(round + 1) < n_tiles;
+            if (ADD != 0) tile_init<TM, TN, ADD>(p, m0, n0, wm, wn, lane, acc);
+            for (int kt = 0; kt < KT; kt += 2) {                    // (KT is even: the launcher checks K % 128 == 0)
+                step(f0, f1, true);
+                step(f1, f0, kt + 2 < KT || next_tile);
+            }
+            tile_epilogue<TM, TN>(p, m0, n0, RBM, RBN, wm, wn, lane, acc);
+            zero_acc<TM, TN>(acc);
+        }
+        return;
+    }
     for (int round = 0;; ++round) {
         const int v = tile_of_round(round);
         if (v >= n_tiles) break;
@@ -226,6 +305,10 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmArgs p, int n_til
 template <int T, int S, int ADD>
 static void ring_launch(bool wide, const GemmArgs& a, int n_tiles, int nbn, int grid, hipStream_t s) {
     if constexpr (T == 1 && S == 2) {          // half-row A, one plane: 64-wide slices whenever K allows
+        if (!wide && a.K % 128 == 0 && !a.ring_bk32 && !a.ring_nodb) {
+            hipLaunchKernelGGL((gemm_ring_kernel<T, S, ADD, 128, 64, true>), dim3(grid), dim3(512), 0, s, a, n_tiles, nbn);
+            return;
+        }
         if (!wide && a.K % 64 == 0 && !a.ring_bk32) {
             hipLaunchKernelGGL((gemm_ring_kernel<T, S, ADD, 128, 64>), dim3(grid), dim3(512), 0, s, a, n_tiles, nbn);
             return;

@@ -31,6 +31,7 @@ struct GemmArgs {
     int a_split = 0, r_split = 0, c_split = 0;
     float c_scale = 1.f;                        // final multiplier of C (after bias / activation)
     int ablate = 0;                             // timing experiments on the ring kernel: bit 0 no operand loads after the first slices, bit 1 no MFMAs (results are garbage)
+    int ring_nodb = 0;                          // experiment: half-row ring kernel without the double-buffered fragment sets
     int ring_bk32 = 0;                          // experiment: half-row ring kernel with 32-wide k slices (default 64 where K allows)
     int ring_wide = 0;                          // experiment: bf16 ring kernel with 128 x 256 tiles where N allows (measured equal)
     int no_ring = 0;                            // debug: keep large bf16 launches on the two-stage 128 x 128 kernel

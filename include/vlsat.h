@@ -174,8 +174,8 @@ int vlsat_k_split_bf16(const float* w, size_t n, uint16_t* hi, uint16_t* lo, voi
  * split-pair format of the split-bf16 mode (one 32-bit word per element: bf16 hi = rne(x) in the upper half, bf16 lo =
  * rne(x - hi) in the lower half) or, with bit 5 set, in the half-row format of the single-rounding modes (bf16 values
  * at byte 2 * column of the fp32-pitched row; prec 1 only); bits 4 / 6 / 7 are benchmarking switches (
- * no ring kernel, small launches on the split-K kernel, ring kernel with 128 x 256 tiles; bit 10: its 32-wide k slices in
- * the half-row mode) and bits 8 / 9 timing
+ * no ring kernel, small launches on the split-K kernel, ring kernel with 128 x 256 tiles; bits 10 / 11: its
+ * 32-wide k slices / single fragment set in the half-row mode) and bits 8 / 9 timing
  * ablations (no operand loads / no MFMAs: garbage results); c_scale multiplies C
  * last.  Asynchronous. */
 int vlsat_k_gemm_planes(const float* A, int32_t lda, const float* W, const uint16_t* Whi, const uint16_t* Wlo, int32_t ldw,
