@@ -49,6 +49,7 @@ template <int TERMS, int AFMT, int ADD, int RBN, int RBK = 32, bool DB = false>
 __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmArgs p, int n_tiles, int nbn) {
     static_assert(RBK == 32 || (RBK == 64 && AFMT == 2 && TERMS == 1), "64-wide slices: half-row A, one plane");
     static_assert(!DB || RBK == 64, "double-buffered fragments: built for the 64-wide slices");
+    // (the split-bf16 variants have no registers left for a second fragment set: 76-197 spilled registers when tried)
     constexpr int BK = RBK;                                  // (shadows the library-wide slice length inside this kernel)
     constexpr bool LR = RBK == 64;                           // long rows: 128 bytes per operand row and slice
     constexpr int RBM = 32768 / RBN;
