@@ -83,6 +83,7 @@ struct vlsat_ctx {
     int debug_stop = -1;
     int gemm_no_dma = 0, gate_grid = 0;      // vlsat_debug_option
     int node_attn_split = 1024;              // node attention: sixteen lanes per query when the plan has fewer waves than this
+    long config_epoch = 0;                   // bumped by every call that changes what a forward launches (graphs are re-captured)
     int gemm_splitk = 1;                     // small GEMM launches take the split-K kernel (gemm_splitk.hip)
     float* sk_ws[2] = {nullptr, nullptr};    // its workspace + counters: [0] launch stream, [1] the side stream of two-stream plans
     unsigned* sk_cnt[2] = {nullptr, nullptr};
@@ -140,6 +141,10 @@ struct vlsat_plan_s {
     float* stn_ws = nullptr;                        // MODEL.feature_transform scratch (carved per phase in stn_encoder)
     size_t stn_ws_floats = 0;
     bool dual = false;
+    // hipGraph replay (vlsat_forward_graph): the captured forward of this plan for ONE set of tensor addresses
+    hipGraphExec_t graph_exec = nullptr;
+    const void* graph_ptrs[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    long graph_epoch = -1;                  // handle configuration (weights / precision / options) it was captured under
     float *NP2 = nullptr, *Hbig2 = nullptr, *KP2 = nullptr, *G2 = nullptr, *T768b = nullptr, *rs2 = nullptr, *H2b = nullptr;
 };
 

@@ -29,6 +29,7 @@ int vlsat_set_edge_attention_scope(vlsat_handle h, int32_t scope) {
     if (!h) return fail(VLSAT_EINVAL, "null handle");
     if (scope != 0 && scope != 1) return fail(VLSAT_EINVAL, "edge attention scope: 0 (per scene) or 1 (whole batch)");
     h->edge_scope = scope;
+    ++h->config_epoch;
     return 0;
 }
 
@@ -49,6 +50,7 @@ int vlsat_set_edge_attention_scope(vlsat_handle h, int32_t scope) {
 int vlsat_debug_option(vlsat_handle h, const char* name, int32_t value) {
     if (!h || !name) return fail(VLSAT_EINVAL, "vlsat_debug_option: null argument");
     const std::string k(name);
+    ++h->config_epoch;
     if (k == "dual_stream") h->dual_stream = value != 0;
     else if (k == "flash_split") h->fa_split = value != 0;
     else if (k == "gemm_dma") h->gemm_no_dma = value == 0;

@@ -251,8 +251,11 @@ extern "C" {
 // -------------------------------------------------------------------------------------------
 struct TrainOut { float *mimic3d, *mimic2d, *edge_dis; };
 
+// capture: the call is being recorded into a hipGraph (vlsat_forward_graph): nothing that touches events owned by the plan
+// or queries the device may happen in here then -- the caller has done the upload wait and records last_use itself.
 static int forward_impl(vlsat_handle h, vlsat_plan p, const float* pts, const float* f2d, const float* desc,
-                        float* obj3d, float* obj2d, float* rel3d, float* rel2d, const TrainOut* tr, void* stream) {
+                        float* obj3d, float* obj2d, float* rel3d, float* rel2d, const TrainOut* tr, void* stream,
+                        bool capture = false) {
     if (!h || !p || !pts || !desc || !obj3d) return fail(VLSAT_EINVAL, "vlsat_forward: null argument");
     if (p->h != h) return fail(VLSAT_EINVAL, "plan belongs to a different handle");
     // 3D-only mode: both 2D outputs NULL -> the 2D branch (adapter, cross-attention, gcn_2ds, edge
@@ -265,18 +268,18 @@ static int forward_impl(vlsat_handle h, vlsat_plan p, const float* pts, const fl
     const int N = (int)p->N, E = (int)p->E, D = h->D, L = h->d.n_layers, LDX = ldx_of(h);
     const int stop = h->debug_stop;
     h->cur_N = N;
-    if (p->upload_pending) {               // the plan's index tables travel on the handle's copy stream
+    if (p->upload_pending && !capture) {   // the plan's index tables travel on the handle's copy stream
         VLSAT_HIP_CHECK(hipStreamWaitEvent(s, p->uploaded, 0));
         if (hipEventQuery(p->uploaded) == hipSuccess) p->upload_pending = false;
     }
     p->used = true;
-    profile_close(h, s);                   // an interval left open by a failed forward must not span foreign work
+    if (!capture) profile_close(h, s);     // an interval left open by a failed forward must not span foreign work
 #define STAGE(id) do { if (stop == (id)) { profile_close(h, s); hipEventRecord(p->last_use, s); return 0; } } while (0)
 
     // Two-stream mode (small plans only; not while profiling or stopping at a debug stage): `t` carries the 2D twin
     // of a stage while `s` carries the 3D one.  fork(): t waits for everything enqueued on s so far; join(): s waits
     // for t.  Every forward ends joined, so the caller only ever sees its own stream.
-    const bool dual = p->dual && do2d && !h->prof && stop < 0 && !tr;
+    const bool dual = p->dual && do2d && (!h->prof || capture) && stop < 0 && !tr;
     hipStream_t t = s;
     size_t ev_i = 0;
     if (dual) {
@@ -459,6 +462,7 @@ static int forward_impl(vlsat_handle h, vlsat_plan p, const float* pts, const fl
     RUN(obj_head(h, p, s, p->X3, h->obj3_w, h->obj3_b, obj3d, sc3));
     if (do2d) RUN(obj_head(h, p, t, p->X2, h->obj2_w, h->obj2_b, obj2d, sc2));
     RUN(join());
+    if (capture) return 0;
     profile_close(h, s);
     VLSAT_HIP_CHECK(hipEventRecord(p->last_use, s));
 #undef STAGE
@@ -481,6 +485,45 @@ int vlsat_forward_train(vlsat_handle h, vlsat_plan p, const float* pts, const fl
         return fail(VLSAT_EINVAL, "vlsat_forward_train: null output");
     const TrainOut tr{obj_feature_3d_mimic, obj_features_2d_mimic, gcn_edge_feature_2d_dis};
     return forward_impl(h, p, pts, f2d, desc, obj3d, obj2d, rel3d, rel2d, &tr, stream);
+}
+
+// vlsat_forward through a hipGraph: the first call for a (plan, tensor addresses, handle configuration) triple records the
+// forward's launches -- both streams of a two-stream plan included -- into a graph; later calls with the same triple
+// replay it with one hipGraphLaunch.  Any other addresses / a changed configuration re-capture.  `stream` must be a
+// capturable stream (not the NULL stream).  Profiling and debug stages fall back to vlsat_forward.
+int vlsat_forward_graph(vlsat_handle h, vlsat_plan p, const float* pts, const float* f2d, const float* desc,
+                        float* obj3d, float* obj2d, float* rel3d, float* rel2d, void* stream) {
+    if (!h || !p) return fail(VLSAT_EINVAL, "vlsat_forward_graph: null argument");
+    if (h->prof || h->debug_stop >= 0) return forward_impl(h, p, pts, f2d, desc, obj3d, obj2d, rel3d, rel2d, nullptr, stream);
+    if (!stream) return fail(VLSAT_EINVAL, "vlsat_forward_graph: the NULL stream cannot be captured; pass a created stream");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const void* ptrs[7] = {pts, f2d, desc, obj3d, obj2d, rel3d, rel2d};
+    if (p->upload_pending) {               // outside the capture: events owned by the plan
+        VLSAT_HIP_CHECK(hipStreamWaitEvent(s, p->uploaded, 0));
+        if (hipEventQuery(p->uploaded) == hipSuccess) p->upload_pending = false;
+    }
+    bool same = p->graph_exec && p->graph_epoch == h->config_epoch;
+    for (int i = 0; same && i < 7; ++i) same = p->graph_ptrs[i] == ptrs[i];
+    if (!same) {
+        if (p->graph_exec) { hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }
+        if (p->dual && !h->side) VLSAT_HIP_CHECK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+        h->sync_ev.reserve(64);            // (events of the fork / join points are created on demand: fine during capture)
+        VLSAT_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+        const int rc = forward_impl(h, p, pts, f2d, desc, obj3d, obj2d, rel3d, rel2d, nullptr, stream, true);
+        hipGraph_t g = nullptr;
+        const hipError_t e = hipStreamEndCapture(s, &g);
+        if (rc) { if (g) hipGraphDestroy(g); return rc; }
+        if (e != hipSuccess || !g) return fail(VLSAT_EHIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+        const hipError_t ei = hipGraphInstantiate(&p->graph_exec, g, nullptr, nullptr, 0);
+        hipGraphDestroy(g);
+        if (ei != hipSuccess) { p->graph_exec = nullptr; return fail(VLSAT_EHIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ei)); }
+        for (int i = 0; i < 7; ++i) p->graph_ptrs[i] = ptrs[i];
+        p->graph_epoch = h->config_epoch;
+    }
+    VLSAT_HIP_CHECK(hipGraphLaunch(p->graph_exec, s));
+    p->used = true;
+    VLSAT_HIP_CHECK(hipEventRecord(p->last_use, s));
+    return 0;
 }
 
 int vlsat_profile_enable(vlsat_handle h, int32_t enable) {

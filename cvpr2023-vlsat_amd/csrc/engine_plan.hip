@@ -297,6 +297,7 @@ int vlsat_plan_create(vlsat_handle h, const int64_t* bid, const int64_t* edges, 
 void vlsat_plan_destroy(vlsat_plan p) {
     if (!p) return;
     vlsat_ctx* h = p->h;
+    if (p->graph_exec) hipGraphExecDestroy(p->graph_exec);     // (a launch still in flight keeps what it needs)
     if (p->arena) {
         // The forward that used this workspace may still be in flight: the arena keeps the event of that forward (or
         // of the upload, if the plan never ran) and whoever takes it next waits for it ON THE DEVICE.  No host wait.

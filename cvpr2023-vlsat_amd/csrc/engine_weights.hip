@@ -426,6 +426,7 @@ int vlsat_finalize_weights(vlsat_handle h) {
     }
     h->host.clear();
     h->finalized = true;
+    ++h->config_epoch;
     if (h->prec) RUN(split_all_weights(h));
     for (int i = 0; i < 2 && !h->sk_ws[i]; ++i) {     // split-K workspaces of the small GEMM launches (gemm_splitk.hip), once per handle
         VLSAT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->sk_ws[i]), SPLITK_WS_FLOATS * sizeof(float)));
@@ -442,6 +443,7 @@ int vlsat_finalize_weights(vlsat_handle h) {
 int vlsat_set_gemm_precision(vlsat_handle h, int32_t mode) {
     if (!h) return fail(VLSAT_EINVAL, "null handle");
     if (mode < 0 || mode > 3) return fail(VLSAT_EINVAL, "gemm precision must be 0 (fp32), 1 (bf16), 2 (mixed) or 3 (bf16x3)");
+    ++h->config_epoch;
     h->prec = mode;
     h->prec_edge = mode == 2 ? 1 : mode;
     h->prec_node = mode == 2 ? 3 : mode;

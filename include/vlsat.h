@@ -124,6 +124,15 @@ int vlsat_forward_train(vlsat_handle h, vlsat_plan p,
                         float* obj_feature_3d_mimic, float* obj_features_2d_mimic, float* gcn_edge_feature_2d_dis,
                         void* stream);
 
+/* vlsat_forward through a hipGraph: the first call for a (plan, tensor addresses, handle configuration) triple records the
+ * forward -- every launch, both streams of a two-stream plan -- and later calls with the same triple replay it with one
+ * hipGraphLaunch; other addresses or a changed configuration (weights, precision, options) re-capture.  For hosts that
+ * run the same graph on static buffers; an evaluation loop over ever-new graphs gains nothing (launch
+ * gaps are 6-12 % of a one-scene forward).  `stream` must be a created stream (the NULL stream cannot be captured). */
+int vlsat_forward_graph(vlsat_handle h, vlsat_plan plan, const float* obj_points, const float* obj_2d_feats,
+                        const float* descriptor, float* obj_logits_3d, float* obj_logits_2d, float* rel_cls_3d,
+                        float* rel_cls_2d, void* stream);
+
 /* Operand precision of the matrix kernels inside vlsat_forward (BASELINE configs[2], "bf16 MFMA for the
  * QKV/FFN GEMMs"): 0 = exact fp32 MFMA (default; BASELINE configs[1]); 3 = split-bf16 (a_hi.w_hi + a_lo.w_hi +
  * a_hi.w_lo on v_mfma_f32_32x32x16_bf16, fp32 accumulate, ~1e-5 error); 1 = single-rounded bf16 operands
