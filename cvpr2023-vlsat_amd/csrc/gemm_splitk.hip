@@ -113,8 +113,6 @@ int launch_gemm_splitk(const GemmArgs& a, int slots, hipStream_t s) {
     const int slices = (total + ks - 1) / ks;
     ks = (total + slices - 1) / slices;                              // no empty parts
     if ((size_t)T * ks * 4096 > a.sk_ws_floats || (size_t)T > a.sk_n_counters) return 1;
-    const int add = (a.resid ? 1 : 0) | (a.g0 ? 2 : 0) | (a.g1 ? 4 : 0);
-    (void)add;
     int prec = a.prec;
     const bool dma_ok = !a.no_dma && ((size_t)a.M + 256) * a.lda * 4 < (1ull << 32) && ((size_t)a.N + 256) * a.ldw * 4 < (1ull << 32);
     if (prec == 0 && dma_ok && !a.relu_a) prec = 4;
