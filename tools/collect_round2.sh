@@ -38,6 +38,7 @@ tools/forward_timeline.sh r02 40 > /dev/null 2>&1
 tools/forward_timeline.sh r02 40 bf16x3 > /dev/null 2>&1 && mv "$OUT/timeline_40.txt" "$OUT/timeline_40_bf16x3.txt"; tools/forward_timeline.sh r02 40 > /dev/null 2>&1
 python tools/graph_replay_probe.py 2>&1 | grep objects > "$OUT/graph_replay.txt"
 tools/bin/l2_fill_probe > "$OUT/l2_fill.txt" 2>&1
+tools/bin/lds_bw_probe > "$OUT/lds_bw.txt" 2>&1
 tools/bin/tr_read_probe > "$OUT/tr_read.txt" 2>&1
 python tools/eval_synth.py > "$OUT/eval_synth.txt" 2>&1
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --hip-runtime-trace --stats -d "$OUT/api" -o api --output-format csv -- python "$ROOT/tools/api_trace_forward.py" > "$OUT/api_trace.txt" 2> "$OUT/api_trace.log" )

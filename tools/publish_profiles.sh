@@ -22,7 +22,7 @@ done
 cp $S/timeline_40.txt $D/r02_forward_timeline_40.txt
 cp $S/timeline_40_bf16x3.txt $D/r02_forward_timeline_40_bf16x3.txt
 { grep -v amdgpu.ids $S/api_trace.txt; echo; echo "rocprofv3 --hip-runtime-trace --stats, HIP API calls by total time:"; cat $S/api_stats_api_hip_api_stats.csv; } > $D/r02_hip_api_trace.txt
-for f in gemm_fp32 gemm_bf16x3 gemm_bf16x3_noring gemm_bf16x3_vgpr gemm_bf16 gemm_bf16_half gemm_ablation gemm_clock_fp32 gemm_clock_bf16x3 gemm_clock_bf16 graph_replay l2_fill tr_read eval_synth; do
+for f in gemm_fp32 gemm_bf16x3 gemm_bf16x3_noring gemm_bf16x3_vgpr gemm_bf16 gemm_bf16_half gemm_ablation gemm_clock_fp32 gemm_clock_bf16x3 gemm_clock_bf16 graph_replay l2_fill lds_bw tr_read eval_synth; do
   grep -v amdgpu.ids $S/$f.txt > $P/$f.txt
 done
 cp $S/tests_gpu.log $D/r02_tests_gpu.txt
