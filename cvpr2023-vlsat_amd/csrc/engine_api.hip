@@ -38,6 +38,7 @@ int vlsat_set_edge_attention_scope(vlsat_handle h, int32_t scope) {
 //   "dual_stream" 0|1   2D twin stages of small plans on a second stream (plans created afterwards)
 //   "flash_split" 0|1   split-key edge attention for plans that cannot fill the chip (plans created afterwards)
 //   "gemm_dma"    0|1   LDS-direct staging of fp32 GEMM operands (0: VGPR-staged)
+//   "gemm_p8"     0|1   single-rounding bf16 modes: large half-row launches on the 256 x 256 8-phase kernel (0: ring kernel)
 //   "gate_grid"   n     persistent grid of the gate kernel (0: default)
 //   "node_attn_split" n  node attention with sixteen lanes per query for plans of fewer than n one-query-per-lane waves
 //   "gemm_splitk" 0|1   small GEMM launches on the split-K kernel (0: everything on the persistent kernel)
@@ -54,6 +55,7 @@ int vlsat_debug_option(vlsat_handle h, const char* name, int32_t value) {
     if (k == "dual_stream") h->dual_stream = value != 0;
     else if (k == "flash_split") h->fa_split = value != 0;
     else if (k == "gemm_dma") h->gemm_no_dma = value == 0;
+    else if (k == "gemm_p8") h->gemm_no_p8 = value == 0;
     else if (k == "gate_grid") h->gate_grid = value > 0 ? value : 0;
     else if (k == "gemm_splitk") h->gemm_splitk = value != 0;
     else if (k == "node_attn_split") h->node_attn_split = value;
@@ -121,9 +123,10 @@ int vlsat_k_gemm_planes(const float* A, int32_t lda, const float* W, const uint1
     // (bit 3 was the k-rotation experiment: removed; bit 4: no ring kernel -- benchmarking)
     a.no_ring = (fmt >> 4) & 1;
     a.ring_wide = (fmt >> 7) & 1;              // (bit 7: ring kernel with 128 x 256 tiles where N allows)
-    a.ablate = (fmt >> 8) & 3;                 // (bits 8, 9: timing experiments, see GemmArgs::ablate)
+    a.ablate = ((fmt >> 8) & 3) | (((fmt >> 13) & 3) << 2);   // (bits 8, 9, 13, 14: timing experiments, see GemmArgs::ablate)
     a.ring_bk32 = (fmt >> 10) & 1;             // (bit 10: half-row ring kernel with 32-wide k slices)
     a.ring_nodb = (fmt >> 11) & 1;             // (bit 11: ... without the double-buffered fragment sets)
+    a.no_p8 = (fmt >> 12) & 1;                 // (bit 12: half-row launches skip the 256 x 256 8-phase kernel)
     if ((fmt >> 6) & 1) RUN(test_splitk_ws(a));    // (bit 6: small launches may take the split-K kernel)
     return launch_gemm(a, static_cast<hipStream_t>(stream));
 }

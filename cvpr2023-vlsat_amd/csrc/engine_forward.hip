@@ -90,6 +90,7 @@ int gemm(vlsat_ctx* h, hipStream_t s, const GemmArgs& a0) {
         a.Wlo = it->second.second;
     }
     a.no_dma = h->gemm_no_dma;
+    a.no_p8 = h->gemm_no_p8;
     a.launches = &h->gemm_launches;
     if (h->gemm_splitk) {
         const int w = (h->side && s == h->side) ? 1 : 0;

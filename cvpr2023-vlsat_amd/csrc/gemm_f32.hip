@@ -267,6 +267,25 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
         const int r = launch_gemm_splitk(a, G, s);
         if (r <= 0) return r;
     }
+    // single-rounding bf16 with half-row operands, large M: the full rounds of 256 x 256 tiles go to the 8-phase kernel
+    // (gemm_bf16_p8.hip: one 8-wave block per CU), the remaining row panels to the kernels below
+    if (a.prec == 1 && a.a_split == 2 && !a.no_dma && !a.no_ring && !a.no_p8 && !a.rowscale && a.N % 256 == 0 && a.K % 128 == 0 &&
+        ((size_t)a.M + 256) * a.lda * 4 < (1ull << 32) && ((size_t)a.M + 256) * a.ldc * 4 < (1ull << 32) &&
+        ((size_t)a.N + 256) * a.ldw * 4 < (1ull << 32)) {
+        const int G1 = G / 2;
+        const long nbn = a.N / 256, rounds = (long)(a.M / 256) * nbn / G1;
+        const long main_panels = rounds * G1 / nbn;
+        if (main_panels > 0) {
+            GemmArgs m = a;
+            m.M = (int)(main_panels * 256);
+            const int r = launch_gemm_p8(m, (int)(main_panels * nbn), G1, s);
+            if (r < 0) return r;
+            if (r == 0) {
+                if (m.M == a.M) return 0;
+                return launch_gemm(tail_of(a, m.M), s);
+            }
+        }
+    }
     // bf16 modes, large M: the full rounds go to the 3-stage ring kernel (gemm_bf16_ring.hip: one 8-wave block per CU,
     // 256 x 128 tiles, two slices in flight), the remaining row panels to the kernels below
     if ((a.prec == 1 || a.prec == 3) && !a.no_dma && !a.no_ring && a.N > 64 && !a.rowscale &&

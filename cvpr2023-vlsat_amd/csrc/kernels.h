@@ -30,11 +30,12 @@ struct GemmArgs {
     // 2 half rows (bf16 values at byte 2 * column of an fp32-pitched row; single-rounding modes)
     int a_split = 0, r_split = 0, c_split = 0;
     float c_scale = 1.f;                        // final multiplier of C (after bias / activation)
-    int ablate = 0;                             // timing experiments on the ring kernel: bit 0 no operand loads after the first slices, bit 1 no MFMAs (results are garbage)
+    int ablate = 0;                             // timing experiments on the ring kernel: bit 0 no operand loads after the first slices, bit 1 no MFMAs, bit 2 (8-phase kernel) no fragment reads (results are garbage)
     int ring_nodb = 0;                          // experiment: half-row ring kernel without the double-buffered fragment sets
     int ring_bk32 = 0;                          // experiment: half-row ring kernel with 32-wide k slices (default 64 where K allows)
     int ring_wide = 0;                          // experiment: bf16 ring kernel with 128 x 256 tiles where N allows (measured equal)
     int no_ring = 0;                            // debug: keep large bf16 launches on the two-stage 128 x 128 kernel
+    int no_p8 = 0;                              // debug: half-row launches skip the 256 x 256 8-phase kernel (gemm_bf16_p8.hip)
     int prefetch = -1;                          // bf16 LDS-direct pipe: slices of look-ahead of the A-panel prefetch (0 off, -1 default)
     int no_dma = 0;                             // debug: VGPR-staged fp32 operands instead of LDS-direct (vlsat_debug_option "gemm_dma")
     long* launches = nullptr;                   // optional host counter, +1 per kernel launched (profiling)
@@ -51,6 +52,9 @@ constexpr size_t SPLITK_COUNTERS = 512;
 // bf16 modes, full rounds of large-M launches: 3-stage LDS ring, 256 x 128 tiles, one 8-wave block per CU
 // (gemm_bf16_ring.hip); returns 1 if the operand combination is not built
 int launch_gemm_ring(const GemmArgs& a, int rbn, int n_tiles, int grid, hipStream_t s);   // rbn: tile width 128 | 256
+// single-rounding bf16 with half-row A, full rounds of large-M launches: 256 x 256 tiles, 8-phase pipeline, one 8-wave block
+// per CU (gemm_bf16_p8.hip); needs M % 256 == 0, N % 256 == 0, K % 128 == 0; returns 1 if the combination is not built
+int launch_gemm_p8(const GemmArgs& a, int n_tiles, int grid, hipStream_t s);
 double gemm_flops(const GemmArgs& a);
 void gemm_set_clock_probe(long long* buf);
 
