@@ -123,7 +123,7 @@ int vlsat_k_gemm_planes(const float* A, int32_t lda, const float* W, const uint1
     // (bit 3 was the k-rotation experiment: removed; bit 4: no ring kernel -- benchmarking)
     a.no_ring = (fmt >> 4) & 1;
     a.ring_wide = (fmt >> 7) & 1;              // (bit 7: ring kernel with 128 x 256 tiles where N allows)
-    a.ablate = ((fmt >> 8) & 3) | (((fmt >> 13) & 3) << 2);   // (bits 8, 9, 13, 14: timing experiments, see GemmArgs::ablate)
+    a.ablate = ((fmt >> 8) & 3) | (((fmt >> 13) & 63) << 2);   // (bits 8, 9, 13..18: timing experiments, see GemmArgs::ablate)
     a.ring_bk32 = (fmt >> 10) & 1;             // (bit 10: half-row ring kernel with 32-wide k slices)
     a.ring_nodb = (fmt >> 11) & 1;             // (bit 11: ... without the double-buffered fragment sets)
     a.no_p8 = (fmt >> 12) & 1;                 // (bit 12: half-row launches skip the 256 x 256 8-phase kernel)

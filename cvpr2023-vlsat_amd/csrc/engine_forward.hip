@@ -428,13 +428,14 @@ static int forward_impl(vlsat_handle h, vlsat_plan p, const float* pts, const fl
             // Split-pair mode: the residual is added by the LayerNorm kernel instead (as an accumulator init it made the
             // out-projection 60 % slower there -- 397 vs 243 us at the bench size -- against +1 KB per row in the LayerNorm).
             float* pre_ln = S ? p->Qe : p->E2;
-            const bool ln_resid = S == 1 && h->ln_resid;
+            // Half rows: the same (the 8-phase GEMM has no fast accumulator-init path).
+            const bool ln_resid = (S == 1 || (S == 2 && !h->gemm_no_p8)) && h->ln_resid;
             GemmArgs o = G(p->Oe, D, w.wo, D, pre_ln, D, E, D, w.bo);
             if (!ln_resid) { o.resid = p->E2; o.ldr = D; o.r_split = S; }
             o.a_split = S;
             RUN(gemm(h, s, o));
             Scope sc(h, s, PC_LAYERNORM, 0);
-            RUN(launch_layernorm_to(pre_ln, D, p->E2, D, E, D, w.lng, w.lnb, inter, S, s, ln_resid ? p->E2 : nullptr, D, 1));
+            RUN(launch_layernorm_to(pre_ln, D, p->E2, D, E, D, w.lng, w.lnb, inter, S, s, ln_resid ? p->E2 : nullptr, D, S));
         }
         e3_pending_relu = inter;
         STAGE(base + 4);

@@ -7,7 +7,7 @@
 //
 // Structure (cdna_hip_programming.md "The 256^2 8-phase template", rebuilt for this library's operand formats):
 //   * ONE persistent block of 8 waves per CU, block tile 256 x 256, waves 2 (M) x 4 (N), wave tile 128 x 64 =
-//     4 x 2 tiles of v_mfma_f32_32x32x16_bf16 (transposed product: a lane owns one output ROW, tile_epilogue's layout).
+//     4 x 2 tiles of v_mfma_f32_32x32x16_bf16 (transposed product: a lane owns one output ROW, gemm_core.h).
 //   * K in tiles of 64; LDS holds two K-tiles (2 x 64 KB), each as four HALF-TILES of 128 rows x 128 bytes:
 //       A_h = rows {wr*128 + h*64 + i} of the block's A panel,  W_h = rows {wc*64 + h*32 + j} of its weight panel,
 //     i.e. half-tile h is what quadrant h of EVERY wave reads.  Rows are 128 bytes, 16-byte chunks XOR-swizzled with
@@ -15,15 +15,20 @@
 //   * A K-tile is FOUR PHASES, one per quadrant of the wave tile, in the order (a0,w0) (a0,w1) (a1,w1) (a1,w0); a phase is
 //         ds_read the operands the quadrant does not hold yet (12 / 4 / 8 / 0 ds_read_b128)
 //         issue ONE half-tile of LDS-direct loads (2 x buffer_load_dwordx4 ... lds per lane)
-//         s_waitcnt vmcnt(8) ; s_barrier ; s_waitcnt lgkmcnt(0) ; 8 MFMAs under s_setprio 1 ; s_barrier
+//         s_waitcnt vmcnt(8 + e) ; s_barrier ; s_waitcnt lgkmcnt(0) ; 8 MFMAs under s_setprio 1 ; s_barrier
 //     and the two wave rows run one barrier apart, so on every SIMD one wave is in its MFMA cluster while its partner
 //     reads LDS and issues loads.
 //   * Loads are never drained: phase q of K-tile g stages  W_1(g+1), A_1(g+1), A_0(g+2), W_0(g+2)  for q = 1..4 -- each
-//     into the buffer half its previous tenant's last ds_read left >= 2 phases earlier -- and every wait is the counted
-//     vmcnt(8): "everything but the four half-tiles issued last has landed", which is exactly what the next phase reads.
-//     The sequence of K-tiles runs on across output tiles (the staging cursor is two K-tiles ahead, in the next tile if
-//     need be).
-// Results are bit-identical to the 128 x 128 kernel's (same k order per accumulator).
+//     into the buffer half its previous tenant's last ds_read left >= 2 phases earlier -- and every wait is counted:
+//     "everything but the four half-tiles issued last (and the e epilogue stores issued since) has landed", which is
+//     exactly what the next phase reads.  The sequence of K-tiles runs on across output tiles (the staging cursor is two
+//     K-tiles ahead, in the next tile if need be).
+//   * The epilogue is spread over the phases around a tile boundary, one 32-row strip of the wave tile per phase: strips
+//     0 / 1 (final after quadrant (a0,w1)) in phases 3 / 4 of the tile's last K-tile, strips 2 / 3 in phases 1 / 2 of the
+//     NEXT tile's first K-tile -- under the partner wave's MFMAs.  A strip goes bias -> activation -> bf16 -> a wave-private
+//     4 KB LDS transposition -> buffer_store_dwordx4 of 8 full 128-byte rows per instruction (row-per-lane 8-byte stores
+//     touch 32 lines per instruction and made the epilogue 40 % of the launch).
+// Results equal the 128 x 128 kernel's up to the place of the bias in the fp32 summation (first instead of last).
 // Roofline: bf16 MFMA (2.5 PF dense); per K-tile a block moves 64 KB from L2 for 8.4 MFLOP.
 #include <type_traits>
 
@@ -34,20 +39,31 @@ namespace vlsat {
 
 namespace {
 
-template <int N> __device__ __forceinline__ void p8_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void p8_wait_vm() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 __device__ __forceinline__ void p8_barrier() { asm volatile("s_barrier" ::: "memory"); }
 __device__ __forceinline__ void p8_wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 constexpr int P8_BM = 256, P8_BN = 256, P8_BK = 64;
 constexpr int P8_HALF = 128 * 128;            // bytes of a half-tile
 constexpr int P8_WBASE = 4 * P8_HALF;         // weight half-tiles start after the four A half-tiles (2 buffers x 2 halves)
+constexpr int P8_TBASE = 8 * P8_HALF;         // wave-private transposition buffers of the epilogue (8 x 4 KB)
 
-// ABL (timing experiments, results are garbage): bit 0 no LDS-direct loads after the prologue, bit 1 no MFMAs, bit 2 no
-// fragment reads, bit 3 no epilogue
-template <int ADD, bool RELU, int ABL = 0>
+// (ABL bit 4: no barrier after the MFMA clusters, bit 5: no barrier in the K loop at all -- timing experiments)
+enum { P8_MID = 0, P8_LAST = 1, P8_FIRST = 2, P8_SECOND = 3, P8_FIRST0 = 4 };   // FIRST0: first K-tile of a tile without strips of a previous one
+
+// CF: storage format of C (0 fp32, 2 half rows).  ABL (timing experiments, results are garbage): bit 0 no LDS-direct
+// loads after the prologue, bit 1 no MFMAs, bit 2 no fragment reads, bit 3 no epilogue stores
+template <int ADD, bool RELU, int CF, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmArgs p, int n_tiles, int nbn) {
-    __shared__ __attribute__((aligned(16))) char smem[8 * P8_HALF];
+    __shared__ __attribute__((aligned(16))) char smem[10 * P8_HALF];
     typedef short s16x8 __attribute__((ext_vector_type(8)));
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    constexpr bool SPREAD = ADD == 0;             // epilogue strips 2 / 3 inside the next tile's first K-tile
+    constexpr int E = CF == 2 ? 4 : 8;            // buffer stores per epilogue strip and lane
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -68,23 +84,22 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmArgs p, int n_tiles
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, na, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.Whi), 0, nw, 0x00020000);
     char* const sdst = smem + wave * 1024;
+    // two wave instructions = one half-tile: rows 0..63 and 64..127 of it
+    auto ld2 = [&](const __amdgpu_buffer_rsrc_t& r, char* dst, unsigned v, unsigned s0, unsigned step) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst, 16, v, s0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst + 8192, 16, v, s0 + step, 0, 0);
+    };
     // half-tile h of the K-tile at byte offsets (sa, sw) into buffer `buf`
     auto stage_a = [&](int buf, int h, unsigned sa) {
-        char* d = sdst + (buf * 2 + h) * P8_HALF;
-        const unsigned s0 = sa + (unsigned)(h * 64) * lda4;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, d, 16, vA, s0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, d + 8192, 16, vA, s0 + 128u * lda4, 0, 0);
+        if (!(ABL & 1)) ld2(ra, sdst + (buf * 2 + h) * P8_HALF, vA, sa + (unsigned)(h * 64) * lda4, 128u * lda4);
     };
     auto stage_w = [&](int buf, int h, unsigned sw) {
-        char* d = sdst + P8_WBASE + (buf * 2 + h) * P8_HALF;
-        const unsigned s0 = sw + (unsigned)(h * 32) * ldw2;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, d, 16, vW, s0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, d + 8192, 16, vW, s0 + 128u * ldw2, 0, 0);
+        if (!(ABL & 1)) ld2(rw, sdst + P8_WBASE + (buf * 2 + h) * P8_HALF, vW, sw + (unsigned)(h * 32) * ldw2, 128u * ldw2);
     };
 
     // ---- staging cursor: the K-tile sequence of this block, across output tiles ----
-    // (past the block's last tile the cursor stays on it: the loads keep their rhythm, so every wait is the same counted
-    //  one and the K loop has no branch; what they fetch is never read)
+    // (past the block's last tile the cursor stays on it: the loads keep their rhythm, so every wait is a counted one and
+    //  the K loop has no branch; what they fetch is never read)
     struct Cur { int r, kt; unsigned sa, sw; };
     auto locate = [&](Cur& c) {
         const int v = tile_of_round(c.r);
@@ -98,7 +113,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmArgs p, int n_tiles
     };
     Cur c1{0, 0, 0u, 0u};
     locate(c1);
-    Cur c0 = c1;
+    const Cur c0 = c1;
     advance(c1);
     Cur c2 = c1;
     advance(c2);
@@ -113,28 +128,65 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmArgs p, int n_tiles
         offW[ks] = P8_WBASE + (wc * 32 + li) * 128 + chunk;
     }
     bf16x8 af[2][4], w0[4], w1[4];
+    bf16x8 dum[12];                              // (ABL bit 6: the reads land here and nothing waits for them before the MFMAs)
     auto read_a = [&](int buf, int h) {
         if (ABL & 4) return;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                s16x8 v = *reinterpret_cast<const s16x8*>(smem + offA[ks] + (buf * 2 + h) * P8_HALF + mt * 4096);
-                af[mt][ks] = __builtin_bit_cast(bf16x8, v);
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + offA[ks] + (buf * 2 + h) * P8_HALF + mt * 4096);
+                if (ABL & 64) dum[4 + mt * 4 + ks] = v; else af[mt][ks] = v;
             }
     };
     auto read_w = [&](int buf, int h, bf16x8 (&w)[4]) {
         if (ABL & 4) return;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) w[ks] = *reinterpret_cast<const bf16x8*>(smem + offW[ks] + (buf * 2 + h) * P8_HALF);
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + offW[ks] + (buf * 2 + h) * P8_HALF);
+            if (ABL & 64) dum[ks] = v; else w[ks] = v;
+        }
+    };
+    auto eat = [&]() {
+        if (ABL & 64) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) asm volatile("" ::"v"(dum[i]));
+        }
     };
 
     f32x16 acc[4][2];
-    zero_acc<4, 2>(acc);
-    // quadrant (ah, bh): 2 m-tiles x 1 n-tile x 4 k-steps
-    auto mma = [&](int ah, int bh, const bf16x8 (&w)[4]) {
+    // The bias enters as ONE EXTRA k-step at the start of a tile: W' = [b_hi b_mid b_lo 0 ...] (the fp32 bias as three bf16
+    // terms: their fp32 sum is exact) against A' = [1 1 1 0 ...] -- 8 MFMAs per tile instead of 128 bias registers or adds
+    // per lane, and it replaces zeroing the accumulators.  The block's columns never change (the launcher makes the tile
+    // order keep n0 per block), so the two operand registers sets live for the whole kernel.
+    const int n0 = (tile_of_round(0) % nbn) * P8_BN;
+    bf16x8 wb[2], ones;
+    {
+        const __bf16 z = (__bf16)0.f, o = hi ? z : (__bf16)1.f;
+        ones = bf16x8{o, o, o, z, z, z, z, z};
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const float b = (p.bias && !hi) ? p.bias[n0 + (wc * 2 + tn) * 32 + li] : 0.f;
+            const __bf16 b0 = (__bf16)b;
+            const float r1 = b - (float)b0;
+            const __bf16 b1 = (__bf16)r1;
+            const __bf16 b2 = (__bf16)(r1 - (float)b1);
+            wb[tn] = bf16x8{b0, b1, b2, z, z, z, z, z};
+            asm volatile("" : "+v"(wb[tn]));     // landed before the pipeline starts: no compiler-inserted wait inside it
+        }
+    }
+    // quadrant (ah, bh): 2 m-tiles x 1 n-tile x 4 k-steps; INIT: first k-tile of an output tile
+    auto mma = [&](int ah, int bh, const bf16x8 (&w)[4], auto initc) {
+        constexpr bool INIT = decltype(initc)::value;
         if (ABL & 2) return;
-        __builtin_amdgcn_s_setprio(1);
+        if (!(ABL & 128)) __builtin_amdgcn_s_setprio(1);
+        if (INIT) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const f32x16 c0 = ADD != 0 ? acc[2 * ah + mt][bh] : f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                acc[2 * ah + mt][bh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[bh], ones, c0, 0, 0, 0);
+            }
+        }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -143,137 +195,174 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmArgs p, int n_tiles
                 if (RELU) a = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, a), s16x8{0, 0, 0, 0, 0, 0, 0, 0}));
                 acc[2 * ah + mt][bh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ks], a, acc[2 * ah + mt][bh], 0, 0, 0);
             }
-        __builtin_amdgcn_s_setprio(0);
+        if (!(ABL & 128)) __builtin_amdgcn_s_setprio(0);
+        eat();
     };
 
-    // ---- prologue: the six half-tiles whose staging phase lies before the first compute phase ----
-    stage_a(0, 0, c0.sa);
-    stage_w(0, 0, c0.sw);
-    stage_w(0, 1, c0.sw);
-    stage_a(0, 1, c0.sa);
-    stage_a(1, 0, c1.sa + c1.kt * 128u);
-    stage_w(1, 0, c1.sw + c1.kt * 128u);
-    p8_wait_vm<8>();
-    p8_barrier();
-    if (wr == 1) p8_barrier();                       // the two wave rows run one barrier apart from here on
-
-    // One K-tile = four phases on buffer B; c1 / c2 = the K-tiles one and two ahead.
-    auto ktile = [&](auto bufc) {
-        constexpr int B = decltype(bufc)::value;
-        constexpr bool ST = !(ABL & 1);
-        const unsigned a1 = c1.sa + c1.kt * 128u, w1o = c1.sw + c1.kt * 128u;
-        const unsigned a2 = c2.sa + c2.kt * 128u, w2o = c2.sw + c2.kt * 128u;
-        // phase 1: quadrant (a0, w0)
-        read_w(B, 0, w0);
-        __builtin_amdgcn_sched_barrier(0);
-        read_a(B, 0);
-        if (ST) stage_w(B ^ 1, 1, w1o);
-        p8_wait_vm<8>();
-        p8_barrier();
-        p8_wait_lds();
-        __builtin_amdgcn_sched_barrier(0);
-        mma(0, 0, w0);
-        __builtin_amdgcn_sched_barrier(0);
-        p8_barrier();
-        // phase 2: quadrant (a0, w1)
-        read_w(B, 1, w1);
-        if (ST) stage_a(B ^ 1, 1, a1);
-        p8_wait_vm<8>();
-        p8_barrier();
-        p8_wait_lds();
-        __builtin_amdgcn_sched_barrier(0);
-        mma(0, 1, w1);
-        __builtin_amdgcn_sched_barrier(0);
-        p8_barrier();
-        // phase 3: quadrant (a1, w1)
-        read_a(B, 1);
-        if (ST) stage_a(B, 0, a2);
-        p8_barrier();
-        p8_wait_lds();
-        __builtin_amdgcn_sched_barrier(0);
-        mma(1, 1, w1);
-        __builtin_amdgcn_sched_barrier(0);
-        p8_barrier();
-        // phase 4: quadrant (a1, w0)
-        if (ST) stage_w(B, 0, w2o);
-        p8_wait_vm<8>();
-        p8_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        mma(1, 0, w0);
-        __builtin_amdgcn_sched_barrier(0);
-        p8_barrier();
-        c1 = c2;
-        advance(c2);
-    };
-
-    // ---- epilogue of one quadrant: bias, activation, scale, store (tiles of this kernel are always interior) ----
-    // Lane (li, hi) holds row li of a 32 x 32 tile and columns 8 g + 4 hi .. + 3, g = 0..3 (gemm_core.h).  Stores go
-    // through a buffer descriptor: one per-lane offset register for the whole kernel, the rest is scalar + immediate.
-    const int half_out = p.c_split == 2;
-    const unsigned crow = (unsigned)(wr * 128 + li) * (unsigned)p.ldc * 4u + (unsigned)hi * (half_out ? 8u : 16u);
+    // ---- epilogue of one 32-row strip (tm) of the wave tile ----
+    // Lane (li, hi) holds row li and columns tn*32 + 8g + 4hi .. +3 (gemm_core.h).  The strip is transposed through a
+    // wave-private LDS buffer of 32 rows x 128 bytes (16-byte chunks XOR-swizzled with row & 7) so that lane l then holds
+    // 16 consecutive bytes of row 8j + (l >> 3), chunk l & 7: one store instruction writes 8 full 128-byte rows.
+    char* const tbuf = smem + P8_TBASE + wave * 4096;
+    const int t_wr = li * 128 + hi * (CF == 2 ? 8 : 0), t_x = (li & 7) << 4;
+    const int t_rd = (lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 3) & 7)) << 4);
+    const unsigned ldc4 = (unsigned)p.ldc * 4u;
+    const unsigned vst = (unsigned)(lane >> 3) * ldc4 + (unsigned)(lane & 7) * 16u;
     const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)(((size_t)(p.M - 1) * p.ldc + p.N) * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias ? p.bias : p.C), 0, p.N * 4, 0x00020000);
-    auto epilogue = [&](int m0, int n0, int ah, int bh) {
-        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-        const int ncol = n0 + (wc * 2 + bh) * 32;                       // first column of the quadrant's n-tile
-        f32x4 b[4];
+    const float cs = p.c_scale;
+    const float act_lo = p.act == ACT_RELU ? 0.f : -__builtin_inff();
+    auto epi = [&](auto tmc, int m0) {
+        constexpr int TM = decltype(tmc)::value;
+        const unsigned srow = (unsigned)(m0 + wr * 128 + TM * 32) * ldc4 + (unsigned)(n0 + wc * 64) * (CF == 2 ? 2u : 4u);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) b[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (p.bias) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                b[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, (unsigned)hi * 16u, (unsigned)(ncol + 8 * g) * 4u, 0));
-        }
-        const float cs = p.c_scale;
-        const int act = p.act;
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const unsigned srow = (unsigned)(m0 + (2 * ah + mt) * 32) * (unsigned)p.ldc * 4u;
+        for (int tn = 0; tn < 2; ++tn) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 f32x4 v;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) v[c] = acc[2 * ah + mt][bh][4 * g + c] + b[g][c];
-                if (act == ACT_RELU) {
+                for (int c = 0; c < 4; ++c) v[c] = acc[TM][tn][4 * g + c];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
-                } else if (act == ACT_SIGMOID) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) v[c] = 1.f / (1.f + __expf(-v[c]));
-                }
-                v *= cs;
-                if (half_out) {
+                for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], act_lo) * cs;      // (branch-free: ReLU or max with -inf)
+                if (CF == 2) {
                     u32x2 w;
                     w.x = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v[0]) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)v[1]) << 16);
                     w.y = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v[2]) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)v[3]) << 16);
-                    __builtin_amdgcn_raw_buffer_store_b64(w, rc, crow, srow + (unsigned)(ncol + 8 * g) * 2u, 0);
+                    *reinterpret_cast<u32x2*>(tbuf + t_wr + (((tn * 4 + g) << 4) ^ t_x)) = w;
                 } else {
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), rc, crow,
-                                                           srow + (unsigned)(ncol + 8 * g) * 4u, 0);
+                    *reinterpret_cast<f32x4*>(tbuf + t_wr + (((2 * g + hi) << 4) ^ t_x)) = v;
                 }
+            }
+            if (CF != 2 || tn == 1) {          // the buffer holds 32 rows x 128 bytes: both n-tiles (bf16) or one (fp32)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) acc[2 * ah + mt][bh][4 * g + c] = 0.f;
+                for (int j = 0; j < 4; ++j) {
+                    const u32x4 r = *reinterpret_cast<const u32x4*>(tbuf + t_rd + j * 1024);
+                    if (!(ABL & 8))
+                        __builtin_amdgcn_raw_buffer_store_b128(r, rc, vst, srow + (unsigned)(8 * j) * ldc4 + (CF == 2 ? 0u : (unsigned)tn * 128u), 0);
+                    else
+                        asm volatile("" ::"v"(r));
+                }
             }
         }
     };
 
+    // ---- prologue: the six half-tiles whose staging phase lies before the first compute phase ----
+    ld2(ra, sdst, vA, c0.sa, 128u * lda4);                                                        // A_0(0)
+    ld2(rw, sdst + P8_WBASE, vW, c0.sw, 128u * ldw2);                                             // W_0(0)
+    ld2(rw, sdst + P8_WBASE + P8_HALF, vW, c0.sw + 32u * ldw2, 128u * ldw2);                      // W_1(0)
+    ld2(ra, sdst + P8_HALF, vA, c0.sa + 64u * lda4, 128u * lda4);                                 // A_1(0)
+    ld2(ra, sdst + 2 * P8_HALF, vA, c1.sa + c1.kt * 128u, 128u * lda4);                           // A_0(1)
+    ld2(rw, sdst + P8_WBASE + 2 * P8_HALF, vW, c1.sw + c1.kt * 128u, 128u * ldw2);                // W_0(1)
+    p8_wait_vm<8>();
+    p8_barrier();
+    if (wr == 1) p8_barrier();                       // the two wave rows run one barrier apart from here on
+
+    // One K-tile = four phases on buffer B; c1 / c2 = the K-tiles one and two ahead.  VAR places the epilogue strips
+    // (pm0: row base of the tile they belong to) and sets the counted waits: the half-tile a phase's wait must retire was
+    // issued four load parts earlier, with 8 LDS-direct loads and the epilogue stores of the parts since behind it.
+    auto ktile = [&](auto bufc, auto varc, int pm0) {
+        constexpr int B = decltype(bufc)::value;
+        constexpr int VAR = decltype(varc)::value;
+        // (a load part is [strip: E stores][2 LDS-direct loads][wait]: the wait of part j lets the loads of parts j-3 .. j
+        //  and the stores of those four parts stay in flight; strips sit in L3, L4, F1, F2)
+        constexpr int N1 = 8 + (VAR == P8_FIRST ? 3 * E : VAR == P8_SECOND ? E : 0);
+        constexpr int N2 = 8 + (VAR == P8_FIRST ? 4 * E : 0);
+        constexpr int N4 = 8 + (VAR == P8_FIRST || VAR == P8_LAST ? 2 * E : 0);
+        using Init = std::integral_constant<bool, VAR == P8_FIRST || VAR == P8_FIRST0>;
+        const unsigned a1 = c1.sa + c1.kt * 128u, w1o = c1.sw + c1.kt * 128u;
+        const unsigned a2 = c2.sa + c2.kt * 128u, w2o = c2.sw + c2.kt * 128u;
+        // phase 1: quadrant (a0, w0)
+        if (VAR == P8_FIRST) {               // (before the fragment reads: the strip's temporaries need their registers)
+            epi(std::integral_constant<int, 2>{}, pm0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        read_w(B, 0, w0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(B, 0);
+        stage_w(B ^ 1, 1, w1o);
+        p8_wait_vm<N1>();
+        if (!(ABL & 32)) p8_barrier();
+        if (!(ABL & 64)) p8_wait_lds();
+        __builtin_amdgcn_sched_barrier(0);
+        mma(0, 0, w0, Init{});
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(ABL & 48)) p8_barrier();
+        // phase 2: quadrant (a0, w1)
+        if (VAR == P8_FIRST) {
+            epi(std::integral_constant<int, 3>{}, pm0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        read_w(B, 1, w1);
+        stage_a(B ^ 1, 1, a1);
+        p8_wait_vm<N2>();
+        if (!(ABL & 32)) p8_barrier();
+        if (!(ABL & 64)) p8_wait_lds();
+        __builtin_amdgcn_sched_barrier(0);
+        mma(0, 1, w1, Init{});
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(ABL & 48)) p8_barrier();
+        // phase 3: quadrant (a1, w1)
+        if (VAR == P8_LAST) {
+            epi(std::integral_constant<int, 0>{}, pm0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        read_a(B, 1);
+        stage_a(B, 0, a2);
+        if (!(ABL & 32)) p8_barrier();
+        if (!(ABL & 64)) p8_wait_lds();
+        __builtin_amdgcn_sched_barrier(0);
+        mma(1, 1, w1, Init{});
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(ABL & 48)) p8_barrier();
+        // phase 4: quadrant (a1, w0)
+        if (VAR == P8_LAST) {
+            epi(std::integral_constant<int, 1>{}, pm0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        stage_w(B, 0, w2o);
+        p8_wait_vm<N4>();
+        if (!(ABL & 32)) p8_barrier();
+        if (!(ABL & 64)) p8_wait_lds();
+        __builtin_amdgcn_sched_barrier(0);
+        mma(1, 0, w0, Init{});
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(ABL & 48)) p8_barrier();
+        c1 = c2;
+        advance(c2);
+    };
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    using Mid = std::integral_constant<int, P8_MID>;
+
+    int pm0 = 0;
     for (int round = 0;; ++round) {
         const int v = tile_of_round(round);
         if (v >= n_tiles) break;
-        const int m0 = (v / nbn) * P8_BM, n0 = (v % nbn) * P8_BN;
+        const int m0 = (v / nbn) * P8_BM;
         if (ADD != 0) tile_init<4, 2, ADD>(p, m0, n0, wr, wc, lane, acc);
-        for (int kt = 0; kt < KT; kt += 2) {         // (KT is even: the launcher checks K % 128 == 0)
-            ktile(std::integral_constant<int, 0>{});
-            ktile(std::integral_constant<int, 1>{});
+        if (SPREAD && round > 0) {                   // strips 2 / 3 of the previous tile go out under this tile's first phases
+            ktile(B0{}, std::integral_constant<int, P8_FIRST>{}, pm0);
+            ktile(B1{}, std::integral_constant<int, P8_SECOND>{}, pm0);
+        } else {
+            ktile(B0{}, std::integral_constant<int, P8_FIRST0>{}, 0);
+            ktile(B1{}, Mid{}, 0);
         }
-        if (!(ABL & 8)) {
-            epilogue(m0, n0, 0, 0);
-            epilogue(m0, n0, 0, 1);
-            epilogue(m0, n0, 1, 1);
-            epilogue(m0, n0, 1, 0);
+        for (int kt = 2; kt < KT - 2; kt += 2) {     // (KT is even and >= 4: the launcher checks K % 128 == 0, K >= 256)
+            ktile(B0{}, Mid{}, 0);
+            ktile(B1{}, Mid{}, 0);
         }
+        ktile(B0{}, Mid{}, 0);
+        ktile(B1{}, std::integral_constant<int, P8_LAST>{}, m0);
+        if (!SPREAD) {                               // additive operands are loaded as accumulator inits of the next tile
+            epi(std::integral_constant<int, 2>{}, m0);
+            epi(std::integral_constant<int, 3>{}, m0);
+        }
+        pm0 = m0;
     }
     if (wr == 0) p8_barrier();
+    if (SPREAD) {
+        epi(std::integral_constant<int, 2>{}, pm0);
+        epi(std::integral_constant<int, 3>{}, pm0);
+    }
     p8_wait_vm<0>();                                 // no LDS-direct load may outlive the block's LDS allocation
 }
 
@@ -282,29 +371,46 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmArgs p, int n_tiles
 // full rounds of a large-M half-row launch on 256 x 256 tiles; 1 = operand combination not built (caller falls back)
 int launch_gemm_p8(const GemmArgs& a, int n_tiles, int grid, hipStream_t s) {
     const int add = (a.resid ? 1 : 0) | (a.g0 ? 2 : 0) | (a.g1 ? 4 : 0);
-    if (a.prec != 1 || a.a_split != 2 || a.c_split == 1 || a.rowscale || (add != 0 && add != 1 && add != 6)) return 1;
-    if (a.N % P8_BN || a.K % 128 || a.M % P8_BM) return 1;
+    if (a.prec != 1 || a.a_split != 2 || a.c_split == 1 || a.rowscale || a.act == ACT_SIGMOID || (add != 0 && add != 1 && add != 6)) return 1;
+    if (a.N % P8_BN || a.K % 128 || a.K < 256 || a.M % P8_BM) return 1;
     const int nbn = a.N / P8_BN;
-#define VLSAT_P8(ADD, RELU) hipLaunchKernelGGL((gemm_p8_kernel<ADD, RELU>), dim3(grid), dim3(512), 0, s, a, n_tiles, nbn)
-#define VLSAT_P8_ADD(RELU)                  \
-    switch (add) {                          \
-        case 0: VLSAT_P8(0, RELU); break;   \
-        case 1: VLSAT_P8(1, RELU); break;   \
-        default: VLSAT_P8(6, RELU); break;  \
-    }
-    if (a.ablate && add == 0 && !a.relu_a) {          // timing experiments (tools/p8_check.py --ablate)
+    if (grid % 8 || (grid / 8) % nbn) return 1;      // the kernel keeps one column tile per block (bias registers)
+#define VLSAT_P8(ADD, RELU, CF) hipLaunchKernelGGL((gemm_p8_kernel<ADD, RELU, CF>), dim3(grid), dim3(512), 0, s, a, n_tiles, nbn)
+#define VLSAT_P8_ABL(X) hipLaunchKernelGGL((gemm_p8_kernel<0, false, 2, X>), dim3(grid), dim3(512), 0, s, a, n_tiles, nbn)
+    const int key = add * 4 + (a.relu_a ? 2 : 0) + (a.c_split == 2 ? 1 : 0);
+    if (a.ablate && key == 1) {                       // timing experiments (tools/p8_check.py --ablate)
         switch (a.ablate) {
-            case 1: hipLaunchKernelGGL((gemm_p8_kernel<0, false, 1>), dim3(grid), dim3(512), 0, s, a, n_tiles, nbn); break;
-            case 2: hipLaunchKernelGGL((gemm_p8_kernel<0, false, 2>), dim3(grid), dim3(512), 0, s, a, n_tiles, nbn); break;
-            case 3: hipLaunchKernelGGL((gemm_p8_kernel<0, false, 3>), dim3(grid), dim3(512), 0, s, a, n_tiles, nbn); break;
-            case 4: hipLaunchKernelGGL((gemm_p8_kernel<0, false, 4>), dim3(grid), dim3(512), 0, s, a, n_tiles, nbn); break;
-            case 6: hipLaunchKernelGGL((gemm_p8_kernel<0, false, 6>), dim3(grid), dim3(512), 0, s, a, n_tiles, nbn); break;
-            case 7: hipLaunchKernelGGL((gemm_p8_kernel<0, false, 7>), dim3(grid), dim3(512), 0, s, a, n_tiles, nbn); break;
-            case 8: hipLaunchKernelGGL((gemm_p8_kernel<0, false, 8>), dim3(grid), dim3(512), 0, s, a, n_tiles, nbn); break;
-            default: hipLaunchKernelGGL((gemm_p8_kernel<0, false, 15>), dim3(grid), dim3(512), 0, s, a, n_tiles, nbn); break;
+            case 1: VLSAT_P8_ABL(1); break;
+            case 2: VLSAT_P8_ABL(2); break;
+            case 3: VLSAT_P8_ABL(3); break;
+            case 4: VLSAT_P8_ABL(4); break;
+            case 6: VLSAT_P8_ABL(6); break;
+            case 7: VLSAT_P8_ABL(7); break;
+            case 8: VLSAT_P8_ABL(8); break;
+            case 5: VLSAT_P8_ABL(5); break;
+            case 21: VLSAT_P8_ABL(21); break;
+            case 37: VLSAT_P8_ABL(37); break;
+            case 16: VLSAT_P8_ABL(16); break;
+            case 65: VLSAT_P8_ABL(65); break;
+            case 64: VLSAT_P8_ABL(64); break;
+            case 128: VLSAT_P8_ABL(128); break;
+            case 129: VLSAT_P8_ABL(129); break;
+            default: VLSAT_P8_ABL(15); break;
         }
-    } else if (a.relu_a) { VLSAT_P8_ADD(true) } else { VLSAT_P8_ADD(false) }
-#undef VLSAT_P8_ADD
+    } else {
+        switch (key) {
+            case 0: VLSAT_P8(0, false, 0); break;
+            case 1: VLSAT_P8(0, false, 2); break;
+            case 2: VLSAT_P8(0, true, 0); break;
+            case 3: VLSAT_P8(0, true, 2); break;
+            case 4: VLSAT_P8(1, false, 0); break;
+            case 5: VLSAT_P8(1, false, 2); break;
+            case 25: VLSAT_P8(6, false, 2); break;
+            case 27: VLSAT_P8(6, true, 2); break;
+            default: return 1;
+        }
+    }
+#undef VLSAT_P8_ABL
 #undef VLSAT_P8
     if (a.launches) ++*a.launches;
     VLSAT_LAUNCH_CHECK("gemm_bf16_p8");

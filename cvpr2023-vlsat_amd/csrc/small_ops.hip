@@ -81,7 +81,7 @@ int launch_desc_tail(const float* desc, int n_nodes, float* x, int ldx, int col0
 // In-place LayerNorm over rows of 512 (eps 1e-5, biased variance = torch.nn.LayerNorm), optional
 // ReLU.  One wave per row, 8 values per lane as two float4 (columns 4*lane and 256 + 4*lane).
 // reference transformer/attention.py:122 (post-LN residual) and network_MMG.py:236-248 (ReLU).
-// Optional residual (rows of `resid`, split-pair words if r_split): y = LN(x + resid) -- the post-LN residual of the edge
+// Optional residual (rows of `resid`; r_split 1: split-pair words, 2: half rows): y = LN(x + resid) -- the post-LN residual of the edge
 // attention in the split-bf16 mode, where adding it here is cheaper than as an accumulator init of the out-projection.
 __global__ __launch_bounds__(256) void layernorm512_kernel(const float* __restrict__ x, int ld, float* __restrict__ y, int ldy,
                                                            int rows, const float* __restrict__ gamma,
@@ -95,10 +95,18 @@ __global__ __launch_bounds__(256) void layernorm512_kernel(const float* __restri
     f32x4 b = *reinterpret_cast<const f32x4*>(p + 256 + 4 * lane);
     if (resid) {
         const float* r = resid + (size_t)row * ldr;
-        f32x4 ra = *reinterpret_cast<const f32x4*>(r + 4 * lane), rb = *reinterpret_cast<const f32x4*>(r + 256 + 4 * lane);
-        if (r_split) {
+        f32x4 ra, rb;
+        if (r_split == 2) {                                // half rows: bf16 at byte 2 * column
+            const uint2 ha = reinterpret_cast<const uint2*>(r)[lane], hb = reinterpret_cast<const uint2*>(r)[64 + lane];
+            ra = f32x4{__uint_as_float(ha.x << 16), __uint_as_float(ha.x & 0xffff0000u), __uint_as_float(ha.y << 16), __uint_as_float(ha.y & 0xffff0000u)};
+            rb = f32x4{__uint_as_float(hb.x << 16), __uint_as_float(hb.x & 0xffff0000u), __uint_as_float(hb.y << 16), __uint_as_float(hb.y & 0xffff0000u)};
+        } else {
+            ra = *reinterpret_cast<const f32x4*>(r + 4 * lane);
+            rb = *reinterpret_cast<const f32x4*>(r + 256 + 4 * lane);
+            if (r_split) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) { ra[c] = unpack_split(ra[c]); rb[c] = unpack_split(rb[c]); }
+                for (int c = 0; c < 4; ++c) { ra[c] = unpack_split(ra[c]); rb[c] = unpack_split(rb[c]); }
+            }
         }
         a += ra;
         b += rb;
@@ -141,8 +149,8 @@ int launch_layernorm(float* x, int ld, int rows, int dim, const float* gamma, co
 int launch_layernorm_to(const float* x, int ld, float* y, int ldy, int rows, int dim, const float* gamma, const float* beta,
                         int relu, int out_split, hipStream_t s, const float* resid, int ldr, int r_split) {
     if (rows <= 0) return 0;
-    if (dim != 512 || (ld & 3) || (ldy & 3) || (resid && ((ldr & 3) || r_split > 1)))
-        return fail(-1, "layernorm: dim must be 512, ld a multiple of 4, residual fp32 or split pairs");
+    if (dim != 512 || (ld & 3) || (ldy & 3) || (resid && ((ldr & 3) || r_split > 2)))
+        return fail(-1, "layernorm: dim must be 512, ld a multiple of 4, residual fp32, split pairs or half rows");
     hipLaunchKernelGGL(layernorm512_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, ld, y, ldy, rows, gamma, beta, relu, out_split,
                        resid, ldr, r_split);
     VLSAT_LAUNCH_CHECK("layernorm512");

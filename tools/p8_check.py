@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--rows", type=int, default=99840)
+    ap.add_argument("--only", default="", help="substring of the shape names to run")
     ap.add_argument("--ablate", action="store_true", help="time the kernel with loads / MFMAs / fragment reads removed (first shape)")
     a = ap.parse_args()
     lib = L.load()
@@ -45,6 +46,8 @@ def main():
     ]
     M = a.rows
     for name, N, K, resid, gather, relu_a, act, c_half in shapes:
+        if a.only and a.only not in name:
+            continue
         A = torch.randn(M, K, generator=g)
         Ah = to_half_rows(A).to(DEV)
         W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV)
@@ -75,19 +78,27 @@ def main():
             torch.cuda.synchronize()
             ref = C.clone()
             if c_half:
-                gv, rv = got.view(torch.int16).view(M, 2 * N)[:, :N], ref.view(torch.int16).view(M, 2 * N)[:, :N]
+                gv, rv = got.view(torch.bfloat16).view(M, 2 * N)[:, :N].float(), ref.view(torch.bfloat16).view(M, 2 * N)[:, :N].float()
             else:
-                gv, rv = got.view(torch.int32), ref.view(torch.int32)
+                gv, rv = got, ref
             bad = int((gv != rv).sum())
-            print(f"{name:40s} check: {'bit-identical' if bad == 0 else f'{bad} of {gv.numel()} elements differ'}", flush=True)
-            if bad:
-                d = (gv != rv).nonzero()
-                print("   first mismatches (row, col):", d[:8].tolist(), " rows hit:", int((gv != rv).any(1).sum()), flush=True)
+            err = float((gv - rv).abs().max())
+            scale = float(rv.abs().max())
+            nan = int((~torch.isfinite(gv)).sum())
+            # the bias sits at the other end of the fp32 summation: a few results may round to the neighbouring bf16 / fp32 value
+            tol = scale * 2.0 ** -7 if c_half else scale * 1e-5
+            ok = nan == 0 and err <= tol and bad <= gv.numel() * (0.02 if c_half else 1.0)
+            print(f"{name:40s} check: {'OK ' if ok else 'FAIL'} {bad} of {gv.numel()} differ, max abs diff {err:.3e} (max |ref| {scale:.2f}), non-finite {nan}", flush=True)
+            if not ok:
+                d = ((gv - rv).abs() > tol).nonzero()
+                print("   first bad (row, col):", d[:8].tolist(), " rows hit:", int(((gv - rv).abs() > tol).any(1).sum()), flush=True)
         variants = [("p8", fmt), ("ring", fmt | NO_P8)]
         if a.ablate and name.startswith("kproj"):
-            ab = lambda bits: ((bits & 3) << 8) | (((bits >> 2) & 3) << 13)
+            ab = lambda bits: ((bits & 3) << 8) | (((bits >> 2) & 63) << 13)
             variants += [("-load", fmt | ab(1)), ("-mfma", fmt | ab(2)), ("-read", fmt | ab(4)), ("-ld-mf", fmt | ab(3)), ("-mf-rd", fmt | ab(6)), ("none", fmt | ab(7)),
-                         ("-epi", fmt | ab(8)), ("bars", fmt | ab(15))]
+                         ("-epi", fmt | ab(8)), ("bars", fmt | ab(15)),
+                         ("mfma+bars", fmt | ab(5)), ("mfma+B1", fmt | ab(21)), ("mfma nobar", fmt | ab(37)), ("full-B2", fmt | ab(16)),
+                         ("-ld rd-nowait", fmt | ab(65)), ("rd-nowait", fmt | ab(64)), ("noprio", fmt | ab(128)), ("-ld noprio", fmt | ab(129))]
         for tag, f in variants:
             for _ in range(3):
                 run(f)
@@ -100,7 +111,7 @@ def main():
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / a.iters
             tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12
-            print(f"{name:40s} {tag:5s} {ms * 1e3:9.1f} us  {tf:7.1f} TF  {100 * tf / 2500:5.1f} %", flush=True)
+            print(f"{name:40s} {tag:14s} {ms * 1e3:9.1f} us  {tf:7.1f} TF  {100 * tf / 2500:5.1f} %", flush=True)
 
 
 if __name__ == "__main__":
