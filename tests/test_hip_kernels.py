@@ -534,10 +534,16 @@ def test_half_row_format_gemm_and_attention(lib):
             return Cb.cpu()
         for relu_a in (0, 1):
             plain = run(Ad, Rd, 0, relu_a)
-            half_in = run(Ah, Rh, 32 | 3, relu_a)
+            half_in = run(Ah, Rh, 32 | 3 | (1 << 12), relu_a)             # (bit 12: not the 8-phase kernel, tested below)
             assert torch.equal(plain, half_in), f"M={M} relu {relu_a}: {float((plain - half_in).abs().max()):.3e}"
-            half_out = _from_half_rows(run(Ah, Rh, 32 | 7, relu_a), N)
+            half_out = _from_half_rows(run(Ah, Rh, 32 | 7 | (1 << 12), relu_a), N)
             assert torch.equal(half_out, plain.to(torch.bfloat16).float())
+            if M >= 65536:        # large launches: the 256 x 256 8-phase kernel takes the full rounds (bias first in the fp32 sum)
+                p8_in = run(Ah, Rh, 32 | 3, relu_a)
+                assert float((p8_in - plain).abs().max()) <= 2e-5 * float(plain.abs().max())
+                p8_out = _from_half_rows(run(Ah, Rh, 32 | 7, relu_a), N)
+                d = (p8_out - half_out).abs()
+                assert bool((d <= 2.0 ** -7 * half_out.abs() + 2e-5 * float(half_out.abs().max())).all()) and float((d > 0).float().mean()) < 0.01
     tok = [0, 70, 70 + 333]
     T = tok[-1]
     sc = 0.125 * 1.4426950408889634
@@ -548,6 +554,61 @@ def test_half_row_format_gemm_and_attention(lib):
     ref = _ref_attn(qs / sc, k, v, tok, 0.125)
     assert float((got - ref).abs().max()) < 8e-2
     assert float((got - plain).abs().max()) < 3e-2          # (the outputs themselves are rounded to bf16 here)
+
+
+@pytest.mark.parametrize("N,K,resid,gather,relu_a,act,c_half", [(512, 512, 0, 0, 0, 1, 1), (1024, 256, 0, 0, 1, 0, 1), (512, 1024, 0, 0, 0, 0, 0),
+                                                                (256, 512, 1, 0, 0, 1, 0), (1024, 512, 0, 1, 1, 1, 1)])
+def test_gemm_bf16_p8_kernel(lib, N, K, resid, gather, relu_a, act, c_half):
+    """Half-row launches with M >= one full round of 256 x 256 tiles: the 8-phase kernel (gemm_bf16_p8.hip) takes the
+    full rounds, the remaining row panels the older kernels.  Same k order per accumulator as the 128 x 128 kernel; the bias
+    enters first instead of last in the fp32 sum, so results may differ by one rounding of the output format -- checked
+    element by element against the launch that keeps everything on the 128 x 128 kernel (fmt bits 4, 12), and against a
+    plain fp32 reference."""
+    l = lib.load()
+    M = (256 * 256 // (N // 256)) + 256 * 9 + 77            # one full round, nine more panels and a ragged end
+    g = torch.Generator().manual_seed(N + K + resid)
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16).float()
+    Ah = _to_half_rows(A).to(DEV)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    R = torch.randn(M, N, generator=g).to(torch.bfloat16).float()
+    Rh = _to_half_rows(R).to(DEV)
+    NG = 777
+    gbuf = torch.randn(NG, 2 * N, generator=g).to(DEV)
+    gi0 = torch.randint(0, NG, (M,), generator=g, dtype=torch.int32).to(DEV)
+    gi1 = torch.randint(0, NG, (M,), generator=g, dtype=torch.int32).to(DEV)
+    hi = torch.empty(N * K + 128, dtype=torch.int16, device=DEV)
+    lo = torch.empty_like(hi)
+    lib.check(l.vlsat_k_split_bf16(W.data_ptr(), N * K, hi.data_ptr(), lo.data_ptr(), lib.stream_ptr()))
+    fmt = 32 | 1 | (4 if c_half else 0) | (2 if resid else 0)
+
+    def run(f):
+        Cb = torch.full((M, N), float("nan"), device=DEV)
+        lib.check(l.vlsat_k_gemm_planes(Ah.data_ptr(), K, W.data_ptr(), hi.data_ptr(), lo.data_ptr(), K, Cb.data_ptr(), N, M, N, K,
+                                        b.data_ptr(), Rh.data_ptr() if resid else 0, N if resid else 0, 0.5,
+                                        gbuf.data_ptr() if gather else 0, gi0.data_ptr() if gather else 0, 2 * N if gather else 0,
+                                        gbuf.data_ptr() + 4 * N if gather else 0, gi1.data_ptr() if gather else 0, 2 * N if gather else 0,
+                                        relu_a, act, 1, 0, -1, f, 1.0, lib.stream_ptr()))
+        _sync()
+        return (_from_half_rows(Cb.cpu(), N) if c_half else Cb.cpu())
+    got, flat = run(fmt), run(fmt | 16 | (1 << 12))
+    assert torch.isfinite(got).all()
+    d = (got - flat).abs()
+    if c_half:
+        assert bool((d <= 2.0 ** -7 * flat.abs() + 2e-5 * float(flat.abs().max())).all()), float(d.max())   # (one bf16 rounding; near a ReLU zero: fp32 roundoff)
+        assert float((d > 0).float().mean()) < 0.01
+    else:
+        assert float(d.max()) <= 2e-5 * float(flat.abs().max())
+    Af = torch.relu(A) if relu_a else A
+    ref = Af.double() @ W.cpu().to(torch.bfloat16).double().t() + b.cpu().double()
+    if resid:
+        ref = ref + 0.5 * R.double()
+    if gather:
+        ref = ref + gbuf.cpu().double()[gi0.cpu().long(), :N] + gbuf.cpu().double()[gi1.cpu().long(), N:]
+    if act:
+        ref = torch.relu(ref)
+    tol = (2.0 ** -7 if c_half else 1e-4) * float(ref.abs().max())
+    assert float((got.double() - ref).abs().max()) <= tol
 
 
 # ---- split-K kernel of the small launches (gemm_splitk.hip) ---------------------------------------------------------
