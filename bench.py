@@ -91,6 +91,89 @@ def cpu_baseline(cfg, n_obj, n_pts, budget_s=15.0, max_scenes=6):
                       f"{ncpu}-cpu host; torch {torch.__version__} CPU fp32"}, first
 
 
+def roofline_of(classes, mode, steps, falg, value, world, traffic=None, traffic_src=None):
+    """`roofline` object of one timed run: the dominant kernel class by HIP-event time on the launch stream."""
+    if not classes:
+        return None
+    dom = max(classes, key=lambda k: classes[k]["ms"])
+    c = classes[dom]
+    achieved = c["flops"] / (c["ms"] * 1e-3) / 1e12 if c["ms"] > 0 else 0.0
+    peak = MODE_PEAK[mode]
+    total_ms = max(sum(x["ms"] for x in classes.values()), 1e-9)
+    return {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": round(peak, 1),
+            "peak_note": {"fp32": "v_mfma_f32_32x32x2_f32", "bf16x3": "2.5 PF bf16 dense / 3 MFMAs per product",
+                          "bf16": "2.5 PF bf16 dense", "bf16_mixed": "2.5 PF bf16 dense"}[mode],
+            "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+            "traffic_unit": "HBM bytes per launch (PMC)", "traffic_source": traffic_src,
+            "launches_per_step": c["launches"] // steps, "avg_launch_ms": round(c["ms"] / max(c["launches"], 1), 4),
+            "flop_per_launch": c["flops"] / max(c["launches"], 1),
+            "whole_forward_tflops": round(falg * value / world / 1e12, 2),
+            "whole_forward_frac": round(falg * value / world / 1e12 / peak, 4),
+            "time_share": {k: round(v["ms"] / total_ms, 4) for k, v in classes.items()},
+            "class_tflops": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)
+                             for k, v in classes.items() if v["ms"] > 0 and v["flops"] > 0}}
+
+
+def timed_run(model, d, n_scenes, steps, warmup, prof, dev):
+    """W untimed steps, then EXACTLY `steps` steps between barrier + synchronize on both sides; the wall time is the max
+    over ranks.  A step = forward over this rank's batch + the one all-reduce of the metrics vector.  Per-step durations
+    (HIP events on the launch stream, this rank) give the median SURVEY 8(d) asks for next to the mean."""
+    def step():
+        out = model(d["obj_points"], d["obj_2d_feats"], d["edge_indices"], d["descriptor"], d["batch_ids"])
+        return out, vdist.allreduce_metrics(vdist.scene_metrics(out, n_scenes))
+
+    for _ in range(warmup):
+        out, metrics = step()
+    torch.cuda.synchronize()
+    if prof:
+        model.profile_enable(True)
+        model.profile_read()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    vdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev[0].record()
+    for i in range(steps):
+        out, metrics = step()
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    local_dt = time.perf_counter() - t0             # this rank's own time (before it waits for the others)
+    vdist.barrier()
+    dt = vdist.max_over_ranks(time.perf_counter() - t0, dev)
+    classes = model.profile_read() if prof else {}
+    model.profile_enable(False)
+    per_step = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(steps))
+    median = per_step[steps // 2] if steps % 2 else 0.5 * (per_step[steps // 2 - 1] + per_step[steps // 2])
+    return {"dt": dt, "local_ms": local_dt / steps * 1e3, "median_ms": median, "min_ms": per_step[0], "max_ms": per_step[-1],
+            "classes": classes, "out": out, "metrics": metrics}
+
+
+def eval_leg(model, scenes, d, n_obj, dev):
+    """Untimed: the step AFTER the path on this rank's batch with seeded synthetic labels -- forward +
+    GPU ranking + the 487-count vector, all-reduced once (evaluate.validation) -- so the line carries real evaluation
+    metrics next to the checksums.  Labels are random: the accuracies are chance level by construction."""
+    import numpy as np
+    from vlsat_amd import evaluate as EV
+    gts, rels = [], []
+    for s in scenes:
+        g = np.random.default_rng([1000 + s, 77])
+        gts.append(g.integers(0, 160, n_obj))
+        rels.append((g.random((n_obj * (n_obj - 1), 26)) < 0.04).astype(np.int64))
+    b = {"obj_points": d["obj_points"], "obj_2d_feats": d["obj_2d_feats"], "descriptor": d["descriptor"],
+         "batch_ids": d["batch_ids"], "edge_indices": d["edge_indices"].t().contiguous(),
+         "gt_class": torch.from_numpy(np.concatenate(gts)).to(dev), "gt_rel_cls": torch.from_numpy(np.concatenate(rels)).to(dev)}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    summ = EV.validation(model, [b], dev)
+    torch.cuda.synchronize()
+    keep = ("scenes", "obj_acc@1_3d", "obj_acc@5_3d", "rel_acc@1_3d", "rel_acc@3_3d", "tri_acc@50_3d", "tri_acc@100_3d",
+            "mean_recall@50_3d", "obj_acc@1_2d", "rel_acc@1_2d", "tri_acc@50_2d", "mean_recall@50_2d")
+    return {"what": "forward + GPU ranking (process_val) + counts vector of evaluate.validation, one all-reduce; synthetic random "
+                    "labels (chance-level accuracies), outside the timed region",
+            "n_counts": len(EV.fields()), "ms_forward_plus_ranking": round((time.perf_counter() - t0) * 1e3, 2),
+            "metrics": {k: round(float(summ[k]), 4) for k in keep if k in summ}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -102,6 +185,9 @@ def main():
     ap.add_argument("--layers", type=int, default=3)
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="headline configuration only: skip the extra_configs legs (BASELINE configs[2] modes and configs[4]) "
+                         "and the evaluation leg")
     ap.add_argument("--native-allreduce", action="store_true",
                     help="sum the metrics vector with the library's own RCCL entry point (vlsat_metrics_allreduce) "
                          "instead of torch.distributed.all_reduce")
@@ -138,29 +224,15 @@ def main():
     batch = synth.collate([synth.make_scene(args.objects, args.points, 1000 + s) for s in scenes])
     d = {k: torch.from_numpy(v).to(dev) for k, v in batch.items()}
     n_scenes = len(scenes)
-
-    def step():
-        out = model(d["obj_points"], d["obj_2d_feats"], d["edge_indices"], d["descriptor"], d["batch_ids"])
-        m = vdist.allreduce_metrics(vdist.scene_metrics(out, n_scenes))
-        return out, m
-
-    for _ in range(args.warmup):
-        out, metrics = step()
-    torch.cuda.synchronize()
     prof = not args.no_profile
-    if prof:
-        model.profile_enable(True)
-        model.profile_read()
-    vdist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out, metrics = step()
-    torch.cuda.synchronize()
-    vdist.barrier()
-    dt = vdist.max_over_ranks(time.perf_counter() - t0, dev)
-    classes = model.profile_read() if prof else {}
-    model.profile_enable(False)
+
+    run = timed_run(model, d, n_scenes, args.steps, args.warmup, prof, dev)
+    dt, out, metrics, classes = run["dt"], run["out"], run["metrics"], run["classes"]
+    rank_ms = vdist.minmax_over_ranks(run["local_ms"], dev)
+    default_wl = (args.scenes, args.objects, args.points, args.layers) == (64, 40, 256, 3)
+    evaluation = None
+    if not args.no_extra:                                # a collective: every rank takes part
+        evaluation = eval_leg(model, list(scenes), d, args.objects, dev)
 
     if rank != 0:
         return
@@ -172,11 +244,7 @@ def main():
     roofline = None
     if classes:
         dom = max(classes, key=lambda k: classes[k]["ms"])
-        c = classes[dom]
-        avg_ms = c["ms"] / max(c["launches"], 1)
-        achieved = c["flops"] / (c["ms"] * 1e-3) / 1e12 if c["ms"] > 0 else 0.0
         traffic, traffic_src = None, None
-        default_wl = (args.scenes, args.objects, args.points, args.layers) == (64, 40, 256, 3)
         tag = {"fp32": "_bench_pmc.json", "bf16x3": "_cfg3_bf16x3_pmc.json", "bf16_mixed": "_cfg3_bf16_mixed_pmc.json"}.get(args.gemm_precision, "_none_")
         pmc = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith(tag)) \
             if os.path.isdir(os.path.join(ROOT, "profiles")) else []
@@ -189,43 +257,73 @@ def main():
                 traffic_src = "profiles/" + pmc[-1]
             except Exception:
                 traffic = None
-        peak = MODE_PEAK[args.gemm_precision]
-        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": round(peak, 1),
-                    "peak_note": {"fp32": "v_mfma_f32_32x32x2_f32", "bf16x3": "2.5 PF bf16 dense / 3 MFMAs per product",
-                                  "bf16": "2.5 PF bf16 dense", "bf16_mixed": "2.5 PF bf16 dense"}[args.gemm_precision],
-                    "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
-                    "traffic_unit": "HBM bytes per launch (PMC)", "traffic_source": traffic_src,
-                    "launches_per_step": c["launches"] // args.steps, "avg_launch_ms": round(avg_ms, 4),
-                    "flop_per_launch": c["flops"] / max(c["launches"], 1),
-                    "whole_forward_tflops": round(falg * value / world / 1e12, 2),
-                    "whole_forward_frac": round(falg * value / world / 1e12 / peak, 4),
-                    "time_share": {k: round(v["ms"] / max(sum(x["ms"] for x in classes.values()), 1e-9), 4)
-                                   for k, v in classes.items()},
-                    "class_tflops": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)
-                                     for k, v in classes.items() if v["ms"] > 0 and v["flops"] > 0}}
+        roofline = roofline_of(classes, args.gemm_precision, args.steps, falg, value, world, traffic, traffic_src)
 
-    cpu, err = None, None
+    cpu, err, ref = None, None, None
     if world == 1 and not args.no_cpu:
         cpu, _ = cpu_baseline(cfg, args.objects, args.points)
         ref = oracle_all_scenes(cfg, batch, cpu["cores"])
         err = {k: float((g.cpu() - r).abs().max()) for k, g, r in zip(("obj3d", "obj2d", "rel3d", "rel2d"), out, ref)}
         err["scenes_checked"] = f"{n_scenes}/{n_scenes}"
 
+    # ---- BASELINE configs[2] (bf16 matrix cores, same batch) and configs[4] (200 x 1024 stress scene) in the same line ----
+    extra = []
+    if world == 1 and not args.no_extra and default_wl and args.gemm_precision == "fp32":
+        names = ("obj3d", "obj2d", "rel3d", "rel2d")
+        for mode in ("bf16x3", "bf16_mixed"):
+            model.set_gemm_precision(mode)
+            r = timed_run(model, d, n_scenes, args.steps, args.warmup, prof, dev)
+            v = n_scenes * args.steps / r["dt"]
+            e = None
+            if ref is not None:
+                e = {k: float((g.cpu() - x).abs().max()) for k, g, x in zip(names, r["out"], ref)}
+                e["scenes_checked"] = f"{n_scenes}/{n_scenes}"
+            extra.append({"workload": f"BASELINE configs[2]: 64 scenes x 40 objects x 256 pts, L=3, {mode}", "dtype": MODE_DTYPE[mode],
+                          "tolerance": 1e-2, "value": round(v, 2), "unit": "scenes/s", "ms_per_step": round(r["dt"] / args.steps * 1e3, 3),
+                          "median_ms_per_step": round(r["median_ms"], 3), "steps": args.steps, "max_abs_err_vs_cpu_oracle": e,
+                          "roofline": roofline_of(r["classes"], mode, args.steps, falg, v, 1)})
+        big = synth.make_batch(1, 200, 1024, seed0=5000)
+        db = {k: torch.from_numpy(v).to(dev) for k, v in big.items()}
+        falg5 = f_alg(200, 1024, 200 * 199, args.layers)
+        gold = os.path.join(ROOT, "tests", "golden", "cfg5_n200_p1024_l3_sub.npz")
+        for mode in ("fp32", "bf16_mixed"):
+            model.set_gemm_precision(mode)
+            r = timed_run(model, db, 1, 5, 2, prof, dev)
+            v = 5 / r["dt"]
+            e = None
+            if os.path.exists(gold):                 # committed oracle subsample of this very scene (tests/golden/make_golden_cfg5.py)
+                import numpy as np
+                z = np.load(gold)
+                idx = torch.from_numpy(z["edge_idx"])
+                got = [r["out"][0].cpu(), r["out"][1].cpu(), r["out"][2].cpu()[idx], r["out"][3].cpu()[idx]]
+                e = {k: float((g - torch.from_numpy(z[k])).abs().max()) for k, g in zip(names, got)}
+                e["checked"] = f"all 200 objects, {len(idx)} of 39800 edges (committed oracle subsample)"
+            extra.append({"workload": f"BASELINE configs[4]: 1 scene x 200 objects x 1024 pts, dense graph E=39800, L=3, {mode}",
+                          "dtype": MODE_DTYPE[mode], "tolerance": 1e-3 if mode == "fp32" else 1e-2, "value": round(v, 2), "unit": "scenes/s",
+                          "ms_per_step": round(r["dt"] / 5 * 1e3, 3), "median_ms_per_step": round(r["median_ms"], 3), "steps": 5,
+                          "max_abs_err_vs_cpu_oracle": e, "flop_per_scene_alg": falg5,
+                          "roofline": roofline_of(r["classes"], mode, 5, falg5, v, 1)})
+        model.set_gemm_precision(args.gemm_precision)
+
     line = {
         "metric": "scenes/sec (3RScan-shaped, N=40 obj x 256 pts)", "value": round(value, 2), "unit": "scenes/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "median_ms_per_step": round(run["median_ms"], 3), "step_ms_min_max": [round(run["min_ms"], 3), round(run["max_ms"], 3)],
+        "rank_ms_per_step_min_max": [round(rank_ms[0], 3), round(rank_ms[1], 3)],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": MODE_DTYPE[args.gemm_precision],
         "data": "synthetic",
-        "config": {"workload": f"{('BASELINE configs[1]' if args.gemm_precision == 'fp32' else 'BASELINE configs[2]') if (args.scenes, args.objects, args.points, args.layers) == (64, 40, 256, 3) else 'custom'}: batch of {args.scenes} synthetic scenes per GPU, "
+        "config": {"workload": f"{('BASELINE configs[1]' if args.gemm_precision == 'fp32' else 'BASELINE configs[2]') if default_wl else 'custom'}: batch of {args.scenes} synthetic scenes per GPU, "
                                f"{args.objects} objects x {args.points} pts, fully-connected edges "
                                f"(E={e_scene}/scene), {args.layers} GNN layers, {args.gemm_precision}",
                    "scenes_per_gpu": args.scenes, "parallelism": f"scene-sharded x{world}"},
         "flop_per_scene_alg": falg,
         "metrics_allreduced": {k: float(v) for k, v in zip(vdist.METRIC_FIELDS, metrics.tolist())},
         "allreduce": "vlsat_metrics_allreduce (RCCL via the C ABI)" if args.native_allreduce else "torch.distributed.all_reduce",
+        "evaluation": evaluation,
         "roofline": roofline, "cpu_baseline": cpu, "max_abs_err_vs_cpu_oracle": err,
         "speedup_vs_cpu": round(value / cpu["value"], 1) if cpu else None,
+        "extra_configs": extra or None,
     }
     print(json.dumps(line))
 

@@ -4,11 +4,12 @@
 // going through a Python framework: bootstrap as usual (rank 0 makes a unique id, the host shares its 128 bytes with the
 // other ranks by any means -- a file, a pipe, torch.distributed -- and every rank joins with vlsat_comm_init on its own GPU).
 //
-// RCCL is resolved at run time: if the process already carries one (PyTorch ships its own librccl.so) that copy is
-// used, so there are never two RCCL instances in a process; otherwise librccl.so.1 is loaded from the ROCm library path.
-// libvlsat_hip.so therefore has no link-time dependency on RCCL and single-GPU users never load it.
+// RCCL is resolved at run time, in this order: (1) symbols already visible to the process (RTLD_DEFAULT), (2) a copy that
+// is already MAPPED but was loaded RTLD_LOCAL -- how Python extension modules load PyTorch's librccl.so -- picked up with
+// dlopen(..., RTLD_NOLOAD), so that a process never ends up with two RCCL instances, (3) librccl.so.1 from the loader path.
+// The few prototypes used are declared here (they are RCCL's stable C ABI): the library has neither a link-time nor a
+// build-time dependency on RCCL, and single-GPU users never load it.
 #include <dlfcn.h>
-#include <rccl/rccl.h>
 
 #include <cstring>
 #include <mutex>
@@ -19,10 +20,18 @@
 
 namespace {
 
+// RCCL C ABI (rccl.h): opaque communicator, 128-byte unique id, result / datatype / reduction codes
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef int ncclResult_t;
+constexpr ncclResult_t ncclSuccess = 0;
+constexpr int ncclDouble = 8;        // ncclFloat64
+constexpr int ncclSum = 0;
+
 struct Rccl {
     ncclResult_t (*get_unique_id)(ncclUniqueId*) = nullptr;
     ncclResult_t (*comm_init_rank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
-    ncclResult_t (*all_reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*all_reduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*comm_destroy)(ncclComm_t) = nullptr;
     const char* (*error_string)(ncclResult_t) = nullptr;
     bool ok = false;
@@ -33,10 +42,13 @@ Rccl& rccl() {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
-        void* lib = RTLD_DEFAULT;                                    // an RCCL the process already loaded (PyTorch's) wins
+        void* lib = RTLD_DEFAULT;
         if (!dlsym(RTLD_DEFAULT, "ncclAllReduce")) {
-            lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-            if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+            lib = nullptr;
+            for (const char* name : {"librccl.so", "librccl.so.1"})          // already mapped (RTLD_LOCAL)? use that copy
+                if (!lib) lib = dlopen(name, RTLD_NOLOAD | RTLD_NOW);
+            for (const char* name : {"librccl.so.1", "librccl.so"})
+                if (!lib) lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (!lib) { r.why = std::string("RCCL not found: ") + dlerror(); return; }
         }
         r.get_unique_id = reinterpret_cast<decltype(r.get_unique_id)>(dlsym(lib, "ncclGetUniqueId"));
@@ -81,7 +93,8 @@ int vlsat_comm_init(const void* id128, int32_t n_ranks, int32_t rank, void** com
     return 0;
 }
 
-// buf (device, fp64[n]) <- sum over ranks, in place, asynchronous on `stream`
+// buf (device, fp64[n]) <- sum over ranks, in place, asynchronous on `stream`.  A collective: EVERY rank of the
+// communicator must call it with the same n (n == 0 returns without entering the collective -- on every rank or on none).
 int vlsat_metrics_allreduce(void* comm, double* buf, int32_t n, void* stream) {
     if (!comm || !buf || n < 0) return vlsat::fail(VLSAT_EINVAL, "metrics_allreduce: bad argument");
     if (n == 0) return 0;

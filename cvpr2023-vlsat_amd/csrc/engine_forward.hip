@@ -254,11 +254,42 @@ struct TrainOut { float *mimic3d, *mimic2d, *edge_dis; };
 
 // capture: the call is being recorded into a hipGraph (vlsat_forward_graph): nothing that touches events owned by the plan
 // or queries the device may happen in here then -- the caller has done the upload wait and records last_use itself.
+static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const float* f2d, const float* desc,
+                        float* obj3d, float* obj2d, float* rel3d, float* rel2d, const TrainOut* tr, void* stream,
+                        bool capture);
+
+// A forward that fails half way has already enqueued kernels on the plan's arena (possibly on the side stream too): every
+// exit path joins the side stream into the caller's and records the plan's last-use event, so that vlsat_plan_destroy never
+// recycles the arena behind a stale or never-recorded event (the contract of vlsat.h).
 static int forward_impl(vlsat_handle h, vlsat_plan p, const float* pts, const float* f2d, const float* desc,
                         float* obj3d, float* obj2d, float* rel3d, float* rel2d, const TrainOut* tr, void* stream,
                         bool capture = false) {
+    const int rc = forward_body(h, p, pts, f2d, desc, obj3d, obj2d, rel3d, rel2d, tr, stream, capture);
+    if (rc != 0 && !capture && h && p && p->h == h && p->used) {
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        const std::string msg = last_error_cstr();                    // (the calls below must not replace the real error)
+        if (h->side && p->dual) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess) {
+                hipEventRecord(e, h->side);
+                hipStreamWaitEvent(s, e, 0);
+                hipEventDestroy(e);                                   // (destruction is deferred until the event completes)
+            }
+        }
+        h->open_ok = false;                                           // a profiling interval left open is dropped
+        hipEventRecord(p->last_use, s);
+        set_error(msg);
+    }
+    return rc;
+}
+
+static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const float* f2d, const float* desc,
+                        float* obj3d, float* obj2d, float* rel3d, float* rel2d, const TrainOut* tr, void* stream,
+                        bool capture) {
     if (!h || !p || !pts || !desc || !obj3d) return fail(VLSAT_EINVAL, "vlsat_forward: null argument");
     if (p->h != h) return fail(VLSAT_EINVAL, "plan belongs to a different handle");
+    // a weight reload is open (vlsat_load_weight after a finalize freed the device weights): nothing may launch on them
+    if (!h->finalized) return fail(VLSAT_ESTATE, "vlsat_forward: weights are not finalised (a reload is in progress or failed)");
     // 3D-only mode: both 2D outputs NULL -> the 2D branch (adapter, cross-attention, gcn_2ds, edge
     // cross-attention, 2D heads) is skipped.  Exact: the 3D branch never reads 2D tensors.
     const bool do2d = obj2d != nullptr || rel2d != nullptr;
@@ -496,6 +527,10 @@ int vlsat_forward_train(vlsat_handle h, vlsat_plan p, const float* pts, const fl
 int vlsat_forward_graph(vlsat_handle h, vlsat_plan p, const float* pts, const float* f2d, const float* desc,
                         float* obj3d, float* obj2d, float* rel3d, float* rel2d, void* stream) {
     if (!h || !p) return fail(VLSAT_EINVAL, "vlsat_forward_graph: null argument");
+    if (!h->finalized) {                    // (a captured graph holds the freed weight pointers: drop it as well)
+        if (p->graph_exec) { hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }
+        return fail(VLSAT_ESTATE, "vlsat_forward_graph: weights are not finalised (a reload is in progress or failed)");
+    }
     if (h->prof || h->debug_stop >= 0) return forward_impl(h, p, pts, f2d, desc, obj3d, obj2d, rel3d, rel2d, nullptr, stream);
     if (!stream) return fail(VLSAT_EINVAL, "vlsat_forward_graph: the NULL stream cannot be captured; pass a created stream");
     hipStream_t s = static_cast<hipStream_t>(stream);

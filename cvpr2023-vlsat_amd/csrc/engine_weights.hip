@@ -237,8 +237,9 @@ int vlsat_create(const VlsatDims* d, vlsat_handle* out) {
     // built for d_k = 512 / H in {32, 64, 128}.  8 x 256 (shipped) takes the MFMA gate / attention kernels, anything
     // else the generic ones.
     if (d->n_heads != 4 && d->n_heads != 8 && d->n_heads != 16) return fail(VLSAT_EINVAL, "NUM_HEADS must be 4, 8 or 16");
-    if (d->dim_atten < d->n_heads || d->dim_atten > 512 || d->dim_atten % (4 * d->n_heads))
-        return fail(VLSAT_EINVAL, "DIM_ATTEN must be a multiple of 4 * NUM_HEADS, at most 512");
+    // (the prop GEMMs have K = 512 + DIM_ATTEN and every GEMM kernel needs K % 32 == 0: checked here, not in the first forward)
+    if (d->dim_atten < d->n_heads || d->dim_atten > 512 || d->dim_atten % (4 * d->n_heads) || d->dim_atten % 32)
+        return fail(VLSAT_EINVAL, "DIM_ATTEN must be a multiple of 32 and of 4 * NUM_HEADS, at most 512");
     if (d->gcn_aggr < 0 || d->gcn_aggr > 2) return fail(VLSAT_EINVAL, "gcn_aggr must be 0 (max), 1 (add) or 2 (mean)");
     if (d->dim_point != 3 && d->dim_point != 6 && d->dim_point != 9)
         return fail(VLSAT_EINVAL, "dim_point must be 3, 6 or 9 (xyz [+ USE_RGB] [+ USE_NORMAL])");
@@ -432,6 +433,8 @@ int vlsat_finalize_weights(vlsat_handle h) {
         VLSAT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->sk_ws[i]), SPLITK_WS_FLOATS * sizeof(float)));
         VLSAT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->sk_cnt[i]), SPLITK_COUNTERS * sizeof(unsigned)));
         VLSAT_HIP_CHECK(hipMemset(h->sk_cnt[i], 0, SPLITK_COUNTERS * sizeof(unsigned)));
+        // (the NULL-stream memset is not ordered against a caller's non-blocking stream: the first forward must see zeros)
+        VLSAT_HIP_CHECK(hipDeviceSynchronize());
     }
     return 0;
 }

@@ -136,3 +136,14 @@ def max_over_ranks(x: float, device) -> float:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
     return x
+
+
+def minmax_over_ranks(x: float, device):
+    """(min, max) of a per-rank scalar: bench.py reports the spread of the ranks' step times."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dv = "cpu" if dist.get_backend() == "gloo" else device
+        lo, hi = torch.tensor([x], dtype=torch.float64, device=dv), torch.tensor([x], dtype=torch.float64, device=dv)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        return float(lo.item()), float(hi.item())
+    return x, x

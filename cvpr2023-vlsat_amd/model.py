@@ -145,16 +145,22 @@ class VLSATModel:
         missing = [k for k in want if k not in weights]
         if missing and strict:
             raise L.VlsatError(f"missing {len(missing)} weights, first: {missing[0]}")
+        # every shape is checked BEFORE the first upload: the first vlsat_load_weight on a finalised handle frees the
+        # device weights, so a reload that fails half way must not be started for a reason known in advance
+        host = {}
+        for k, shape in want.items():
+            if k not in weights:
+                continue
+            v = weights[k]
+            if torch.is_tensor(v):
+                v = v.detach().cpu().numpy()
+            v = np.ascontiguousarray(v, dtype=np.float32)
+            if tuple(v.shape) != tuple(shape):
+                raise L.VlsatError(f"weight {k}: shape {v.shape}, expected {shape}")
+            host[k] = v
+        self._loaded = False                    # until the finalize below succeeds, forward() refuses to run
         with torch.cuda.device(self.device):
-            for k, shape in want.items():
-                if k not in weights:
-                    continue
-                v = weights[k]
-                if torch.is_tensor(v):
-                    v = v.detach().cpu().numpy()
-                v = np.ascontiguousarray(v, dtype=np.float32)
-                if tuple(v.shape) != tuple(shape):
-                    raise L.VlsatError(f"weight {k}: shape {v.shape}, expected {shape}")
+            for k, v in host.items():
                 L.check(self._lib.vlsat_load_weight(self._h, k.encode(), v.ctypes.data, v.size))
             L.check(self._lib.vlsat_finalize_weights(self._h))
         self._loaded = True
@@ -195,7 +201,9 @@ class VLSATModel:
     def _plan(self, edge_indices, batch_ids, n, p, fc_sizes: Optional[Sequence[int]] = None) -> _Plan:
         """Plan for this graph, from a content-keyed LRU cache.  In order of cost:
           1. ``fc_sizes`` given: the caller states that edge_indices IS the canonical fully-connected edge list of
-             scenes with these object counts -> key (sizes, P); nothing is read from the device;
+             scenes with these object counts (source-major, ``synth.fc_edges`` order) -> key (sizes, P); nothing is read
+             from the device.  Host-side edge tensors are compared with the canonical list; device tensors are taken
+             on trust (UNCHECKED: a different order would attribute every rel_cls row to the wrong edge);
           2. the same tensor OBJECTS as an earlier call, unmodified -> no copy either;
           3. edge_indices / batch_ids on the host (the reference's loader yields them there) -> hashed on the host;
           4. device tensors never seen before -> one D2H copy (a stream sync) to hash them.
@@ -214,6 +222,9 @@ class VLSATModel:
             if sum(sizes) != n or edge_indices.shape[1] != sum(k * (k - 1) for k in sizes):
                 raise L.VlsatError("fc_sizes does not match the node / edge counts")
             key = ("fc", sizes, p, self.batch_mode)
+            if not edge_indices.is_cuda and key not in self._plans:      # free to verify on the host, once per key
+                if not torch.equal(edge_indices.contiguous(), self._fc_host(sizes)[0]):
+                    raise L.VlsatError("fc_sizes: edge_indices is not the canonical fully-connected edge list of these scenes")
         else:
             ik = (id(edge_indices), id(batch_ids))
             hit = self._ident.get(ik)
@@ -229,8 +240,14 @@ class VLSATModel:
                 self.plan_stats["d2h_copies"] += 1
             ei = edge_indices.detach().cpu().contiguous()
             bid = batch_ids.detach().view(-1).cpu().contiguous()
-            # scene ids only matter through the partition they induce: hash the run lengths, not the values
+            # scene ids only matter through the partition they induce: hash the run lengths, not the values -- after checking
+            # that no id comes back in a later run ([0,1,0] has the cuts of [0,1,2] but is not a valid batch: an uncached call
+            # fails with "nodes of a scene must be contiguous", and so must a cached one)
             cuts = torch.nonzero(bid[1:] != bid[:-1]).view(-1).numpy() if n > 1 else np.zeros(0, np.int64)
+            if len(cuts):
+                runs = bid[np.concatenate([[0], cuts + 1])].numpy()
+                if len(np.unique(runs)) != len(runs):
+                    raise L.VlsatError("batch_ids: the nodes of a scene must be contiguous (a scene id appears in two runs)")
             hsh = hashlib.blake2b(digest_size=16)
             hsh.update(np.ascontiguousarray(cuts).tobytes())
             hsh.update(ei.numpy().tobytes())

@@ -446,7 +446,7 @@ def test_cfg3_full_batch_all_scenes(bench_batch_oracle, mode, tol):
         assert float(per.max()) < tol, f"{mode}: scenes over {tol}: {torch.nonzero(per >= tol).view(-1).tolist()}"
         # the same with every experiment switch of the bf16 modes turned off one at a time (fp32 tensors between the
         # kernels, fp32 attention, gather instead of the LDS transpose read): same contract
-        for opt in ("split_fmt", "flash_tr", "flash_bf16", "pointnet_bf16", "gate_bf16", "ln_resid", "gemm_splitk"):
+        for opt in ("split_fmt", "flash_tr", "flash_bf16", "pointnet_bf16", "gate_bf16", "ln_resid", "gemm_splitk", "gemm_p8"):
             m.debug_option(opt, 0)
             alt = [o.cpu() for o in m(d["obj_points"], d["obj_2d_feats"], d["edge_indices"], d["descriptor"], d["batch_ids"])]
             pa = _per_scene_err(alt, ref, S, N, E)

@@ -14,9 +14,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _bench(n_ranks, scenes_per_rank, port):
-    env = dict(os.environ, VLSAT_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    tail = ["bench.py", "--gpus", str(n_ranks), "--steps", "2", "--warmup", "1", "--no-cpu", "--scenes", str(scenes_per_rank)]
+def _bench(n_ranks, scenes_per_rank, port, backend="gloo", extra=()):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if backend:
+        env["VLSAT_DIST_BACKEND"] = backend
+    else:
+        env.pop("VLSAT_DIST_BACKEND", None)
+    tail = ["bench.py", "--gpus", str(n_ranks), "--steps", "2", "--warmup", "1", "--no-cpu", "--scenes", str(scenes_per_rank)] + list(extra)
     if n_ranks == 1:
         cmd = [sys.executable] + tail
     else:
@@ -42,3 +46,24 @@ def test_two_ranks_on_one_gpu_reproduce_the_single_process_metrics():
         assert abs(a[k] - b[k]) <= 1e-3 * max(1.0, abs(b[k])), (k, a[k], b[k])
     for k in ("top1_agree_obj", "top1_agree_rel"):
         assert abs(a[k] - b[k]) <= 2, (k, a[k], b[k])
+
+
+def test_two_gpus_over_rccl_native_allreduce():
+    """The run the driver launches on a multi-GPU node, at N = 2: one rank per GPU, RCCL for torch.distributed AND for the
+    library's own collective (bench.py --native-allreduce -> vlsat_metrics_allreduce on a 2-rank communicator).  Needs two
+    GPUs: on the one-GPU test box this SKIPS -- loudly, because it means RCCL has still only ever seen one rank here
+    (tests/test_hip_round2.py::test_native_rccl_allreduce_single_rank)."""
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: the HIP path cannot run and there is no fallback")
+    if torch.cuda.device_count() < 2:
+        pytest.skip(f"ONLY {torch.cuda.device_count()} GPU VISIBLE: the 2-rank RCCL all-reduce over xGMI was NOT exercised")
+    two = _bench(2, 8, 29641, backend="", extra=["--native-allreduce"])
+    one = _bench(1, 16, 0)
+    assert two["n_gpus"] == 2 and two["allreduce"].startswith("vlsat_metrics_allreduce")
+    lo, hi = two["rank_ms_per_step_min_max"]
+    assert 0 < lo <= hi
+    a, b = two["metrics_allreduced"], one["metrics_allreduced"]
+    assert a["scenes"] == 16 and a["nodes"] == b["nodes"] and a["edges"] == b["edges"]
+    for k in ("sum_obj3d", "sum_obj2d", "sum_rel3d", "sum_rel2d"):
+        assert abs(a[k] - b[k]) <= 1e-3 * max(1.0, abs(b[k])), (k, a[k], b[k])
+    assert two["evaluation"]["metrics"]["scenes"] == 16
