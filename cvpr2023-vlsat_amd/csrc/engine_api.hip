@@ -95,6 +95,7 @@ int vlsat_k_gemm(const float* A, int32_t lda, const float* W, int32_t ldw, float
     a.g0 = g0; a.gi0 = gi0; a.ldg0 = ldg0; a.g1 = g1; a.gi1 = gi1; a.ldg1 = ldg1; a.relu_a = relu_a & 1; a.act = act;
     if (relu_a & 2) a.prefetch = 0;             // (bit 1 of relu_a: no A-panel prefetch -- benchmarking)
     if (relu_a & 4) RUN(test_splitk_ws(a));     // (bit 2: small launches may take the split-K kernel)
+    if (relu_a & 8) a.no_p8 = 1;                // (bit 3: large launches stay off the 256 x 256 8-phase kernel)
     return launch_gemm(a, static_cast<hipStream_t>(stream));
 }
 

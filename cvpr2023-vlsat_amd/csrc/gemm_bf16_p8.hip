@@ -56,8 +56,13 @@ enum { P8_MID = 0, P8_LAST = 1, P8_FIRST = 2, P8_SECOND = 3, P8_FIRST0 = 4 };   
 
 // CF: storage format of C (0 fp32, 2 half rows).  ABL (timing experiments, results are garbage): bit 0 no LDS-direct
 // loads after the prologue, bit 1 no MFMAs, bit 2 no fragment reads, bit 3 no epilogue stores
-template <int ADD, bool RELU, int CF, int ABL = 0>
+// F32: exact-fp32 operands (A fp32 rows, W fp32 [N,K], v_mfma_f32_32x32x2_f32, K-tiles of 32): the same LDS image -- 128-byte
+// rows, a lane's fragment is the 16-byte chunk 2 ks + hi = four consecutive k (gemm_core.h, K-permutation trick) -- so
+// loader, phases, waits and epilogue are shared; a phase is 32 MFMAs of 64 cycles there.  Bias then joins after the
+// transposition (8 registers per lane; same fp32 operation order as gemm_f32.hip: bit-identical results).
+template <bool F32, int ADD, bool RELU, int CF, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmArgs p, int n_tiles, int nbn) {
+    static_assert(!F32 || CF == 0, "fp32 operands: fp32 output");
     __shared__ __attribute__((aligned(16))) char smem[10 * P8_HALF];
     typedef short s16x8 __attribute__((ext_vector_type(8)));
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -70,19 +75,20 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmArgs p, int n_tiles
     const int wr = wave >> 2, wc = wave & 3;
     const int li = lane & 31, hi = lane >> 5;
     const int g8 = gridDim.x >> 3, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int KT = p.K / P8_BK;
+    const int KT = p.K / (F32 ? 32 : P8_BK);           // K-tiles of 128 bytes per operand row
     auto tile_of_round = [&](int r) { return (r * 8 + xcd) * g8 + slot; };
     if (tile_of_round(0) >= n_tiles) return;
 
     // ---- LDS-direct loader: lane constants (a wave instruction fills 8 rows x 128 bytes) ----
     const int srow = wave * 8 + (lane >> 3);                                   // LDS row inside a 64-row round
     const unsigned schunk = (unsigned)((lane & 7) ^ ((srow >> 1) & 7));          // logical chunk this lane fetches
-    const unsigned lda4 = (unsigned)p.lda * 4u, ldw2 = (unsigned)p.ldw * 2u;
+    constexpr unsigned EB = F32 ? 4u : 2u;                                     // bytes per operand element
+    const unsigned lda4 = (unsigned)p.lda * 4u, ldw2 = (unsigned)p.ldw * EB;     // row pitches in bytes (half rows keep the fp32 pitch)
     const unsigned vA = (unsigned)srow * lda4 + schunk * 16u;
     const unsigned vW = (unsigned)((wave >> 2) * 64 + (wave & 3) * 8 + (lane >> 3)) * ldw2 + schunk * 16u;
-    const int na = (int)((size_t)(p.M - 1) * lda4 + (size_t)p.K * 2), nw = (int)(((size_t)(p.N - 1) * p.ldw + p.K) * 2);
+    const int na = (int)((size_t)(p.M - 1) * lda4 + (size_t)p.K * EB), nw = (int)(((size_t)(p.N - 1) * p.ldw + p.K) * EB);
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, na, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.Whi), 0, nw, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(F32 ? (void*)const_cast<float*>(p.W) : (void*)const_cast<uint16_t*>(p.Whi), 0, nw, 0x00020000);
     char* const sdst = smem + wave * 1024;
     // two wave instructions = one half-tile: rows 0..63 and 64..127 of it
     auto ld2 = [&](const __amdgpu_buffer_rsrc_t& r, char* dst, unsigned v, unsigned s0, unsigned step) {
@@ -155,13 +161,14 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmArgs p, int n_tiles
     };
 
     f32x16 acc[4][2];
-    // The bias enters as ONE EXTRA k-step at the start of a tile: W' = [b_hi b_mid b_lo 0 ...] (the fp32 bias as three bf16
-    // terms: their fp32 sum is exact) against A' = [1 1 1 0 ...] -- 8 MFMAs per tile instead of 128 bias registers or adds
-    // per lane, and it replaces zeroing the accumulators.  The block's columns never change (the launcher makes the tile
-    // order keep n0 per block), so the two operand registers sets live for the whole kernel.
+    // bf16: the bias enters as ONE EXTRA k-step at the start of a tile: W' = [b_hi b_mid b_lo 0 ...] (the fp32 bias as three
+    // bf16 terms: their fp32 sum is exact) against A' = [1 1 1 0 ...] -- 8 MFMAs per tile instead of 128 bias registers or
+    // adds per lane, and it replaces zeroing the accumulators.  The block's columns never change (the launcher makes the tile
+    // order keep n0 per block), so the two operand register sets live for the whole kernel.
     const int n0 = (tile_of_round(0) % nbn) * P8_BN;
     bf16x8 wb[2], ones;
-    {
+    f32x4 biasr[2];                               // fp32: the lane's bias values in the layout AFTER the transposition
+    if (!F32) {
         const __bf16 z = (__bf16)0.f, o = hi ? z : (__bf16)1.f;
         ones = bf16x8{o, o, o, z, z, z, z, z};
 #pragma unroll
@@ -174,27 +181,48 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmArgs p, int n_tiles
             wb[tn] = bf16x8{b0, b1, b2, z, z, z, z, z};
             asm volatile("" : "+v"(wb[tn]));     // landed before the pipeline starts: no compiler-inserted wait inside it
         }
+    } else {
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            biasr[tn] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n0 + (wc * 2 + tn) * 32 + 4 * (lane & 7)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            asm volatile("" : "+v"(biasr[tn]));
+        }
     }
     // quadrant (ah, bh): 2 m-tiles x 1 n-tile x 4 k-steps; INIT: first k-tile of an output tile
     auto mma = [&](int ah, int bh, const bf16x8 (&w)[4], auto initc) {
         constexpr bool INIT = decltype(initc)::value;
         if (ABL & 2) return;
         if (!(ABL & 128)) __builtin_amdgcn_s_setprio(1);
-        if (INIT) {
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (F32) {
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                const f32x16 c0 = ADD != 0 ? acc[2 * ah + mt][bh] : f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                acc[2 * ah + mt][bh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[bh], ones, c0, 0, 0, 0);
+            for (int ks = 0; ks < 4; ++ks) {
+                const f32x4 wf = __builtin_bit_cast(f32x4, w[ks]);
+#pragma unroll
+                for (int sft = 0; sft < 4; ++sft)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        float a = __builtin_bit_cast(f32x4, af[mt][ks])[sft];
+                        if (RELU) a = fmaxf(a, 0.f);
+                        const f32x16 c0 = (INIT && ADD == 0 && ks == 0 && sft == 0) ? zero : acc[2 * ah + mt][bh];
+                        acc[2 * ah + mt][bh] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[sft], a, c0, 0, 0, 0);
+                    }
             }
+        } else {
+            if (INIT) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    acc[2 * ah + mt][bh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[bh], ones, ADD != 0 ? acc[2 * ah + mt][bh] : zero, 0, 0, 0);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    bf16x8 a = af[mt][ks];
+                    if (RELU) a = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, a), s16x8{0, 0, 0, 0, 0, 0, 0, 0}));
+                    acc[2 * ah + mt][bh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ks], a, acc[2 * ah + mt][bh], 0, 0, 0);
+                }
         }
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                bf16x8 a = af[mt][ks];
-                if (RELU) a = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, a), s16x8{0, 0, 0, 0, 0, 0, 0, 0}));
-                acc[2 * ah + mt][bh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ks], a, acc[2 * ah + mt][bh], 0, 0, 0);
-            }
         if (!(ABL & 128)) __builtin_amdgcn_s_setprio(0);
         eat();
     };
@@ -221,8 +249,10 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmArgs p, int n_tiles
                 f32x4 v;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) v[c] = acc[TM][tn][4 * g + c];
+                if (!F32) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], act_lo) * cs;      // (branch-free: ReLU or max with -inf)
+                    for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], act_lo) * cs;      // (branch-free: ReLU or max with -inf)
+                }
                 if (CF == 2) {
                     u32x2 w;
                     w.x = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v[0]) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)v[1]) << 16);
@@ -235,7 +265,13 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmArgs p, int n_tiles
             if (CF != 2 || tn == 1) {          // the buffer holds 32 rows x 128 bytes: both n-tiles (bf16) or one (fp32)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const u32x4 r = *reinterpret_cast<const u32x4*>(tbuf + t_rd + j * 1024);
+                    u32x4 r = *reinterpret_cast<const u32x4*>(tbuf + t_rd + j * 1024);
+                    if (F32) {                 // lane: row 8j + (l >> 3), columns tn*32 + 4 (l & 7) .. +3
+                        f32x4 x = __builtin_bit_cast(f32x4, r) + biasr[tn];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) x[c] = fmaxf(x[c], act_lo);
+                        r = __builtin_bit_cast(u32x4, x);
+                    }
                     if (!(ABL & 8))
                         __builtin_amdgcn_raw_buffer_store_b128(r, rc, vst, srow + (unsigned)(8 * j) * ldc4 + (CF == 2 ? 0u : (unsigned)tn * 128u), 0);
                     else
@@ -338,7 +374,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmArgs p, int n_tiles
         const int v = tile_of_round(round);
         if (v >= n_tiles) break;
         const int m0 = (v / nbn) * P8_BM;
-        if (ADD != 0) tile_init<4, 2, ADD>(p, m0, n0, wr, wc, lane, acc);
+        if (ADD != 0) tile_init<4, 2, ADD, F32>(p, m0, n0, wr, wc, lane, acc);
         if (SPREAD && round > 0) {                   // strips 2 / 3 of the previous tile go out under this tile's first phases
             ktile(B0{}, std::integral_constant<int, P8_FIRST>{}, pm0);
             ktile(B1{}, std::integral_constant<int, P8_SECOND>{}, pm0);
@@ -368,17 +404,30 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmArgs p, int n_tiles
 
 }  // namespace
 
-// full rounds of a large-M half-row launch on 256 x 256 tiles; 1 = operand combination not built (caller falls back)
+// full rounds of a large-M launch on 256 x 256 tiles: half-row bf16 operands (prec 1) or exact fp32 (prec 0);
+// 1 = operand combination not built (the caller falls back to the older kernels)
 int launch_gemm_p8(const GemmArgs& a, int n_tiles, int grid, hipStream_t s) {
     const int add = (a.resid ? 1 : 0) | (a.g0 ? 2 : 0) | (a.g1 ? 4 : 0);
-    if (a.prec != 1 || a.a_split != 2 || a.c_split == 1 || a.rowscale || a.act == ACT_SIGMOID || (add != 0 && add != 1 && add != 6)) return 1;
-    if (a.N % P8_BN || a.K % 128 || a.K < 256 || a.M % P8_BM) return 1;
+    const bool f32 = a.prec == 0;
+    if (a.rowscale || a.act == ACT_SIGMOID || (add != 0 && add != 1 && add != 6)) return 1;
+    if (f32 ? (a.a_split || a.c_split || a.r_split || a.c_scale != 1.f) : (a.prec != 1 || a.a_split != 2 || a.c_split == 1)) return 1;
+    const int kt = f32 ? 32 : P8_BK;                  // an output tile is an even number (>= 4) of K-tiles
+    if (a.N % P8_BN || a.K % (2 * kt) || a.K < 4 * kt || a.M % P8_BM) return 1;
     const int nbn = a.N / P8_BN;
     if (grid % 8 || (grid / 8) % nbn) return 1;      // the kernel keeps one column tile per block (bias registers)
-#define VLSAT_P8(ADD, RELU, CF) hipLaunchKernelGGL((gemm_p8_kernel<ADD, RELU, CF>), dim3(grid), dim3(512), 0, s, a, n_tiles, nbn)
-#define VLSAT_P8_ABL(X) hipLaunchKernelGGL((gemm_p8_kernel<0, false, 2, X>), dim3(grid), dim3(512), 0, s, a, n_tiles, nbn)
+#define VLSAT_P8(F32, ADD, RELU, CF) hipLaunchKernelGGL((gemm_p8_kernel<F32, ADD, RELU, CF>), dim3(grid), dim3(512), 0, s, a, n_tiles, nbn)
+#define VLSAT_P8_ABL(X) hipLaunchKernelGGL((gemm_p8_kernel<false, 0, false, 2, X>), dim3(grid), dim3(512), 0, s, a, n_tiles, nbn)
     const int key = add * 4 + (a.relu_a ? 2 : 0) + (a.c_split == 2 ? 1 : 0);
-    if (a.ablate && key == 1) {                       // timing experiments (tools/p8_check.py --ablate)
+    if (f32) {
+        switch (key) {
+            case 0: VLSAT_P8(true, 0, false, 0); break;
+            case 2: VLSAT_P8(true, 0, true, 0); break;
+            case 4: VLSAT_P8(true, 1, false, 0); break;
+            case 24: VLSAT_P8(true, 6, false, 0); break;
+            case 26: VLSAT_P8(true, 6, true, 0); break;
+            default: return 1;
+        }
+    } else if (a.ablate && key == 1) {                // timing experiments (tools/p8_check.py --ablate)
         switch (a.ablate) {
             case 1: VLSAT_P8_ABL(1); break;
             case 2: VLSAT_P8_ABL(2); break;
@@ -388,32 +437,27 @@ int launch_gemm_p8(const GemmArgs& a, int n_tiles, int grid, hipStream_t s) {
             case 7: VLSAT_P8_ABL(7); break;
             case 8: VLSAT_P8_ABL(8); break;
             case 5: VLSAT_P8_ABL(5); break;
-            case 21: VLSAT_P8_ABL(21); break;
             case 37: VLSAT_P8_ABL(37); break;
-            case 16: VLSAT_P8_ABL(16); break;
             case 65: VLSAT_P8_ABL(65); break;
-            case 64: VLSAT_P8_ABL(64); break;
-            case 128: VLSAT_P8_ABL(128); break;
-            case 129: VLSAT_P8_ABL(129); break;
             default: VLSAT_P8_ABL(15); break;
         }
     } else {
         switch (key) {
-            case 0: VLSAT_P8(0, false, 0); break;
-            case 1: VLSAT_P8(0, false, 2); break;
-            case 2: VLSAT_P8(0, true, 0); break;
-            case 3: VLSAT_P8(0, true, 2); break;
-            case 4: VLSAT_P8(1, false, 0); break;
-            case 5: VLSAT_P8(1, false, 2); break;
-            case 25: VLSAT_P8(6, false, 2); break;
-            case 27: VLSAT_P8(6, true, 2); break;
+            case 0: VLSAT_P8(false, 0, false, 0); break;
+            case 1: VLSAT_P8(false, 0, false, 2); break;
+            case 2: VLSAT_P8(false, 0, true, 0); break;
+            case 3: VLSAT_P8(false, 0, true, 2); break;
+            case 4: VLSAT_P8(false, 1, false, 0); break;
+            case 5: VLSAT_P8(false, 1, false, 2); break;
+            case 25: VLSAT_P8(false, 6, false, 2); break;
+            case 27: VLSAT_P8(false, 6, true, 2); break;
             default: return 1;
         }
     }
 #undef VLSAT_P8_ABL
 #undef VLSAT_P8
     if (a.launches) ++*a.launches;
-    VLSAT_LAUNCH_CHECK("gemm_bf16_p8");
+    VLSAT_LAUNCH_CHECK("gemm_p8");
     return 0;
 }
 

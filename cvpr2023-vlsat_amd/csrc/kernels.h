@@ -35,7 +35,7 @@ struct GemmArgs {
     int ring_bk32 = 0;                          // experiment: half-row ring kernel with 32-wide k slices (default 64 where K allows)
     int ring_wide = 0;                          // experiment: bf16 ring kernel with 128 x 256 tiles where N allows (measured equal)
     int no_ring = 0;                            // debug: keep large bf16 launches on the two-stage 128 x 128 kernel
-    int no_p8 = 0;                              // debug: half-row launches skip the 256 x 256 8-phase kernel (gemm_bf16_p8.hip)
+    int no_p8 = 0;                              // debug: large launches skip the 256 x 256 8-phase kernel (gemm_bf16_p8.hip)
     int prefetch = -1;                          // bf16 LDS-direct pipe: slices of look-ahead of the A-panel prefetch (0 off, -1 default)
     int no_dma = 0;                             // debug: VGPR-staged fp32 operands instead of LDS-direct (vlsat_debug_option "gemm_dma")
     long* launches = nullptr;                   // optional host counter, +1 per kernel launched (profiling)
@@ -52,8 +52,8 @@ constexpr size_t SPLITK_COUNTERS = 512;
 // bf16 modes, full rounds of large-M launches: 3-stage LDS ring, 256 x 128 tiles, one 8-wave block per CU
 // (gemm_bf16_ring.hip); returns 1 if the operand combination is not built
 int launch_gemm_ring(const GemmArgs& a, int rbn, int n_tiles, int grid, hipStream_t s);   // rbn: tile width 128 | 256
-// single-rounding bf16 with half-row A, full rounds of large-M launches: 256 x 256 tiles, 8-phase pipeline, one 8-wave block
-// per CU (gemm_bf16_p8.hip); needs M % 256 == 0, N % 256 == 0, K % 128 == 0; returns 1 if the combination is not built
+// full rounds of large-M launches, exact fp32 or single-rounding bf16 with half-row A: 256 x 256 tiles, 8-phase pipeline,
+// one 8-wave block per CU (gemm_bf16_p8.hip); needs M % 256 == 0, N % 256 == 0, K % 128 == 0; returns 1 if the combination is not built
 int launch_gemm_p8(const GemmArgs& a, int n_tiles, int grid, hipStream_t s);
 double gemm_flops(const GemmArgs& a);
 void gemm_set_clock_probe(long long* buf);

@@ -611,6 +611,44 @@ def test_gemm_bf16_p8_kernel(lib, N, K, resid, gather, relu_a, act, c_half):
     assert float((got.double() - ref).abs().max()) <= tol
 
 
+@pytest.mark.parametrize("N,K,resid,gather,relu_a,act", [(512, 512, 0, 0, 0, 1), (1024, 128, 0, 0, 1, 0), (512, 1024, 1, 0, 0, 0), (1024, 512, 0, 1, 0, 1)])
+def test_gemm_f32_p8_kernel_is_bit_identical(lib, N, K, resid, gather, relu_a, act):
+    """Exact-fp32 launches with M >= one full round of 256 x 256 tiles take the 8-phase kernel for the full rounds.  Same k
+    order per accumulator, same epilogue order (accumulator init, bias, activation) as the 128 x 128 kernel: the results must
+    be BIT-IDENTICAL to the launch that stays off it (relu_a bit 3), with every additive operand."""
+    l = lib.load()
+    M = (256 * 256 // (N // 256)) + 256 * 5 + 33
+    g = torch.Generator().manual_seed(N * 3 + K)
+    A = torch.randn(M, K, generator=g).to(DEV)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    R = torch.randn(M, N, generator=g).to(DEV)
+    NG = 555
+    gbuf = torch.randn(NG, 2 * N, generator=g).to(DEV)
+    gi0 = torch.randint(0, NG, (M,), generator=g, dtype=torch.int32).to(DEV)
+    gi1 = torch.randint(0, NG, (M,), generator=g, dtype=torch.int32).to(DEV)
+
+    def run(flags):
+        Cb = torch.full((M, N), float("nan"), device=DEV)
+        lib.check(l.vlsat_k_gemm(A.data_ptr(), K, W.data_ptr(), K, Cb.data_ptr(), N, M, N, K, b.data_ptr(), 0,
+                                 R.data_ptr() if resid else 0, N if resid else 0, 0.5,
+                                 gbuf.data_ptr() if gather else 0, gi0.data_ptr() if gather else 0, 2 * N if gather else 0,
+                                 gbuf.data_ptr() + 4 * N if gather else 0, gi1.data_ptr() if gather else 0, 2 * N if gather else 0,
+                                 relu_a | flags, act, lib.stream_ptr()))
+        _sync()
+        return Cb.cpu()
+    got, flat = run(0), run(8)
+    assert torch.isfinite(got).all()
+    assert torch.equal(got, flat), f"{int((got != flat).sum())} elements differ, max {float((got - flat).abs().max()):.3e}"
+    kw = dict(bias=b, act=act)
+    if resid:
+        kw.update(resid=R, resid_scale=0.5)
+    if gather:
+        kw.update(g0=gbuf[:, :N], gi0=gi0, g1=gbuf[:, N:], gi1=gi1)
+    ref = _ref_gemm(torch.relu(A) if relu_a else A, W, **kw)
+    assert float((got - ref.cpu()).abs().max()) < 2e-4 * math.sqrt(K / 64)
+
+
 # ---- split-K kernel of the small launches (gemm_splitk.hip) ---------------------------------------------------------
 @pytest.mark.parametrize("M,N,K", [(9, 512, 512), (80, 3328, 512), (80, 512, 768), (40, 160, 512), (72, 26, 256), (600, 512, 1024),
                                    (1500, 1024, 512), (130, 1536, 128), (7, 40, 64)])

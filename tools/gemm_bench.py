@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--no-prefetch", action="store_true", help="fp32: without the A-panel prefetch")
     ap.add_argument("--fmt", type=int, default=0, help="bit 0: A, bit 1: resid, bit 2: C in the split-pair format, bit 5: half rows instead (timing only)")
     ap.add_argument("--rows", type=int, default=0, help="override M of the edge-row shapes (e.g. 8192: operands stay in L2)")
+    ap.add_argument("--no-p8", action="store_true", help="fp32: large launches stay off the 256 x 256 8-phase kernel")
     ap.add_argument("--splitk", action="store_true", help="small launches may take the split-K kernel (what the engine does)")
     ap.add_argument("--nodes", type=int, default=0, help="override M of the node-row shapes (one scene: 9..80)")
     a = ap.parse_args()
@@ -80,7 +81,7 @@ def main():
                                      L.ptr(R), Nn if resid else 0, 1.0,
                                      L.ptr(G0), L.ptr(gi), 2 * Nn if gather else 0,
                                      (G0.data_ptr() + 4 * Nn) if gather else 0, L.ptr(gi), 2 * Nn if gather else 0,
-                                     (2 if a.no_prefetch else 0) | (4 if a.splitk else 0), 1, L.stream_ptr()))
+                                     (2 if a.no_prefetch else 0) | (4 if a.splitk else 0) | (8 if a.no_p8 else 0), 1, L.stream_ptr()))
         variants = [("", run)] if not a.prec else [(f" pf={d}", (lambda d=d: run_planes(int(d)))) for d in a.prefetch.split(",")]
         for tag, fn in variants:
             for _ in range(3):
