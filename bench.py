@@ -230,14 +230,24 @@ def main():
     dt, out, metrics, classes = run["dt"], run["out"], run["metrics"], run["classes"]
     rank_ms = vdist.minmax_over_ranks(run["local_ms"], dev)
     default_wl = (args.scenes, args.objects, args.points, args.layers) == (64, 40, 256, 3)
-    evaluation = None
-    if not args.no_extra:                                # a collective: every rank takes part
+    evaluation, plain = None, None
+    if not args.no_extra:                                # collectives: every rank takes part
+        if prof:
+            # The same K steps again without the per-class HIP events: the instrumented run above (the headline `value`)
+            # serialises the 2D twin stages on the launch stream so that class times are attributable; a deployment runs them
+            # on the library's second stream.
+            r2 = timed_run(model, d, n_scenes, args.steps, args.warmup, False, dev)
+            plain = {"what": "same batch and steps, no HIP-event instrumentation, 2D twin stages on the library's second stream",
+                     "value": None, "ms_per_step": round(r2["dt"] / args.steps * 1e3, 3), "median_ms_per_step": round(r2["median_ms"], 3),
+                     "_dt": r2["dt"]}
         evaluation = eval_leg(model, list(scenes), d, args.objects, dev)
 
     if rank != 0:
         return
     total_scenes = float(metrics[0].item()) if world > 1 else n_scenes
     value = total_scenes * args.steps / dt
+    if plain:
+        plain["value"] = round(total_scenes * args.steps / plain.pop("_dt"), 2)
     e_scene = args.objects * (args.objects - 1)
     falg = f_alg(args.objects, args.points, e_scene, args.layers)
 
@@ -320,6 +330,7 @@ def main():
         "flop_per_scene_alg": falg,
         "metrics_allreduced": {k: float(v) for k, v in zip(vdist.METRIC_FIELDS, metrics.tolist())},
         "allreduce": "vlsat_metrics_allreduce (RCCL via the C ABI)" if args.native_allreduce else "torch.distributed.all_reduce",
+        "uninstrumented": plain,
         "evaluation": evaluation,
         "roofline": roofline, "cpu_baseline": cpu, "max_abs_err_vs_cpu_oracle": err,
         "speedup_vs_cpu": round(value / cpu["value"], 1) if cpu else None,

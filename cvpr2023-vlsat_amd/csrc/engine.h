@@ -45,7 +45,8 @@ struct Arena { char* p = nullptr; size_t bytes = 0; hipEvent_t last = nullptr; }
 
 struct vlsat_ctx {
     VlsatDims d{};
-    int dual_stream = 1;     // run the 2D twin stages of small plans on a second stream (vlsat_debug_option "dual_stream")
+    int dual_stream = 2;     // 2D twin stages on a second stream: 0 never, 1 launch-bound plans only (E <= 8192), 2 every plan
+                             // (vlsat_debug_option "dual_stream"; never while the per-class HIP-event profiling is on)
     hipStream_t side = nullptr;
     hipStream_t copy = nullptr;          // plan index uploads (non-blocking stream)
     std::vector<hipEvent_t> sync_ev;     // fork/join events (timing disabled), created on first use

@@ -35,7 +35,7 @@ int vlsat_set_edge_attention_scope(vlsat_handle h, int32_t scope) {
 
 // debug / experiment switches of one handle (they replace the VLSAT_* environment variables of round 1; defaults are
 // the measured-best settings and none changes results beyond fp32 summation order):
-//   "dual_stream" 0|1   2D twin stages of small plans on a second stream (plans created afterwards)
+//   "dual_stream" 0|1|2 2D twin stages on a second stream: 1 small plans only, 2 every plan (plans created afterwards)
 //   "flash_split" 0|1   split-key edge attention for plans that cannot fill the chip (plans created afterwards)
 //   "gemm_dma"    0|1   LDS-direct staging of fp32 GEMM operands (0: VGPR-staged)
 //   "gemm_p8"     0|1   single-rounding bf16 modes: large half-row launches on the 256 x 256 8-phase kernel (0: ring kernel)
@@ -52,7 +52,7 @@ int vlsat_debug_option(vlsat_handle h, const char* name, int32_t value) {
     if (!h || !name) return fail(VLSAT_EINVAL, "vlsat_debug_option: null argument");
     const std::string k(name);
     ++h->config_epoch;
-    if (k == "dual_stream") h->dual_stream = value != 0;
+    if (k == "dual_stream") h->dual_stream = value < 0 ? 0 : value;
     else if (k == "flash_split") h->fa_split = value != 0;
     else if (k == "gemm_dma") h->gemm_no_dma = value == 0;
     else if (k == "gemm_p8") h->gemm_no_p8 = value == 0;

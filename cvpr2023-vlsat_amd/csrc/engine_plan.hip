@@ -207,7 +207,7 @@ int vlsat_plan_create(vlsat_handle h, const int64_t* bid, const int64_t* edges, 
     want(&p->Hbig, Es * 1024); want(&p->KP, Es * 512); want(&p->G, Es * A);
     want(&p->Qe, Es * 512); want(&p->KVe, Es * 1024); want(&p->Oe, Es * 512);
     // launch-bound plans (every edge GEMM fits one round of the grid): second scratch set for the 2D twin stages
-    p->dual = h->dual_stream && E > 0 && E <= 8192;
+    p->dual = h->dual_stream && E > 0 && (h->dual_stream > 1 || E <= 8192);      // (dual_stream = 2: every plan)
     if (p->dual) {
         want(&p->NP2, Ns * NPC); want(&p->Hbig2, Es * 1024); want(&p->KP2, Es * 512); want(&p->G2, Es * A);
         want(&p->T768b, Ns * LDX); want(&p->rs2, Ns); want(&p->H2b, Es * 128);

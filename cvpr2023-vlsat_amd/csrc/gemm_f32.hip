@@ -274,8 +274,12 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
         ((size_t)a.M + 256) * a.lda * 4 < (1ull << 32) && ((size_t)a.M + 256) * a.ldc * 4 < (1ull << 32) &&
         ((size_t)a.N + 256) * a.ldw * 4 < (1ull << 32)) {
         const int G1 = G / 2;
-        const long nbn = a.N / 256, rounds = (long)(a.M / 256) * nbn / G1;
-        const long main_panels = rounds * G1 / nbn;
+        const long nbn = a.N / 256, panels = a.M / 256, rounds = panels * nbn / G1;
+        long main_panels = rounds * G1 / nbn;
+        // less than one round left (the tail of a big launch, or a medium-sized one): a partial round costs a whole tile time
+        // (one tile per CU), the 128 x 128 kernels ~0.7 (fp32) / ~0.5 (bf16) of it per full round of tiles -- from 5/8 of a
+        // round on this kernel is the faster one
+        if (main_panels == 0 && panels * nbn >= (G1 * 5) / 8) main_panels = panels;
         if (main_panels > 0) {
             GemmArgs m = a;
             m.M = (int)(main_panels * 256);

@@ -282,7 +282,7 @@ int vlsat_debug_read(vlsat_plan p, const char* name, float* dst, int64_t dst_ld)
 int vlsat_debug_gemm_clock_probe(int64_t* buf);
 
 /* Experiment switches of one handle; defaults are the measured-best settings and none changes results beyond
- * fp32 summation order.  "dual_stream" 0|1: 2D twin stages of small plans on a second stream; "flash_split" 0|1:
+ * fp32 summation order.  "dual_stream" 0|1|2: 2D twin stages on a second stream (1: launch-bound plans only, 2 = default: every plan); "flash_split" 0|1:
  * split-key edge attention for plans that cannot fill the chip (both: plans created afterwards); "gemm_dma" 0|1:
  * LDS-direct staging of fp32 GEMM operands; "gate_grid" n: persistent grid of the gate kernel (0 = default);
  * "split_fmt" 0|1: in the bf16 modes, edge tensors between matrix kernels as bf16 hi/lo pairs (0: fp32, split on read);
