@@ -60,9 +60,15 @@ enum { P8_MID = 0, P8_LAST = 1, P8_FIRST = 2, P8_SECOND = 3, P8_FIRST0 = 4 };   
 // rows, a lane's fragment is the 16-byte chunk 2 ks + hi = four consecutive k (gemm_core.h, K-permutation trick) -- so
 // loader, phases, waits and epilogue are shared; a phase is 32 MFMAs of 64 cycles there.  Bias then joins after the
 // transposition (8 registers per lane; same fp32 operation order as gemm_f32.hip: bit-identical results).
-template <bool F32, int ADD, bool RELU, int CF, int ABL = 0>
+// MODE 2 (X3): split-bf16, three MFMAs per product.  A = split-pair words (bf16 hi | lo in one 32-bit word, common.h), the
+// same 128-byte rows as fp32 (K-tiles of 32), separated with v_perm on the fragment side; a weight half-tile is the hi and
+// the lo plane side by side, 128 rows x 64 bytes each (chunks swizzled with (row >> 2) & 3), one LDS-direct load per plane
+// -- so a half-tile is still two loads and every counted wait is unchanged.  Term order per accumulator and epilogue order
+// as in the older split-bf16 kernels: bit-identical results.
+template <int MODE, int ADD, bool RELU, int CF, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmArgs p, int n_tiles, int nbn) {
-    static_assert(!F32 || CF == 0, "fp32 operands: fp32 output");
+    constexpr bool F32 = MODE == 1, X3 = MODE == 2, WORDS = MODE != 0;      // WORDS: 4-byte A elements, K-tiles of 32
+    static_assert(MODE == 0 ? (CF == 0 || CF == 2) : F32 ? CF == 0 : (CF == 0 || CF == 1), "output format of the mode");
     __shared__ __attribute__((aligned(16))) char smem[10 * P8_HALF];
     typedef short s16x8 __attribute__((ext_vector_type(8)));
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -75,32 +81,47 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmArgs p, int n_tiles
     const int wr = wave >> 2, wc = wave & 3;
     const int li = lane & 31, hi = lane >> 5;
     const int g8 = gridDim.x >> 3, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int KT = p.K / (F32 ? 32 : P8_BK);           // K-tiles of 128 bytes per operand row
+    const int KT = p.K / (WORDS ? 32 : P8_BK);         // K-tiles of 128 bytes per A row
     auto tile_of_round = [&](int r) { return (r * 8 + xcd) * g8 + slot; };
     if (tile_of_round(0) >= n_tiles) return;
 
     // ---- LDS-direct loader: lane constants (a wave instruction fills 8 rows x 128 bytes) ----
     const int srow = wave * 8 + (lane >> 3);                                   // LDS row inside a 64-row round
     const unsigned schunk = (unsigned)((lane & 7) ^ ((srow >> 1) & 7));          // logical chunk this lane fetches
-    constexpr unsigned EB = F32 ? 4u : 2u;                                     // bytes per operand element
-    const unsigned lda4 = (unsigned)p.lda * 4u, ldw2 = (unsigned)p.ldw * EB;     // row pitches in bytes (half rows keep the fp32 pitch)
+    constexpr unsigned EA = WORDS ? 4u : 2u, EW = F32 ? 4u : 2u;              // bytes per A / W element
+    constexpr unsigned KA = 128u, KW = X3 ? 64u : 128u;                        // bytes of a K-tile in an A / W row
+    const unsigned lda4 = (unsigned)p.lda * 4u, ldw2 = (unsigned)p.ldw * EW;     // row pitches in bytes (half rows keep the fp32 pitch)
     const unsigned vA = (unsigned)srow * lda4 + schunk * 16u;
-    const unsigned vW = (unsigned)((wave >> 2) * 64 + (wave & 3) * 8 + (lane >> 3)) * ldw2 + schunk * 16u;
-    const int na = (int)((size_t)(p.M - 1) * lda4 + (size_t)p.K * EB), nw = (int)(((size_t)(p.N - 1) * p.ldw + p.K) * EB);
+    // weight rows: 128-byte K-tiles like A (8 rows per wave instruction), or -- X3 -- 64-byte ones (16 rows, one plane)
+    const int wrow3 = wave * 16 + (lane >> 2);                                  // X3: LDS row of the half-tile's plane
+    const unsigned vW = X3 ? (unsigned)((wrow3 >> 5) * 64 + (wrow3 & 31)) * ldw2 + (unsigned)((lane & 3) ^ ((wrow3 >> 2) & 3)) * 16u
+                           : (unsigned)((wave >> 2) * 64 + (wave & 3) * 8 + (lane >> 3)) * ldw2 + schunk * 16u;
+    const int na = (int)((size_t)(p.M - 1) * lda4 + (size_t)p.K * EA), nw = (int)(((size_t)(p.N - 1) * p.ldw + p.K) * EW);
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, na, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(F32 ? (void*)const_cast<float*>(p.W) : (void*)const_cast<uint16_t*>(p.Whi), 0, nw, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rwl = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(X3 ? p.Wlo : p.Whi), 0, nw, 0x00020000);
     char* const sdst = smem + wave * 1024;
     // two wave instructions = one half-tile: rows 0..63 and 64..127 of it
     auto ld2 = [&](const __amdgpu_buffer_rsrc_t& r, char* dst, unsigned v, unsigned s0, unsigned step) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst, 16, v, s0, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst + 8192, 16, v, s0 + step, 0, 0);
     };
+    // weight half-tile h at byte offset sw (K-tile included): two 64-row rounds of one plane, or (X3) the two planes
+    auto ldw = [&](char* dst, unsigned sw, int h) {
+        const unsigned s0 = sw + (unsigned)(h * 32) * ldw2;
+        if (X3) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, dst, 16, vW, s0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rwl, dst + 8192, 16, vW, s0, 0, 0);
+        } else {
+            ld2(rw, dst, vW, s0, 128u * ldw2);
+        }
+    };
     // half-tile h of the K-tile at byte offsets (sa, sw) into buffer `buf`
     auto stage_a = [&](int buf, int h, unsigned sa) {
         if (!(ABL & 1)) ld2(ra, sdst + (buf * 2 + h) * P8_HALF, vA, sa + (unsigned)(h * 64) * lda4, 128u * lda4);
     };
     auto stage_w = [&](int buf, int h, unsigned sw) {
-        if (!(ABL & 1)) ld2(rw, sdst + P8_WBASE + (buf * 2 + h) * P8_HALF, vW, sw + (unsigned)(h * 32) * ldw2, 128u * ldw2);
+        if (!(ABL & 1)) ldw(sdst + P8_WBASE + (buf * 2 + h) * P8_HALF, sw, h);
     };
 
     // ---- staging cursor: the K-tile sequence of this block, across output tiles ----
@@ -125,13 +146,16 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmArgs p, int n_tiles
     advance(c2);
 
     // ---- fragment readers: per-lane byte offsets of k-step ks (the chunk XOR is not an add: one register per k-step) ----
+    // (X3: fragment i of an A tile is chunk 4 (i >> 1) + 2 hi + (i & 1) -- eight words of k-step i >> 1 in two reads; weight
+    //  fragment i is chunk 2 (i & 1) + hi of the 64-byte row of plane i >> 1)
     const int swz = (li >> 1) & 7;
     int offA[4], offW[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-        const int chunk = ((2 * ks + hi) ^ swz) * 16;
-        offA[ks] = (wr * 64 + li) * 128 + chunk;
-        offW[ks] = P8_WBASE + (wc * 32 + li) * 128 + chunk;
+        const int ca = X3 ? (((ks >> 1) << 2) | (hi << 1) | (ks & 1)) : 2 * ks + hi;
+        offA[ks] = (wr * 64 + li) * 128 + ((ca ^ swz) * 16);
+        offW[ks] = X3 ? P8_WBASE + (ks >> 1) * 8192 + (wc * 32 + li) * 64 + (((2 * (ks & 1) + hi) ^ ((li >> 2) & 3)) * 16)
+                      : P8_WBASE + (wc * 32 + li) * 128 + (((2 * ks + hi) ^ swz) * 16);
     }
     bf16x8 af[2][4], w0[4], w1[4];
     bf16x8 dum[12];                              // (ABL bit 6: the reads land here and nothing waits for them before the MFMAs)
@@ -168,7 +192,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmArgs p, int n_tiles
     const int n0 = (tile_of_round(0) % nbn) * P8_BN;
     bf16x8 wb[2], ones;
     f32x4 biasr[2];                               // fp32: the lane's bias values in the layout AFTER the transposition
-    if (!F32) {
+    if (!WORDS) {
         const __bf16 z = (__bf16)0.f, o = hi ? z : (__bf16)1.f;
         ones = bf16x8{o, o, o, z, z, z, z, z};
 #pragma unroll
@@ -207,6 +231,37 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmArgs p, int n_tiles
                         const f32x16 c0 = (INIT && ADD == 0 && ks == 0 && sft == 0) ? zero : acc[2 * ah + mt][bh];
                         acc[2 * ah + mt][bh] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[sft], a, c0, 0, 0, 0);
                     }
+            }
+        } else if (X3) {
+            // w = {hi ks0, hi ks1, lo ks0, lo ks1}; term order per accumulator: w_hi.a_lo, w_lo.a_hi, w_hi.a_hi (small terms
+            // first, as gemm_core.h PipeSplitDma); the two accumulators take turns so that no MFMA waits for its predecessor
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 ahi[2], alo[2];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    u32x4 x0 = __builtin_bit_cast(u32x4, af[mt][2 * ks]), x1 = __builtin_bit_cast(u32x4, af[mt][2 * ks + 1]);
+                    if (RELU) {          // x < 0  <=>  its hi part is negative: sign bit of the word; the whole word becomes +0
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) { x0[c] = (unsigned)max((int)x0[c], 0); x1[c] = (unsigned)max((int)x1[c], 0); }
+                    }
+                    u32x4 h, l;
+                    h[0] = __builtin_amdgcn_perm(x0[1], x0[0], 0x07060302u); h[1] = __builtin_amdgcn_perm(x0[3], x0[2], 0x07060302u);
+                    h[2] = __builtin_amdgcn_perm(x1[1], x1[0], 0x07060302u); h[3] = __builtin_amdgcn_perm(x1[3], x1[2], 0x07060302u);
+                    l[0] = __builtin_amdgcn_perm(x0[1], x0[0], 0x05040100u); l[1] = __builtin_amdgcn_perm(x0[3], x0[2], 0x05040100u);
+                    l[2] = __builtin_amdgcn_perm(x1[1], x1[0], 0x05040100u); l[3] = __builtin_amdgcn_perm(x1[3], x1[2], 0x05040100u);
+                    ahi[mt] = __builtin_bit_cast(bf16x8, h);
+                    alo[mt] = __builtin_bit_cast(bf16x8, l);
+                }
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    acc[2 * ah + mt][bh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ks], alo[mt], (INIT && ADD == 0 && ks == 0) ? zero : acc[2 * ah + mt][bh], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    acc[2 * ah + mt][bh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[2 + ks], ahi[mt], acc[2 * ah + mt][bh], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    acc[2 * ah + mt][bh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ks], ahi[mt], acc[2 * ah + mt][bh], 0, 0, 0);
             }
         } else {
             if (INIT) {
@@ -249,7 +304,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmArgs p, int n_tiles
                 f32x4 v;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) v[c] = acc[TM][tn][4 * g + c];
-                if (!F32) {
+                if (!WORDS) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], act_lo) * cs;      // (branch-free: ReLU or max with -inf)
                 }
@@ -266,15 +321,36 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmArgs p, int n_tiles
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     u32x4 r = *reinterpret_cast<const u32x4*>(tbuf + t_rd + j * 1024);
-                    if (F32) {                 // lane: row 8j + (l >> 3), columns tn*32 + 4 (l & 7) .. +3
+                    if (WORDS) {               // lane: row 8j + (l >> 3), columns tn*32 + 4 (l & 7) .. +3
                         f32x4 x = __builtin_bit_cast(f32x4, r) + biasr[tn];
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) x[c] = fmaxf(x[c], act_lo);
+                        for (int c = 0; c < 4; ++c) {
+                            x[c] = fmaxf(x[c], act_lo);
+                            if (X3) x[c] *= cs;
+                        }
                         r = __builtin_bit_cast(u32x4, x);
+                        if (CF == 1) {         // split pairs (common.h pack_split), two elements at a time
+#pragma unroll
+                            for (int c = 0; c < 4; c += 2) {
+                                typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                                const f32x2 v2 = {x[c], x[c + 1]};
+                                const bf16x2 h2 = __builtin_convertvector(v2, bf16x2);
+                                const bf16x2 l2 = __builtin_convertvector(v2 - __builtin_convertvector(h2, f32x2), bf16x2);
+                                const unsigned hb = __builtin_bit_cast(unsigned, h2), lb = __builtin_bit_cast(unsigned, l2);
+                                r[c] = __builtin_amdgcn_perm(hb, lb, 0x05040100u);
+                                r[c + 1] = __builtin_amdgcn_perm(hb, lb, 0x07060302u);
+                            }
+                        }
                     }
-                    if (!(ABL & 8))
+                    if (!(ABL & 8)) {
                         __builtin_amdgcn_raw_buffer_store_b128(r, rc, vst, srow + (unsigned)(8 * j) * ldc4 + (CF == 2 ? 0u : (unsigned)tn * 128u), 0);
-                    else
+                        // A 128-bit buffer store reads its data registers a few cycles after issue; hipcc pads a following VALU
+                        // write of them ONLY when the store has no SGPR soffset (LLVM's hazard rule assumes the register form is
+                        // safe) -- on gfx950 it is not: split-pair epilogues, whose pack code reuses the registers at once, stored
+                        // garbage in one dword of some lanes until this pad went in (found with the bit-identity test).
+                        asm volatile("s_nop 3" ::: "memory");
+                    } else
                         asm volatile("" ::"v"(r));
                 }
             }
@@ -283,11 +359,11 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmArgs p, int n_tiles
 
     // ---- prologue: the six half-tiles whose staging phase lies before the first compute phase ----
     ld2(ra, sdst, vA, c0.sa, 128u * lda4);                                                        // A_0(0)
-    ld2(rw, sdst + P8_WBASE, vW, c0.sw, 128u * ldw2);                                             // W_0(0)
-    ld2(rw, sdst + P8_WBASE + P8_HALF, vW, c0.sw + 32u * ldw2, 128u * ldw2);                      // W_1(0)
+    ldw(sdst + P8_WBASE, c0.sw, 0);                                                               // W_0(0)
+    ldw(sdst + P8_WBASE + P8_HALF, c0.sw, 1);                                                     // W_1(0)
     ld2(ra, sdst + P8_HALF, vA, c0.sa + 64u * lda4, 128u * lda4);                                 // A_1(0)
-    ld2(ra, sdst + 2 * P8_HALF, vA, c1.sa + c1.kt * 128u, 128u * lda4);                           // A_0(1)
-    ld2(rw, sdst + P8_WBASE + 2 * P8_HALF, vW, c1.sw + c1.kt * 128u, 128u * ldw2);                // W_0(1)
+    ld2(ra, sdst + 2 * P8_HALF, vA, c1.sa + c1.kt * KA, 128u * lda4);                             // A_0(1)
+    ldw(sdst + P8_WBASE + 2 * P8_HALF, c1.sw + c1.kt * KW, 0);                                    // W_0(1)
     p8_wait_vm<8>();
     p8_barrier();
     if (wr == 1) p8_barrier();                       // the two wave rows run one barrier apart from here on
@@ -304,8 +380,8 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmArgs p, int n_tiles
         constexpr int N2 = 8 + (VAR == P8_FIRST ? 4 * E : 0);
         constexpr int N4 = 8 + (VAR == P8_FIRST || VAR == P8_LAST ? 2 * E : 0);
         using Init = std::integral_constant<bool, VAR == P8_FIRST || VAR == P8_FIRST0>;
-        const unsigned a1 = c1.sa + c1.kt * 128u, w1o = c1.sw + c1.kt * 128u;
-        const unsigned a2 = c2.sa + c2.kt * 128u, w2o = c2.sw + c2.kt * 128u;
+        const unsigned a1 = c1.sa + c1.kt * KA, w1o = c1.sw + c1.kt * KW;
+        const unsigned a2 = c2.sa + c2.kt * KA, w2o = c2.sw + c2.kt * KW;
         // phase 1: quadrant (a0, w0)
         if (VAR == P8_FIRST) {               // (before the fragment reads: the strip's temporaries need their registers)
             epi(std::integral_constant<int, 2>{}, pm0);
@@ -374,7 +450,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmArgs p, int n_tiles
         const int v = tile_of_round(round);
         if (v >= n_tiles) break;
         const int m0 = (v / nbn) * P8_BM;
-        if (ADD != 0) tile_init<4, 2, ADD, F32>(p, m0, n0, wr, wc, lane, acc);
+        if (ADD != 0) tile_init<4, 2, ADD, F32>(p, m0, n0, wr, wc, lane, acc);   // (PLAIN only for fp32: formats fold away)
         if (SPREAD && round > 0) {                   // strips 2 / 3 of the previous tile go out under this tile's first phases
             ktile(B0{}, std::integral_constant<int, P8_FIRST>{}, pm0);
             ktile(B1{}, std::integral_constant<int, P8_SECOND>{}, pm0);
@@ -404,27 +480,39 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmArgs p, int n_tiles
 
 }  // namespace
 
-// full rounds of a large-M launch on 256 x 256 tiles: half-row bf16 operands (prec 1) or exact fp32 (prec 0);
-// 1 = operand combination not built (the caller falls back to the older kernels)
+// full rounds of a large-M launch on 256 x 256 tiles: half-row bf16 operands (prec 1), exact fp32 (prec 0) or split-bf16
+// on split-pair operands (prec 3); 1 = operand combination not built (the caller falls back to the older kernels)
 int launch_gemm_p8(const GemmArgs& a, int n_tiles, int grid, hipStream_t s) {
     const int add = (a.resid ? 1 : 0) | (a.g0 ? 2 : 0) | (a.g1 ? 4 : 0);
-    const bool f32 = a.prec == 0;
+    const bool f32 = a.prec == 0, x3 = a.prec == 3;
     if (a.rowscale || a.act == ACT_SIGMOID || (add != 0 && add != 1 && add != 6)) return 1;
-    if (f32 ? (a.a_split || a.c_split || a.r_split || a.c_scale != 1.f) : (a.prec != 1 || a.a_split != 2 || a.c_split == 1)) return 1;
-    const int kt = f32 ? 32 : P8_BK;                  // an output tile is an even number (>= 4) of K-tiles
+    if (f32 ? (a.a_split || a.c_split || a.r_split || a.c_scale != 1.f)
+            : x3 ? (a.a_split != 1 || a.c_split == 2 || !a.Wlo) : (a.prec != 1 || a.a_split != 2 || a.c_split == 1)) return 1;
+    const int kt = (f32 || x3) ? 32 : P8_BK;          // an output tile is an even number (>= 4) of K-tiles
     if (a.N % P8_BN || a.K % (2 * kt) || a.K < 4 * kt || a.M % P8_BM) return 1;
     const int nbn = a.N / P8_BN;
     if (grid % 8 || (grid / 8) % nbn) return 1;      // the kernel keeps one column tile per block (bias registers)
-#define VLSAT_P8(F32, ADD, RELU, CF) hipLaunchKernelGGL((gemm_p8_kernel<F32, ADD, RELU, CF>), dim3(grid), dim3(512), 0, s, a, n_tiles, nbn)
-#define VLSAT_P8_ABL(X) hipLaunchKernelGGL((gemm_p8_kernel<false, 0, false, 2, X>), dim3(grid), dim3(512), 0, s, a, n_tiles, nbn)
-    const int key = add * 4 + (a.relu_a ? 2 : 0) + (a.c_split == 2 ? 1 : 0);
+#define VLSAT_P8(MODE, ADD, RELU, CF) hipLaunchKernelGGL((gemm_p8_kernel<MODE, ADD, RELU, CF>), dim3(grid), dim3(512), 0, s, a, n_tiles, nbn)
+#define VLSAT_P8_ABL(X) hipLaunchKernelGGL((gemm_p8_kernel<0, 0, false, 2, X>), dim3(grid), dim3(512), 0, s, a, n_tiles, nbn)
+    const int key = add * 4 + (a.relu_a ? 2 : 0) + (a.c_split ? 1 : 0);
     if (f32) {
         switch (key) {
-            case 0: VLSAT_P8(true, 0, false, 0); break;
-            case 2: VLSAT_P8(true, 0, true, 0); break;
-            case 4: VLSAT_P8(true, 1, false, 0); break;
-            case 24: VLSAT_P8(true, 6, false, 0); break;
-            case 26: VLSAT_P8(true, 6, true, 0); break;
+            case 0: VLSAT_P8(1, 0, false, 0); break;
+            case 2: VLSAT_P8(1, 0, true, 0); break;
+            case 4: VLSAT_P8(1, 1, false, 0); break;
+            case 24: VLSAT_P8(1, 6, false, 0); break;
+            case 26: VLSAT_P8(1, 6, true, 0); break;
+            default: return 1;
+        }
+    } else if (x3) {
+        switch (key) {
+            case 0: VLSAT_P8(2, 0, false, 0); break;
+            case 1: VLSAT_P8(2, 0, false, 1); break;
+            case 2: VLSAT_P8(2, 0, true, 0); break;
+            case 3: VLSAT_P8(2, 0, true, 1); break;
+            case 4: VLSAT_P8(2, 1, false, 0); break;
+            case 25: VLSAT_P8(2, 6, false, 1); break;
+            case 27: VLSAT_P8(2, 6, true, 1); break;
             default: return 1;
         }
     } else if (a.ablate && key == 1) {                // timing experiments (tools/p8_check.py --ablate)
@@ -443,14 +531,14 @@ int launch_gemm_p8(const GemmArgs& a, int n_tiles, int grid, hipStream_t s) {
         }
     } else {
         switch (key) {
-            case 0: VLSAT_P8(false, 0, false, 0); break;
-            case 1: VLSAT_P8(false, 0, false, 2); break;
-            case 2: VLSAT_P8(false, 0, true, 0); break;
-            case 3: VLSAT_P8(false, 0, true, 2); break;
-            case 4: VLSAT_P8(false, 1, false, 0); break;
-            case 5: VLSAT_P8(false, 1, false, 2); break;
-            case 25: VLSAT_P8(false, 6, false, 2); break;
-            case 27: VLSAT_P8(false, 6, true, 2); break;
+            case 0: VLSAT_P8(0, 0, false, 0); break;
+            case 1: VLSAT_P8(0, 0, false, 2); break;
+            case 2: VLSAT_P8(0, 0, true, 0); break;
+            case 3: VLSAT_P8(0, 0, true, 2); break;
+            case 4: VLSAT_P8(0, 1, false, 0); break;
+            case 5: VLSAT_P8(0, 1, false, 2); break;
+            case 25: VLSAT_P8(0, 6, false, 2); break;
+            case 27: VLSAT_P8(0, 6, true, 2); break;
             default: return 1;
         }
     }

@@ -267,9 +267,9 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
         const int r = launch_gemm_splitk(a, G, s);
         if (r <= 0) return r;
     }
-    // Large M, exact fp32 or single-rounding bf16 with half-row operands: the full rounds of 256 x 256 tiles go to the 8-phase
+    // Large M; exact fp32, single-rounding bf16 with half-row operands or split-bf16 with split-pair operands: the full rounds of 256 x 256 tiles go to the 8-phase
     // kernel (gemm_bf16_p8.hip: one 8-wave block per CU), the remaining row panels to the kernels below
-    if (((a.prec == 1 && a.a_split == 2) || (a.prec == 0 && !a.a_split && !a.c_split && !a.r_split)) && !a.no_dma && !a.no_ring &&
+    if (((a.prec == 1 && a.a_split == 2) || (a.prec == 3 && a.a_split == 1) || (a.prec == 0 && !a.a_split && !a.c_split && !a.r_split)) && !a.no_dma && !a.no_ring &&
         !a.no_p8 && !a.rowscale && !a.clock_probe && a.N % 256 == 0 && a.K % 128 == 0 &&
         ((size_t)a.M + 256) * a.lda * 4 < (1ull << 32) && ((size_t)a.M + 256) * a.ldc * 4 < (1ull << 32) &&
         ((size_t)a.N + 256) * a.ldw * 4 < (1ull << 32)) {

@@ -649,6 +649,49 @@ def test_gemm_f32_p8_kernel_is_bit_identical(lib, N, K, resid, gather, relu_a, a
     assert float((got - ref.cpu()).abs().max()) < 2e-4 * math.sqrt(K / 64)
 
 
+@pytest.mark.parametrize("N,K,resid,gather,relu_a,act,c_pairs", [(512, 512, 0, 0, 0, 1, 1), (1024, 128, 0, 0, 1, 0, 1), (512, 1024, 0, 0, 0, 0, 0),
+                                                                 (1024, 512, 0, 1, 1, 1, 1)])
+def test_gemm_bf16x3_p8_kernel_is_bit_identical(lib, N, K, resid, gather, relu_a, act, c_pairs):
+    """Split-bf16 launches on split-pair operands with M >= one full round of 256 x 256 tiles: the 8-phase kernel takes the
+    full rounds.  Same term order per accumulator (w_hi.a_lo, w_lo.a_hi, w_hi.a_hi per 16 k) and the same epilogue order as
+    the 128 x 128 kernel: BIT-IDENTICAL to the launch that stays off it (fmt bits 4, 12); and close to fp64."""
+    l = lib.load()
+    M = (256 * 256 // (N // 256)) + 256 * 5 + 33
+    g = torch.Generator().manual_seed(N * 5 + K)
+    A = torch.randn(M, K, generator=g)
+    Ap = _pack_split(A).to(DEV)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    NG = 555
+    gbuf = torch.randn(NG, 2 * N, generator=g).to(DEV)
+    gi0 = torch.randint(0, NG, (M,), generator=g, dtype=torch.int32).to(DEV)
+    gi1 = torch.randint(0, NG, (M,), generator=g, dtype=torch.int32).to(DEV)
+    hi = torch.empty(N * K + 128, dtype=torch.int16, device=DEV)
+    lo = torch.empty_like(hi)
+    lib.check(l.vlsat_k_split_bf16(W.data_ptr(), N * K, hi.data_ptr(), lo.data_ptr(), lib.stream_ptr()))
+    fmt = 1 | (4 if c_pairs else 0)
+
+    def run(f):
+        Cb = torch.full((M, N), float("nan"), device=DEV)
+        lib.check(l.vlsat_k_gemm_planes(Ap.data_ptr(), K, W.data_ptr(), hi.data_ptr(), lo.data_ptr(), K, Cb.data_ptr(), N, M, N, K,
+                                        b.data_ptr(), 0, 0, 1.0,
+                                        gbuf.data_ptr() if gather else 0, gi0.data_ptr() if gather else 0, 2 * N if gather else 0,
+                                        gbuf.data_ptr() + 4 * N if gather else 0, gi1.data_ptr() if gather else 0, 2 * N if gather else 0,
+                                        relu_a, act, 3, 0, -1, f, 1.0, lib.stream_ptr()))
+        _sync()
+        return Cb.cpu()
+    got, flat = run(fmt), run(fmt | 16 | (1 << 12))
+    assert torch.equal(got.view(torch.int32), flat.view(torch.int32)), f"{int((got.view(torch.int32) != flat.view(torch.int32)).sum())} words differ"
+    val = _unpack_split(got) if c_pairs else got
+    assert torch.isfinite(val).all()
+    kw = dict(bias=b, act=act)
+    if gather:
+        kw.update(g0=gbuf[:, :N], gi0=gi0, g1=gbuf[:, N:], gi1=gi1)
+    Af = _unpack_split(Ap.cpu())
+    ref = _ref_gemm(torch.relu(Af) if relu_a else Af, W, **kw)
+    assert float((val - ref).abs().max()) < 1e-4 * math.sqrt(K / 64) + 2e-5
+
+
 # ---- split-K kernel of the small launches (gemm_splitk.hip) ---------------------------------------------------------
 @pytest.mark.parametrize("M,N,K", [(9, 512, 512), (80, 3328, 512), (80, 512, 768), (40, 160, 512), (72, 26, 256), (600, 512, 1024),
                                    (1500, 1024, 512), (130, 1536, 128), (7, 40, 64)])
