@@ -1,0 +1,25 @@
+#!/bin/bash
+# Everything DESIGN.md quotes for round 3, in one GPU session; outputs under gpurun_out/r03/ (tools/publish_profiles.sh r03
+# copies the summaries to profiles/).
+set -u
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/r03
+mkdir -p "$OUT"
+cd "$ROOT"
+python bench.py > "$OUT/bench_fp32.json" 2> "$OUT/bench_fp32.err"                       # the driver's command: headline + extra_configs
+python bench.py --gemm-precision bf16x3 --no-extra > "$OUT/bench_cfg3_bf16x3.json" 2> "$OUT/bench_cfg3_bf16x3.err"
+python bench.py --gemm-precision bf16_mixed --no-extra > "$OUT/bench_cfg3_bf16_mixed.json" 2> "$OUT/bench_cfg3_bf16_mixed.err"
+tools/profile_run.sh r03/prof_fp32 --no-extra > /dev/null 2>&1
+tools/profile_run.sh r03/prof_cfg3 --gemm-precision bf16x3 --no-extra > /dev/null 2>&1
+tools/profile_run.sh r03/prof_cfg3_mixed --gemm-precision bf16_mixed --no-extra > /dev/null 2>&1
+python tools/gemm_bench.py --only E > "$OUT/gemm_fp32.txt" 2>&1
+python tools/gemm_bench.py --only E --no-p8 > "$OUT/gemm_fp32_no_p8.txt" 2>&1
+python tools/p8_check.py --no-check > "$OUT/gemm_bf16_half.txt" 2>&1
+python tools/p8_check.py --no-check --ablate --rows 98304 --only kproj > "$OUT/gemm_p8_ablation.txt" 2>&1
+python tools/gemm_bench.py --prec 3 --only E --fmt 5 > "$OUT/gemm_bf16x3.txt" 2>&1
+python tools/gemm_bench.py --prec 3 --only E --fmt 4101 > "$OUT/gemm_bf16x3_no_p8.txt" 2>&1
+python tools/latency_probe.py > "$OUT/latency_fp32.txt" 2>&1
+python tools/latency_probe.py --gemm-precision bf16x3 > "$OUT/latency_bf16x3.txt" 2>&1
+python tools/eval_synth.py > "$OUT/eval_synth.txt" 2>&1
+python -m pytest tests -q -m gpu 2>&1 | tail -3 > "$OUT/tests_gpu.log"
+du -sh "$OUT"; ls "$OUT"
