@@ -163,6 +163,32 @@ int vlsat_plan_create(vlsat_handle h, const int64_t* bid, const int64_t* edges, 
         bias_ptr[s] = bias_total;
         bias_total += (int64_t)H * n * n;
     }
+    // Many blocks (several rounds of the resident slots): the kernels map block b to tile xcd_remap(b) -- XCD b % 8 walks a
+    // contiguous range of tile ids in order -- and a scene's last query tile is usually mostly empty (1560 = 12 * 128 + 24:
+    // one wave of four has work).  Those light tiles go to the END of every XCD's range, so that the last, partly filled
+    // round of blocks is made of light work instead of ending on full tiles next to idle CUs.
+    if (tiles.size() >= 2048) {
+        std::vector<int4> full, part;
+        for (const int4& t : tiles) (t.z + FLASH_BQ <= t.y ? full : part).push_back(t);
+        if (!part.empty() && !full.empty()) {
+            const size_t n = tiles.size(), q = n / 8, r = n % 8;
+            std::vector<int4> out;
+            out.reserve(n);
+            size_t fi = 0, pi = 0;
+            for (size_t x = 0; x < 8; ++x) {
+                const size_t cnt = q + (x < r ? 1 : 0);
+                size_t np = part.size() * (x + 1) / 8 - part.size() * x / 8;          // this XCD's share of the light tiles
+                np = std::min(np, cnt);
+                size_t nf = std::min(cnt - np, full.size() - fi);
+                np = cnt - nf;                                                          // (whatever the full list cannot cover)
+                for (size_t i = 0; i < nf; ++i) out.push_back(full[fi++]);
+                for (size_t i = 0; i < np && pi < part.size(); ++i) out.push_back(part[pi++]);
+            }
+            while (fi < full.size()) out.push_back(full[fi++]);                         // (rounding leftovers, if any)
+            while (pi < part.size()) out.push_back(part[pi++]);
+            if (out.size() == n) tiles.swap(out);
+        }
+    }
     // Few blocks (one scene alone: ceil(T/128)*8 ~ 100 for 256 CUs): cut every block's key range into `parts`
     // pieces so that about two rounds of 512 resident blocks exist; each piece keeps at least two key tiles.
     std::vector<int4> krange;
