@@ -63,7 +63,7 @@ def main(sq, fetch, write, out, l2=None):
         m = re.search(r"vlsat::(\w+?)(_kernel)?(<|$)", name)
         key = m.group(1) if m else name
         key = {"layernorm512": "layernorm512", "row_invnorm512": "misc", "desc_tail": "misc", "edge_embed": "misc",
-               "dist_bias": "misc", "gemm_ring": "gemm_f32", "gemm_splitk": "gemm_f32", "flash_attn_bf16": "flash_attn_f32",
+               "dist_bias": "misc", "gemm_ring": "gemm_f32", "gemm_p8": "gemm_f32", "gemm_splitk": "gemm_f32", "flash_attn_bf16": "flash_attn_f32",
                "flash_merge": "flash_attn_f32", "pointnet_bf16": "pointnet", "edge_gate_bf16": "edge_gate",
                "edge_gate_generic": "edge_gate", "node_attn_split": "node_attn"}.get(key, key)     # bench.py's class names
         d = cls.setdefault(key, {"launches": 0, "hbm_read_bytes": 0.0, "hbm_write_bytes": 0.0, "kernel_ns": 0.0})
