@@ -46,13 +46,16 @@ __global__ __launch_bounds__(256, 2) void edge_gate_kernel(GateArgs p) {
     for (int r = 0; r < 16; ++r) b3f[r] = p.b3[crow32(r, hi)];
     __syncthreads();
 
-    const int n_groups = (p.n_edges + 15) / 16;
-    for (int g = blockIdx.x; g < n_groups; g += gridDim.x) {
+    // Work unit = 32 consecutive edges x 4 heads: a wave's 32 rows are 32 EDGES of ONE head (head = 4 (unit & 1) + wave).
+    // Edge lists are source-major (reference dataset_3dssg.py:264-266), so the 32 lanes of a Gq load mostly name the same
+    // node row: one cache line per instruction instead of 32 (row_map = 0: the older 4 edges x 8 heads per wave).
+    const int n_units = 2 * ((p.n_edges + 31) / 32);
+    for (int g = blockIdx.x; g < n_units; g += gridDim.x) {
         // the weight fragments are loop-invariant; without this clobber LICM hoists all 192 of
         // them into VGPRs and the kernel spills.  Re-reading them from LDS per step is free.
         asm volatile("" ::: "memory");
-        const int e_raw = g * 16 + wave * 4 + (li >> 3);
-        const int h = li & 7;
+        const int e_raw = p.row_map ? (g >> 1) * 32 + li : g * 16 + wave * 4 + (li >> 3);
+        const int h = p.row_map ? (g & 1) * 4 + wave : li & 7;
         const bool valid = e_raw < p.n_edges;
         const int e = valid ? e_raw : p.n_edges - 1;
         const float* zrow = p.kproj + (size_t)e * 512 + h * 64 + 4 * hi;
@@ -190,7 +193,7 @@ int launch_edge_gate_generic(const GateArgs& a, int n_heads, int dk, int dox, hi
 int launch_edge_gate(const GateArgs& a, hipStream_t s) {
     if (a.n_edges <= 0) return 0;
     if ((a.ld_node & 3) || (a.gq_off & 3) || (a.v_off & 3)) return fail(-1, "edge_gate: ld_node/gq_off/v_off must be multiples of 4");
-    const int n_groups = (a.n_edges + 15) / 16;
+    const int n_groups = a.row_map ? 2 * ((a.n_edges + 31) / 32) : (a.n_edges + 15) / 16;
     // persistent: 3 blocks per CU are resident (51.7 KB LDS each); every block stages the weights once
     // and walks ~n_groups/768 groups, so there is no partial last wave of blocks
     const int cap = a.grid_cap > 0 ? a.grid_cap : 768;

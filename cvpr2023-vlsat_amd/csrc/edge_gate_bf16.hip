@@ -53,11 +53,14 @@ __global__ __launch_bounds__(256, 2) void edge_gate_bf16_kernel(GateArgs p) {
     __syncthreads();
 
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    const int n_groups = (p.n_edges + 15) / 16;
-    for (int g = blockIdx.x; g < n_groups; g += gridDim.x) {
+    // Work unit = 32 consecutive edges x 4 heads: a wave's 32 rows are 32 EDGES of ONE head (head = 4 (unit & 1) + wave).
+    // Edge lists are source-major (reference dataset_3dssg.py:264-266), so the 32 lanes of a Gq load mostly name the same
+    // node row: one cache line per instruction instead of 32 (row_map = 0: the older 4 edges x 8 heads per wave).
+    const int n_units = 2 * ((p.n_edges + 31) / 32);
+    for (int g = blockIdx.x; g < n_units; g += gridDim.x) {
         asm volatile("" ::: "memory");                    // keep the weight fragments out of LICM's hands (edge_gate.hip)
-        const int e_raw = g * 16 + wave * 4 + (li >> 3);
-        const int h = li & 7;
+        const int e_raw = p.row_map ? (g >> 1) * 32 + li : g * 16 + wave * 4 + (li >> 3);
+        const int h = p.row_map ? (g & 1) * 4 + wave : li & 7;
         const bool valid = e_raw < p.n_edges;
         const int e = valid ? e_raw : p.n_edges - 1;
         // ---- this row's kproj values: k-slot (hi, e) of step ks is c = 16 ks + 8 hi + e ----
@@ -182,7 +185,7 @@ int launch_edge_gate_bf16(const GateArgs& a, int terms, int kproj_split, hipStre
     if (a.n_edges <= 0) return 0;
     if ((a.ld_node & 3) || (a.gq_off & 3) || (a.v_off & 3)) return fail(-1, "edge_gate: ld_node/gq_off/v_off must be multiples of 4");
     if (terms != 1 && terms != 3) return fail(-1, "edge_gate_bf16: terms must be 1 or 3");
-    const int n_groups = (a.n_edges + 15) / 16;
+    const int n_groups = a.row_map ? 2 * ((a.n_edges + 31) / 32) : (a.n_edges + 15) / 16;
     const int cap = a.grid_cap > 0 ? a.grid_cap : 768;            // persistent grid (weights staged once per block)
     const int grid = n_groups < cap ? n_groups : cap;
 #define VLSAT_GB(T, K) hipLaunchKernelGGL((edge_gate_bf16_kernel<T, K>), dim3(grid), dim3(256), 0, s, a)

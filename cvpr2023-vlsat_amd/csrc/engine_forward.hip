@@ -157,7 +157,7 @@ int gcn_block(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const GcnW& w, float
         GateArgs g{};
         g.kproj = sc.KP; g.node = sc.NP; g.ld_node = NPC; g.gq_off = 4 * D; g.v_off = 6 * D;    // Gq spans H * 2 d_k = 2 D columns
         g.src = p->d_src; g.dst = p->d_dst; g.w0k = w.w0k; g.w3 = w.w3; g.b3 = w.b3; g.gated = sc.G;
-        g.prob = p->prob; g.n_edges = E; g.use_edge = h->d.use_gcn_edge; g.grid_cap = h->gate_grid;
+        g.prob = p->prob; g.n_edges = E; g.use_edge = h->d.use_gcn_edge; g.grid_cap = h->gate_grid; g.row_map = h->gate_row_map;
         const double dk = D / h->H, dox = A / h->H;
         Scope scope(h, s, PC_GATE, (double)E * h->H * (2.0 * dk * 2 * dk + 2.0 * 2 * dk * dox));
         if (!default_heads(h)) RUN(launch_edge_gate_generic(g, h->H, D / h->H, A / h->H, s));

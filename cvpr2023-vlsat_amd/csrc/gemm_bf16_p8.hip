@@ -73,7 +73,9 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmArgs p, int n_tiles
     typedef short s16x8 __attribute__((ext_vector_type(8)));
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    constexpr bool SPREAD = ADD == 0;             // epilogue strips 2 / 3 inside the next tile's first K-tile
+    constexpr bool SPREAD = ADD == 0 || (ABL & 1024);   // epilogue strips 2 / 3 inside the next tile's first K-tile
+    // (ABL bits 8..10, gathered-row launches: 256 = the init loads in a row-contiguous lane pattern, 512 = no init loads,
+    //  1024 = no init loads and the spread epilogue)
     constexpr int E = CF == 2 ? 4 : 8;            // buffer stores per epilogue strip and lane
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -450,7 +452,23 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmArgs p, int n_tiles
         const int v = tile_of_round(round);
         if (v >= n_tiles) break;
         const int m0 = (v / nbn) * P8_BM;
-        if (ADD != 0) tile_init<4, 2, ADD, F32>(p, m0, n0, wr, wc, lane, acc);   // (PLAIN only for fp32: formats fold away)
+        if (ADD == 6 && (ABL & 256)) {
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int row = m0 + wr * 128 + tm * 32 + g * 8 + (lane >> 3);
+                    const float* r0 = p.g0 + (size_t)p.gi0[row] * p.ldg0 + n0 + wc * 64 + (lane & 7) * 4;
+                    const float* r1 = p.g1 + (size_t)p.gi1[row] * p.ldg1 + n0 + wc * 64 + (lane & 7) * 4;
+#pragma unroll
+                    for (int tn = 0; tn < 2; ++tn) {
+                        const f32x4 x = *reinterpret_cast<const f32x4*>(r0 + tn * 32) + *reinterpret_cast<const f32x4*>(r1 + tn * 32);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) acc[tm][tn][4 * g + c] = x[c];
+                    }
+                }
+        } else if (ADD != 0 && !(ABL & (512 | 1024)))
+            tile_init<4, 2, ADD, F32>(p, m0, n0, wr, wc, lane, acc);   // (PLAIN only for fp32: formats fold away)
         if (SPREAD && round > 0) {                   // strips 2 / 3 of the previous tile go out under this tile's first phases
             ktile(B0{}, std::integral_constant<int, P8_FIRST>{}, pm0);
             ktile(B1{}, std::integral_constant<int, P8_SECOND>{}, pm0);
@@ -514,6 +532,12 @@ int launch_gemm_p8(const GemmArgs& a, int n_tiles, int grid, hipStream_t s) {
             case 25: VLSAT_P8(2, 6, false, 1); break;
             case 27: VLSAT_P8(2, 6, true, 1); break;
             default: return 1;
+        }
+    } else if (a.ablate && key == 27) {               // timing experiments on the gathered-row launch
+        switch (a.ablate) {
+            case 1: hipLaunchKernelGGL((gemm_p8_kernel<0, 6, true, 2, 256>), dim3(grid), dim3(512), 0, s, a, n_tiles, nbn); break;
+            case 2: hipLaunchKernelGGL((gemm_p8_kernel<0, 6, true, 2, 512>), dim3(grid), dim3(512), 0, s, a, n_tiles, nbn); break;
+            default: hipLaunchKernelGGL((gemm_p8_kernel<0, 6, true, 2, 1024>), dim3(grid), dim3(512), 0, s, a, n_tiles, nbn); break;
         }
     } else if (a.ablate && key == 1) {                // timing experiments (tools/p8_check.py --ablate)
         switch (a.ablate) {

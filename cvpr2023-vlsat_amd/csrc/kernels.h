@@ -145,6 +145,7 @@ struct GateArgs {
     int n_edges;
     int use_edge = 1;        // MODEL.USE_GCN_EDGE: 0 -> the gate MLP sees the query alone (kproj / w0k unused)
     int grid_cap = 0;        // debug: persistent grid size (0 = 3 blocks per CU; vlsat_debug_option "gate_grid")
+    int row_map = 1;         // rows of a wave: 1 = 32 edges of one head, 0 = 4 edges x 8 heads (vlsat_debug_option "gate_row_map")
 };
 int launch_edge_gate(const GateArgs& a, hipStream_t s);
 // any head geometry (dk query / edge channels per head, dox output channels per head): plain VALU

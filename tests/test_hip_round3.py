@@ -125,3 +125,21 @@ def test_create_rejects_dim_atten_the_gemms_cannot_run():
     h = C.c_void_p()
     assert lib.vlsat_create(C.byref(dims), C.byref(h)) != 0
     assert b"DIM_ATTEN" in lib.vlsat_last_error()
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3", "bf16_mixed"])
+def test_gate_row_mappings_give_identical_bits(mode):
+    """The gate kernels give a wave 32 edges of one head (Gq loads of source-major edge lists hit one cache line) where they
+    used to give it 4 edges x 8 heads: a row's products and sums do not depend on which lane owns it, so the two mappings
+    must agree bit for bit -- on a ragged batch whose edge counts are no multiple of 32."""
+    cfg = VLSATConfig(N_LAYERS=2)
+    m = _model(cfg, synth.make_weights(cfg)).set_gemm_precision(mode)
+    try:
+        b = synth.collate([synth.make_scene(n, 64, 3000 + n) for n in (9, 14, 5, 23)])
+        new = _run(m, b)
+        m.debug_option("gate_row_map", 0)
+        old = _run(m, b)
+        for n, a, c in zip(NAMES, new, old):
+            assert torch.equal(a, c), (mode, n, float((a - c).abs().max()))
+    finally:
+        m.close()

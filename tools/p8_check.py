@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--rows", type=int, default=99840)
     ap.add_argument("--only", default="", help="substring of the shape names to run")
+    ap.add_argument("--structured", action="store_true", help="gather indices of the bench batch instead of random ones")
     ap.add_argument("--ablate", action="store_true", help="time the kernel with loads / MFMAs / fragment reads removed (first shape)")
     a = ap.parse_args()
     lib = L.load()
@@ -56,6 +57,13 @@ def main():
         G0 = torch.randn(NG, 2 * N, generator=g).to(DEV) if gather else None
         gi0 = torch.randint(0, NG, (M,), generator=g, dtype=torch.int32).to(DEV) if gather else None
         gi1 = torch.randint(0, NG, (M,), generator=g, dtype=torch.int32).to(DEV) if gather else None
+        if gather and a.structured:           # the bench batch: scenes of 40 objects, every ordered pair, source-major
+            n = 40
+            i, j = torch.meshgrid(torch.arange(n), torch.arange(n), indexing="ij")
+            keep = i != j
+            src = torch.cat([i[keep] + n * s for s in range(M // (n * (n - 1)))])
+            dst = torch.cat([j[keep] + n * s for s in range(M // (n * (n - 1)))])
+            gi0, gi1 = src.int().to(DEV), dst.int().to(DEV)
         hi = torch.empty(N * K + 128, dtype=torch.int16, device=DEV)
         lo = torch.empty_like(hi)
         L.check(lib.vlsat_k_split_bf16(W.data_ptr(), N * K, hi.data_ptr(), lo.data_ptr(), L.stream_ptr()))
@@ -99,6 +107,9 @@ def main():
                          ("-epi", fmt | ab(8)), ("bars", fmt | ab(15)),
                          ("mfma+bars", fmt | ab(5)), ("mfma+B1", fmt | ab(21)), ("mfma nobar", fmt | ab(37)), ("full-B2", fmt | ab(16)),
                          ("-ld rd-nowait", fmt | ab(65)), ("rd-nowait", fmt | ab(64)), ("noprio", fmt | ab(128)), ("-ld noprio", fmt | ab(129))]
+        if a.ablate and gather:
+            ab = lambda bits: ((bits & 3) << 8) | (((bits >> 2) & 63) << 13)
+            variants += [("row-contiguous init loads", fmt | ab(1)), ("no init loads", fmt | ab(2)), ("no init loads, spread epilogue", fmt | ab(3))]
         for tag, f in variants:
             for _ in range(3):
                 run(f)
