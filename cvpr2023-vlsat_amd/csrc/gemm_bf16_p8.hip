@@ -296,8 +296,17 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmArgs p, int n_tiles
     const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)(((size_t)(p.M - 1) * p.ldc + p.N) * 4), 0x00020000);
     const float cs = p.c_scale;
     const float act_lo = p.act == ACT_RELU ? 0.f : -__builtin_inff();
-    auto epi = [&](auto tmc, int m0) {
+    // ACTV (wave-uniform, picked once per strip): 0 = no output activation and c_scale 1, 1 = ReLU and c_scale 1, 2 = the
+    // general form.  The first two are what the forward launches; they drop the max / multiply per element (the compiler
+    // needs two v_max per fmaxf on values it cannot prove canonical), and the half-row ReLU runs on packed bf16 pairs.
+    const int actv = __builtin_amdgcn_readfirstlane(cs != 1.f ? 2 : p.act == ACT_RELU ? 1 : 0);
+    auto relu1 = [](float x) { float y; asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x)); return y; };
+    auto epi_t = [&](auto tmc, auto actc, int m0) __attribute__((always_inline)) {
         constexpr int TM = decltype(tmc)::value;
+        constexpr int ACTV = decltype(actc)::value;
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        typedef short s16x2 __attribute__((ext_vector_type(2)));
         const unsigned srow = (unsigned)(m0 + wr * 128 + TM * 32) * ldc4 + (unsigned)(n0 + wc * 64) * (CF == 2 ? 2u : 4u);
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn) {
@@ -308,34 +317,48 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmArgs p, int n_tiles
                 for (int c = 0; c < 4; ++c) v[c] = acc[TM][tn][4 * g + c];
                 if (!WORDS) {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], act_lo) * cs;      // (branch-free: ReLU or max with -inf)
+                    for (int c = 0; c < 4; ++c) {
+                        if (ACTV == 2) v[c] = fmaxf(v[c], act_lo) * cs;      // (branch-free: ReLU or max with -inf)
+                        else if (ACTV == 1 && CF != 2) v[c] = relu1(v[c]);
+                    }
                 }
                 if (CF == 2) {
+                    s16x2 w0 = __builtin_bit_cast(s16x2, __builtin_convertvector((f32x2{v[0], v[1]}), bf16x2));
+                    s16x2 w1 = __builtin_bit_cast(s16x2, __builtin_convertvector((f32x2{v[2], v[3]}), bf16x2));
+                    if (ACTV == 1) {          // ReLU after the rounding: the same values (rounding keeps the sign; -0 becomes +0)
+                        w0 = __builtin_elementwise_max(w0, s16x2{0, 0});
+                        w1 = __builtin_elementwise_max(w1, s16x2{0, 0});
+                    }
                     u32x2 w;
-                    w.x = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v[0]) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)v[1]) << 16);
-                    w.y = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v[2]) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)v[3]) << 16);
+                    w.x = __builtin_bit_cast(unsigned, w0);
+                    w.y = __builtin_bit_cast(unsigned, w1);
                     *reinterpret_cast<u32x2*>(tbuf + t_wr + (((tn * 4 + g) << 4) ^ t_x)) = w;
                 } else {
                     *reinterpret_cast<f32x4*>(tbuf + t_wr + (((2 * g + hi) << 4) ^ t_x)) = v;
                 }
             }
             if (CF != 2 || tn == 1) {          // the buffer holds 32 rows x 128 bytes: both n-tiles (bf16) or one (fp32)
+                u32x4 rj[4];                   // (all four reads in flight before the first store waits for its data)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) rj[j] = *reinterpret_cast<const u32x4*>(tbuf + t_rd + j * 1024);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    u32x4 r = *reinterpret_cast<const u32x4*>(tbuf + t_rd + j * 1024);
+                    u32x4 r = rj[j];
                     if (WORDS) {               // lane: row 8j + (l >> 3), columns tn*32 + 4 (l & 7) .. +3
                         f32x4 x = __builtin_bit_cast(f32x4, r) + biasr[tn];
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
-                            x[c] = fmaxf(x[c], act_lo);
-                            if (X3) x[c] *= cs;
+                            if (ACTV == 2) {
+                                x[c] = fmaxf(x[c], act_lo);
+                                if (X3) x[c] *= cs;
+                            } else if (ACTV == 1) {
+                                x[c] = relu1(x[c]);
+                            }
                         }
                         r = __builtin_bit_cast(u32x4, x);
                         if (CF == 1) {         // split pairs (common.h pack_split), two elements at a time
 #pragma unroll
                             for (int c = 0; c < 4; c += 2) {
-                                typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-                                typedef float f32x2 __attribute__((ext_vector_type(2)));
                                 const f32x2 v2 = {x[c], x[c + 1]};
                                 const bf16x2 h2 = __builtin_convertvector(v2, bf16x2);
                                 const bf16x2 l2 = __builtin_convertvector(v2 - __builtin_convertvector(h2, f32x2), bf16x2);
@@ -357,6 +380,11 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmArgs p, int n_tiles
                 }
             }
         }
+    };
+    auto epi = [&](auto tmc, int m0) __attribute__((always_inline)) {     // (not inlined = the accumulators live in scratch)
+        if (actv == 0) epi_t(tmc, std::integral_constant<int, 0>{}, m0);
+        else if (actv == 1) epi_t(tmc, std::integral_constant<int, 1>{}, m0);
+        else epi_t(tmc, std::integral_constant<int, 2>{}, m0);
     };
 
     // ---- prologue: the six half-tiles whose staging phase lies before the first compute phase ----
