@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--rows", type=int, default=99840)
     ap.add_argument("--only", default="", help="substring of the shape names to run")
+    ap.add_argument("--cold", type=int, default=1, help="cycle through this many copies of A and C (4: nothing a launch reads is in a cache)")
     ap.add_argument("--structured", action="store_true", help="gather indices of the bench batch instead of random ones")
     ap.add_argument("--ablate", action="store_true", help="time the kernel with loads / MFMAs / fragment reads removed (first shape)")
     a = ap.parse_args()
@@ -70,8 +71,14 @@ def main():
         fmt = HALF | HALF_A | (HALF_C if c_half else 0) | (HALF_R if resid else 0)
         C = torch.empty(M, N, device=DEV)
 
+        As = [Ah] + [Ah.clone() for _ in range(a.cold - 1)]
+        Cs = [C] + [torch.empty_like(C) for _ in range(a.cold - 1)]
+        turn = [0]
+
         def run(f):
-            L.check(lib.vlsat_k_gemm_planes(Ah.data_ptr(), K, W.data_ptr(), hi.data_ptr(), lo.data_ptr(), K, C.data_ptr(), N, M, N, K,
+            turn[0] += 1
+            Ax, Cx = As[turn[0] % a.cold], Cs[turn[0] % a.cold]
+            L.check(lib.vlsat_k_gemm_planes(Ax.data_ptr(), K, W.data_ptr(), hi.data_ptr(), lo.data_ptr(), K, Cx.data_ptr(), N, M, N, K,
                                             b.data_ptr(), L.ptr(R), N if resid else 0, 0.5,
                                             L.ptr(G0), L.ptr(gi0), 2 * N if gather else 0,
                                             (G0.data_ptr() + 4 * N) if gather else 0, L.ptr(gi1), 2 * N if gather else 0,
