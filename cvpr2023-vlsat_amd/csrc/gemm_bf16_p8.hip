@@ -73,9 +73,8 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmArgs p, int n_tiles
     typedef short s16x8 __attribute__((ext_vector_type(8)));
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    constexpr bool SPREAD = ADD == 0 || (ABL & 1024);   // epilogue strips 2 / 3 inside the next tile's first K-tile
-    // (ABL bits 8..10, gathered-row launches: 256 = the init loads in a row-contiguous lane pattern, 512 = no init loads,
-    //  1024 = no init loads and the spread epilogue)
+    constexpr bool SPREAD = ADD == 0;             // epilogue strips 2 / 3 inside the next tile's first K-tile
+    // (ABL bits 8, 9, gathered-row launches: 256 = the init loads in a row-contiguous lane pattern, 512 = no init loads)
     constexpr int E = CF == 2 ? 4 : 8;            // buffer stores per epilogue strip and lane
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -495,7 +494,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmArgs p, int n_tiles
                         for (int c = 0; c < 4; ++c) acc[tm][tn][4 * g + c] = x[c];
                     }
                 }
-        } else if (ADD != 0 && !(ABL & (512 | 1024)))
+        } else if (ADD != 0 && !(ABL & 512))
             tile_init<4, 2, ADD, F32>(p, m0, n0, wr, wc, lane, acc);   // (PLAIN only for fp32: formats fold away)
         if (SPREAD && round > 0) {                   // strips 2 / 3 of the previous tile go out under this tile's first phases
             ktile(B0{}, std::integral_constant<int, P8_FIRST>{}, pm0);
@@ -564,8 +563,7 @@ int launch_gemm_p8(const GemmArgs& a, int n_tiles, int grid, hipStream_t s) {
     } else if (a.ablate && key == 27) {               // timing experiments on the gathered-row launch
         switch (a.ablate) {
             case 1: hipLaunchKernelGGL((gemm_p8_kernel<0, 6, true, 2, 256>), dim3(grid), dim3(512), 0, s, a, n_tiles, nbn); break;
-            case 2: hipLaunchKernelGGL((gemm_p8_kernel<0, 6, true, 2, 512>), dim3(grid), dim3(512), 0, s, a, n_tiles, nbn); break;
-            default: hipLaunchKernelGGL((gemm_p8_kernel<0, 6, true, 2, 1024>), dim3(grid), dim3(512), 0, s, a, n_tiles, nbn); break;
+            default: hipLaunchKernelGGL((gemm_p8_kernel<0, 6, true, 2, 512>), dim3(grid), dim3(512), 0, s, a, n_tiles, nbn); break;
         }
     } else if (a.ablate && key == 1) {                // timing experiments (tools/p8_check.py --ablate)
         switch (a.ablate) {

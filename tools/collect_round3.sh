@@ -16,10 +16,14 @@ python tools/gemm_bench.py --only E > "$OUT/gemm_fp32.txt" 2>&1
 python tools/gemm_bench.py --only E --no-p8 > "$OUT/gemm_fp32_no_p8.txt" 2>&1
 python tools/p8_check.py --no-check > "$OUT/gemm_bf16_half.txt" 2>&1
 python tools/p8_check.py --no-check --ablate --rows 98304 --only kproj > "$OUT/gemm_p8_ablation.txt" 2>&1
+python tools/p8_check.py --no-check --ablate --rows 98304 --only kproj --cold 6 --iters 300 > "$OUT/gemm_p8_ablation_cold.txt" 2>&1
+python tools/p8_check.py --no-check --rows 98304 --cold 6 --iters 300 > "$OUT/gemm_bf16_half_cold.txt" 2>&1
+python tools/p8_check.py --no-check --ablate --only gather > "$OUT/gemm_p8_gather_ablation.txt" 2>&1
+python tools/p8_check.py --no-check --ablate --only gather --structured >> "$OUT/gemm_p8_gather_ablation.txt" 2>&1
 python tools/gemm_bench.py --prec 3 --only E --fmt 5 > "$OUT/gemm_bf16x3.txt" 2>&1
 python tools/gemm_bench.py --prec 3 --only E --fmt 4101 > "$OUT/gemm_bf16x3_no_p8.txt" 2>&1
 python tools/latency_probe.py > "$OUT/latency_fp32.txt" 2>&1
 python tools/latency_probe.py --gemm-precision bf16x3 > "$OUT/latency_bf16x3.txt" 2>&1
 python tools/eval_synth.py > "$OUT/eval_synth.txt" 2>&1
-python -m pytest tests -q -m gpu 2>&1 | tail -3 > "$OUT/tests_gpu.log"
+python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -3 > "$OUT/tests_gpu.log"
 du -sh "$OUT"; ls "$OUT"

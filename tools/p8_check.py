@@ -116,7 +116,7 @@ def main():
                          ("-ld rd-nowait", fmt | ab(65)), ("rd-nowait", fmt | ab(64)), ("noprio", fmt | ab(128)), ("-ld noprio", fmt | ab(129))]
         if a.ablate and gather:
             ab = lambda bits: ((bits & 3) << 8) | (((bits >> 2) & 63) << 13)
-            variants += [("row-contiguous init loads", fmt | ab(1)), ("no init loads", fmt | ab(2)), ("no init loads, spread epilogue", fmt | ab(3))]
+            variants += [("row-contiguous init loads", fmt | ab(1)), ("no init loads", fmt | ab(2))]
         for tag, f in variants:
             for _ in range(3):
                 run(f)
