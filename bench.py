@@ -183,6 +183,8 @@ def main():
     ap.add_argument("--objects", type=int, default=40)
     ap.add_argument("--points", type=int, default=256)
     ap.add_argument("--layers", type=int, default=3)
+    ap.add_argument("--heads", type=int, default=8, help="MODEL.NUM_HEADS (4 | 8 | 16; not the headline configuration unless 8)")
+    ap.add_argument("--dim-atten", type=int, default=256, help="MODEL.DIM_ATTEN (128 | 256 | 512)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-extra", action="store_true",
@@ -214,7 +216,7 @@ def main():
         vdist.use_native_allreduce(rank, world)
     from vlsat_amd.model import VLSATModel
 
-    cfg = VLSATConfig(N_LAYERS=args.layers)
+    cfg = VLSATConfig(N_LAYERS=args.layers, NUM_HEADS=args.heads, DIM_ATTEN=args.dim_atten)
     model = VLSATModel(cfg, str(dev)).load_state(synth.make_weights(cfg)).eval()
     model.set_gemm_precision(args.gemm_precision)
     for kv in args.debug_option:
@@ -229,7 +231,7 @@ def main():
     run = timed_run(model, d, n_scenes, args.steps, args.warmup, prof, dev)
     dt, out, metrics, classes = run["dt"], run["out"], run["metrics"], run["classes"]
     rank_ms = vdist.minmax_over_ranks(run["local_ms"], dev)
-    default_wl = (args.scenes, args.objects, args.points, args.layers) == (64, 40, 256, 3)
+    default_wl = (args.scenes, args.objects, args.points, args.layers, args.heads, args.dim_atten) == (64, 40, 256, 3, 8, 256)
     evaluation, plain = None, None
     if not args.no_extra:                                # collectives: every rank takes part
         if prof:
@@ -325,7 +327,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"{('BASELINE configs[1]' if args.gemm_precision == 'fp32' else 'BASELINE configs[2]') if default_wl else 'custom'}: batch of {args.scenes} synthetic scenes per GPU, "
                                f"{args.objects} objects x {args.points} pts, fully-connected edges "
-                               f"(E={e_scene}/scene), {args.layers} GNN layers, {args.gemm_precision}",
+                               f"(E={e_scene}/scene), {args.layers} GNN layers, {args.gemm_precision}"
+                               + ("" if (args.heads, args.dim_atten) == (8, 256) else f", NUM_HEADS={args.heads}, DIM_ATTEN={args.dim_atten}"),
                    "scenes_per_gpu": args.scenes, "parallelism": f"scene-sharded x{world}"},
         "flop_per_scene_alg": falg,
         "metrics_allreduced": {k: float(v) for k, v in zip(vdist.METRIC_FIELDS, metrics.tolist())},

@@ -160,7 +160,11 @@ int gcn_block(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const GcnW& w, float
         g.prob = p->prob; g.n_edges = E; g.use_edge = h->d.use_gcn_edge; g.grid_cap = h->gate_grid; g.row_map = h->gate_row_map;
         const double dk = D / h->H, dox = A / h->H;
         Scope scope(h, s, PC_GATE, (double)E * h->H * (2.0 * dk * 2 * dk + 2.0 * 2 * dk * dox));
-        if (!default_heads(h)) RUN(launch_edge_gate_generic(g, h->H, D / h->H, A / h->H, s));
+        if (!default_heads(h)) {
+            int r = h->gate_heads_mfma ? launch_edge_gate_heads(g, h->H, D / h->H, A / h->H, s) : 1;
+            if (r < 0) return r;
+            if (r) RUN(launch_edge_gate_generic(g, h->H, D / h->H, A / h->H, s));
+        }
         else if (gate16) RUN(launch_edge_gate_bf16(g, h->prec_edge == 3 ? 3 : 1, S, s));
         else RUN(launch_edge_gate(g, s));
     }
@@ -444,15 +448,17 @@ static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const fl
                 FlashSplit sp;
                 sp.parts = p->fa_parts; sp.krange = p->d_krange; sp.o_part = p->fa_opart; sp.m_part = p->fa_m;
                 sp.l_part = p->fa_l; sp.part_stride = (size_t)E * D; sp.rows = E; sp.heads = h->H;
-                if (D / h->H != 64)          // generic head dim: VALU attention over the scenes' edge ranges (no bias)
+                const int dh = D / h->H;
+                if (dh != 32 && dh != 64 && dh != 128)   // any other head dim: VALU attention over the scenes' edge ranges (no bias)
                     RUN(launch_node_attn(p->Qe, D, p->KVe, 2 * D, p->KVe + D, 2 * D, p->Oe, D, nullptr, p->d_edge_ptr32, nullptr,
                                          h->edge_scope == 1 ? 1 : p->S, h->edge_scope == 1 ? E : p->max_e, h->H, D / h->H,
                                          1.f / std::sqrt((float)(D / h->H)), s, h->node_attn_split));
-                else if (h->prec_edge && h->flash_bf16)
+                else if (h->prec_edge && h->flash_bf16 && dh == 64)
                     RUN(launch_flash_attn_bf16(p->Qe, D, p->KVe, p->KVe + (S == 2 ? D / 2 : D), 2 * D, p->Oe, D, p->d_tiles, p->n_tiles,
                                                sc2e, h->prec_edge == 3 ? 3 : 1, h->flash_tr, S, s, &sp, h->flash_pv_terms));    // (half rows: V starts at byte 2 D)
                 else
-                    RUN(launch_flash_attn(p->Qe, D, p->KVe, p->KVe + D, 2 * D, p->Oe, D, p->d_tiles, p->n_tiles, sc2e, s, &sp));
+                    RUN(launch_flash_attn(p->Qe, D, p->KVe, p->KVe + D, 2 * D, p->Oe, D, p->d_tiles, p->n_tiles,
+                                          (1.f / std::sqrt((float)dh)) * 1.4426950408889634f, s, &sp, dh));   // (head dims 32 / 128: NUM_HEADS 16 / 4)
             }
             // out-projection + residual, then LayerNorm (+ inter-layer ReLU).  Split format: the GEMM reads O and the
             // residual as hi/lo pairs and writes plain fp32 into the (now dead) Q buffer; the LayerNorm packs E2 again.

@@ -30,14 +30,17 @@
 namespace vlsat {
 
 constexpr int FA_KV = 32;        // keys per tile
-constexpr int FA_D = 64;         // head dim
-constexpr int FA_PITCH = 68;     // LDS row pitch (floats): 16-B pad -> conflict-free b128 reads
 
+// FA_D: head dim = 512 / MODEL.NUM_HEADS (reference network_MMG.py:48-50): 64 as shipped (8 heads), 32 (16 heads) or 128
+// (4 heads).  A lane holds FA_D / 2 query values and FA_D / 32 output accumulators; everything else is the same kernel.
+template <int FA_D>
 __global__ __launch_bounds__(256, 2) void flash_attn_f32_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
     float* __restrict__ O, int ldq, int ldkv, int ldo, const int4* __restrict__ tiles, int n_tiles,
     float scale_log2e, FlashSplit sp) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * 2 * FA_KV * FA_PITCH];   // [buf][K|V][32][68]
+    constexpr int FA_PITCH = FA_D + 4;   // LDS row pitch (floats): 16-B pad -> conflict-free b128 reads
+    constexpr int HD = FA_D / 2, NO = FA_D / 32, NS = FA_D / 32;     // query values per lane, output blocks, staged float4 per thread and operand
+    __shared__ __attribute__((aligned(16))) float smem[2 * 2 * FA_KV * FA_PITCH];   // [buf][K|V][32][FA_D + 4]
     constexpr int BUF = 2 * FA_KV * FA_PITCH;
 
     const int tile_id = xcd_remap(blockIdx.x, n_tiles);
@@ -49,36 +52,39 @@ __global__ __launch_bounds__(256, 2) void flash_attn_f32_kernel(
     const int li = lane & 31, hi = lane >> 5;
     const size_t col0 = (size_t)head * FA_D;
 
-    // ---- this lane's query row: d = 32*hi + s, s = 0..31 (pre-scaled) ----
+    // ---- this lane's query row: d = HD*hi + s, s = 0..HD-1 (pre-scaled) ----
     // A wave whose 32 query rows are all past the scene's token count still helps staging K/V
     // but issues no MFMA (the last 128-row block of a scene is usually mostly empty:
     // 1560 = 12*128 + 24), leaving the matrix pipe to the other resident blocks.
     const bool wave_active = q0 + wave * 32 < n_tok;
     int qrow = q0 + wave * 32 + li;
     if (qrow >= n_tok) qrow = n_tok - 1;      // clamped rows are computed but never stored
-    float q[32];
+    float q[HD];
     {
-        const float* qp = Q + (size_t)(row_base + qrow) * ldq + col0 + 32 * hi;
+        const float* qp = Q + (size_t)(row_base + qrow) * ldq + col0 + HD * hi;
 #pragma unroll
-        for (int g = 0; g < 8; ++g) {
+        for (int g = 0; g < HD / 4; ++g) {
             const f32x4 x = *reinterpret_cast<const f32x4*>(qp + 4 * g);
 #pragma unroll
             for (int c = 0; c < 4; ++c) q[4 * g + c] = x[c] * scale_log2e;
         }
     }
 
-    f32x16 o0, o1;
+    f32x16 o[NO];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    for (int b = 0; b < NO; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[b][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
-    // staging: K and V tile each [32][64] = 512 float4; thread -> rows (tid>>4) and +16
-    const int srow = tid >> 4, sc4 = (tid & 15) * 4;
-    f32x4 rk[2], rv[2];
+    // staging: K and V tile each [32][FA_D] = 8 FA_D float4; thread -> column chunk tid % C4 of rows tid / C4 + RS i
+    constexpr int C4 = FA_D / 4, RS = 256 / C4;  // float4 per row; rows covered by one pass of the 256 threads
+    const int srow = tid / C4, sc4 = (tid % C4) * 4;
+    f32x4 rk[NS], rv[NS];
     auto load_tile = [&](int kv0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int r = kv0 + srow + 16 * i;
+        for (int i = 0; i < NS; ++i) {
+            int r = kv0 + srow + RS * i;
             r = r < n_tok ? r : n_tok - 1;
             const size_t off = (size_t)(row_base + r) * ldkv + col0 + sc4;
             rk[i] = *reinterpret_cast<const f32x4*>(K + off);
@@ -87,9 +93,9 @@ __global__ __launch_bounds__(256, 2) void flash_attn_f32_kernel(
     };
     auto store_tile = [&](float* buf) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            *reinterpret_cast<f32x4*>(buf + (srow + 16 * i) * FA_PITCH + sc4) = rk[i];
-            *reinterpret_cast<f32x4*>(buf + FA_KV * FA_PITCH + (srow + 16 * i) * FA_PITCH + sc4) = rv[i];
+        for (int i = 0; i < NS; ++i) {
+            *reinterpret_cast<f32x4*>(buf + (srow + RS * i) * FA_PITCH + sc4) = rk[i];
+            *reinterpret_cast<f32x4*>(buf + FA_KV * FA_PITCH + (srow + RS * i) * FA_PITCH + sc4) = rv[i];
         }
     };
 
@@ -113,8 +119,8 @@ __global__ __launch_bounds__(256, 2) void flash_attn_f32_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            const f32x4 kf = *reinterpret_cast<const f32x4*>(sK + li * FA_PITCH + 32 * hi + 4 * g);
+        for (int g = 0; g < HD / 4; ++g) {
+            const f32x4 kf = *reinterpret_cast<const f32x4*>(sK + li * FA_PITCH + HD * hi + 4 * g);
 #pragma unroll
             for (int c = 0; c < 4; ++c)
                 s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[c], q[4 * g + c], s, 0, 0, 0);
@@ -146,14 +152,16 @@ __global__ __launch_bounds__(256, 2) void flash_attn_f32_kernel(
         // first few key tiles this skips 32 multiplies per tile for the whole wave without changing a bit)
         if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+            for (int b = 0; b < NO; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[b][r] *= alpha;
         }
         // ---- O^T[d][query] += sum_key V[key][d] * P[key][query] ----
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float* vp = sV + crow32(r, hi) * FA_PITCH + li;
-            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[0], s[r], o0, 0, 0, 0);
-            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[32], s[r], o1, 0, 0, 0);
+#pragma unroll
+            for (int b = 0; b < NO; ++b) o[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[32 * b], s[r], o[b], 0, 0, 0);
         }
         }   // wave_active
         if (more) store_tile(smem + ((kt + 1) & 1) * BUF);
@@ -173,17 +181,16 @@ __global__ __launch_bounds__(256, 2) void flash_attn_f32_kernel(
             sp.l_part[i] = l_run;
         }
     }
-    float* so = smem + wave * (32 * FA_PITCH);     // 4 x 8704 B = all of smem
+    float* so = smem + wave * (32 * FA_PITCH);     // 4 x 32 rows = all of smem
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        so[li * FA_PITCH + crow32(r, hi)] = o0[r] * inv_l;
-        so[li * FA_PITCH + 32 + crow32(r, hi)] = o1[r] * inv_l;
-    }
+    for (int b = 0; b < NO; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) so[li * FA_PITCH + 32 * b + crow32(r, hi)] = o[b][r] * inv_l;
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int idx = lane + 64 * i;             // 512 float4 = 32 rows x 16
-        const int r = idx >> 4, c4 = (idx & 15) * 4;
+    for (int i = 0; i < FA_D / 8; ++i) {
+        const int idx = lane + 64 * i;             // 8 FA_D float4 = 32 rows x FA_D / 4
+        const int r = idx / C4, c4 = (idx % C4) * 4;
         const int qr = q0 + wave * 32 + r;
         if (qr < n_tok)
             *reinterpret_cast<f32x4*>(O + (size_t)(row_base + qr) * ldo + col0 + c4) =
@@ -192,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_f32_kernel(
 }
 
 // O[row, h*64 + d] = sum_p 2^(m_p - m) O_p[row, h*64 + d] / sum_p 2^(m_p - m) l_p,  m = max_p m_p  (per row, head)
-__global__ __launch_bounds__(256) void flash_merge_kernel(float* __restrict__ O, int ldo, FlashSplit sp, int out_split) {
+__global__ __launch_bounds__(256) void flash_merge_kernel(float* __restrict__ O, int ldo, FlashSplit sp, int out_split, int FA_D) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;       // one float4 of one row
     const int per_row = sp.heads * (FA_D / 4);
     const size_t row = idx / per_row;
@@ -227,8 +234,10 @@ __global__ __launch_bounds__(256) void flash_merge_kernel(float* __restrict__ O,
 }
 
 int launch_flash_attn(const float* Q, int ldq, const float* K, const float* V, int ldkv, float* O, int ldo,
-                      const int4* tiles, int n_tiles, float scale_log2e, hipStream_t s, const FlashSplit* split) {
+                      const int4* tiles, int n_tiles, float scale_log2e, hipStream_t s, const FlashSplit* split, int head_dim) {
     if (n_tiles <= 0) return 0;
+    const int FA_D = head_dim;
+    if (FA_D != 32 && FA_D != 64 && FA_D != 128) return fail(-1, "flash_attn: head dim must be 32, 64 or 128");
     if ((ldq | ldkv | ldo) & 3) return fail(-1, "flash_attn: leading dims must be multiples of 4");
     FlashSplit sp{};
     if (split && split->parts > 1) {
@@ -236,16 +245,21 @@ int launch_flash_attn(const float* Q, int ldq, const float* K, const float* V, i
         if (!sp.krange || !sp.o_part || !sp.m_part || !sp.l_part || sp.heads * FA_D > ldo)
             return fail(-1, "flash_attn: incomplete split-key workspace");
     }
-    hipLaunchKernelGGL(flash_attn_f32_kernel, dim3(n_tiles), dim3(256), 0, s, Q, K, V, O, ldq, ldkv, ldo, tiles,
-                       n_tiles, scale_log2e, sp);
+    if (FA_D == 32)
+        hipLaunchKernelGGL(flash_attn_f32_kernel<32>, dim3(n_tiles), dim3(256), 0, s, Q, K, V, O, ldq, ldkv, ldo, tiles, n_tiles, scale_log2e, sp);
+    else if (FA_D == 64)
+        hipLaunchKernelGGL(flash_attn_f32_kernel<64>, dim3(n_tiles), dim3(256), 0, s, Q, K, V, O, ldq, ldkv, ldo, tiles, n_tiles, scale_log2e, sp);
+    else
+        hipLaunchKernelGGL(flash_attn_f32_kernel<128>, dim3(n_tiles), dim3(256), 0, s, Q, K, V, O, ldq, ldkv, ldo, tiles, n_tiles, scale_log2e, sp);
     VLSAT_LAUNCH_CHECK("flash_attn_f32");
-    if (sp.parts > 1) return launch_flash_merge(O, ldo, sp, s, 0);
+    if (sp.parts > 1) return launch_flash_merge(O, ldo, sp, s, 0, FA_D);
     return 0;
 }
 
-int launch_flash_merge(float* O, int ldo, const FlashSplit& sp, hipStream_t s, int out_split) {
+int launch_flash_merge(float* O, int ldo, const FlashSplit& sp, hipStream_t s, int out_split, int head_dim) {
+    const int FA_D = head_dim;
     const size_t n4 = (size_t)sp.rows * sp.heads * (FA_D / 4);
-    hipLaunchKernelGGL(flash_merge_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, O, ldo, sp, out_split);
+    hipLaunchKernelGGL(flash_merge_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, O, ldo, sp, out_split, FA_D);
     VLSAT_LAUNCH_CHECK("flash_merge");
     return 0;
 }

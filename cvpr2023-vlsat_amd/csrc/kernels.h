@@ -82,8 +82,9 @@ struct FlashSplit {
     int rows = 0, heads = 0;
 };
 int launch_flash_attn(const float* Q, int ldq, const float* K, const float* V, int ldkv, float* O, int ldo,
-                      const int4* tiles, int n_tiles, float scale_log2e, hipStream_t s, const FlashSplit* split = nullptr);
-int launch_flash_merge(float* O, int ldo, const FlashSplit& sp, hipStream_t s, int out_split);
+                      const int4* tiles, int n_tiles, float scale_log2e, hipStream_t s, const FlashSplit* split = nullptr,
+                      int head_dim = 64);      // head_dim = 512 / NUM_HEADS: 32 | 64 | 128
+int launch_flash_merge(float* O, int ldo, const FlashSplit& sp, hipStream_t s, int out_split, int head_dim = 64);
 // the same attention on the bf16 matrix cores (flash_attn_bf16.hip): terms = 3 split-bf16 (~1e-5) | 1 single-rounded;
 // use_tr = 0 selects the gather fallback for the V operand instead of ds_read_b64_tr_b16 (tests); io_split = 1: Q (already
 // scaled), K, V and O are in the split-pair format of the bf16 modes (common.h pack_split)
@@ -150,6 +151,9 @@ struct GateArgs {
 int launch_edge_gate(const GateArgs& a, hipStream_t s);
 // any head geometry (dk query / edge channels per head, dox output channels per head): plain VALU
 int launch_edge_gate_generic(const GateArgs& a, int n_heads, int dk, int dox, hipStream_t s);
+// the head geometries of MODEL.NUM_HEADS in {4, 8, 16} x DIM_ATTEN in {128, 256, 512} on the fp32 matrix cores
+// (edge_gate_heads.hip); returns 1 when (dk, dox) is not one of them (-> the VALU kernel)
+int launch_edge_gate_heads(const GateArgs& a, int n_heads, int dk, int dox, hipStream_t s);
 // the same on the bf16 matrix cores (edge_gate_bf16.hip): terms = 3 split-bf16 | 1 single-rounded; kproj_split = 1: kproj is
 // in the split-pair format of the bf16 modes (common.h pack_split)
 int launch_edge_gate_bf16(const GateArgs& a, int terms, int kproj_split, hipStream_t s);

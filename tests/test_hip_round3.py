@@ -143,3 +143,29 @@ def test_gate_row_mappings_give_identical_bits(mode):
             assert torch.equal(a, c), (mode, n, float((a - c).abs().max()))
     finally:
         m.close()
+
+
+@pytest.mark.parametrize("heads,atten", [(4, 256), (16, 256), (8, 128), (8, 512), (4, 512), (16, 128)])
+def test_head_geometries_on_the_matrix_cores_match_the_valu_kernels(heads, atten):
+    """MODEL.NUM_HEADS / DIM_ATTEN other than 8 / 256 (reference network_MMG.py:48-50): the gate runs on
+    edge_gate_heads.hip (fp32 MFMA, d_k in {32, 64, 128}, d_o = DIM_ATTEN / heads) and the edge attention on the head-dim
+    template of flash_attn_f32.hip.  Both against the VALU kernels they replace (which the reference goldens
+    heads_*.npz pinned in round 2), and against the fp64 oracle, on a ragged batch."""
+    from oracle import vlsat_oracle as O
+    cfg = VLSATConfig(N_LAYERS=2, NUM_HEADS=heads, DIM_ATTEN=atten)
+    w = synth.make_weights(cfg)
+    m = _model(cfg, w)
+    try:
+        b = synth.collate([synth.make_scene(n, 64, 4000 + n) for n in (11, 6, 19)])
+        got = _run(m, b)
+        m.debug_option("gate_heads_mfma", 0)
+        valu = _run(m, b)
+        for n, a, c in zip(NAMES, got, valu):
+            assert float((a - c).abs().max()) < 2e-5, (heads, atten, n, float((a - c).abs().max()))
+        c = {k: torch.from_numpy(v) for k, v in b.items()}
+        ref = O.forward(O.to_torch(w, torch.float64), cfg, c["obj_points"].double(), c["obj_2d_feats"].double(), c["edge_indices"],
+                        c["descriptor"].double(), c["batch_ids"])
+        for n, a, r in zip(NAMES, got, ref):
+            assert float((a - r.float()).abs().max()) < 1e-4, (heads, atten, n, float((a - r.float()).abs().max()))
+    finally:
+        m.close()
