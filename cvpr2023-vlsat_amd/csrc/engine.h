@@ -105,6 +105,11 @@ struct vlsat_ctx {
     // scene; hipMalloc/hipFree per scene would dominate small scenes), pinned upload buffers, spare events
     std::vector<vlsat::Arena> arena_pool;
     std::vector<vlsat::Arena> arena_trash;          // too many pooled: freed once their last forward has completed
+    // graph executables of destroyed / re-captured plans: destroyed once their last launch has completed (hipGraphExecDestroy
+    // on an executable that is still running frees the streams its branches run on: the next hipGraphLaunch of ANY graph then
+    // crashed inside hip::Graph::UpdateStreams, one run in four of tools/latency_probe.py -- found in round 3)
+    struct DeadGraph { hipGraphExec_t g; hipEvent_t done; };
+    std::vector<DeadGraph> graph_trash;
     std::vector<vlsat::Staging> staging;
     std::vector<hipEvent_t> spare_ev;
 };
@@ -145,6 +150,7 @@ struct vlsat_plan_s {
     bool dual = false;
     // hipGraph replay (vlsat_forward_graph): the captured forward of this plan for ONE set of tensor addresses
     hipGraphExec_t graph_exec = nullptr;
+    hipEvent_t graph_done = nullptr;        // recorded behind every launch of graph_exec
     const void* graph_ptrs[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     long graph_epoch = -1;                  // handle configuration (weights / precision / options) it was captured under
     float *NP2 = nullptr, *Hbig2 = nullptr, *KP2 = nullptr, *G2 = nullptr, *T768b = nullptr, *rs2 = nullptr, *H2b = nullptr;
@@ -176,5 +182,6 @@ int split_all_weights(vlsat_ctx* h);
 hipEvent_t take_event(vlsat_ctx* h);
 void give_event(vlsat_ctx* h, hipEvent_t e);
 void release_plan_resources(vlsat_ctx* h);       // frees pools (vlsat_destroy)
+void retire_graph(vlsat_ctx* h, vlsat_plan_s* p); // p's graph executable (if any) -> graph_trash; sweeps what has completed
 
 }  // namespace vlsat

@@ -534,7 +534,7 @@ int vlsat_forward_graph(vlsat_handle h, vlsat_plan p, const float* pts, const fl
                         float* obj3d, float* obj2d, float* rel3d, float* rel2d, void* stream) {
     if (!h || !p) return fail(VLSAT_EINVAL, "vlsat_forward_graph: null argument");
     if (!h->finalized) {                    // (a captured graph holds the freed weight pointers: drop it as well)
-        if (p->graph_exec) { hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }
+        retire_graph(h, p);
         return fail(VLSAT_ESTATE, "vlsat_forward_graph: weights are not finalised (a reload is in progress or failed)");
     }
     if (h->prof || h->debug_stop >= 0) return forward_impl(h, p, pts, f2d, desc, obj3d, obj2d, rel3d, rel2d, nullptr, stream);
@@ -548,7 +548,7 @@ int vlsat_forward_graph(vlsat_handle h, vlsat_plan p, const float* pts, const fl
     bool same = p->graph_exec && p->graph_epoch == h->config_epoch;
     for (int i = 0; same && i < 7; ++i) same = p->graph_ptrs[i] == ptrs[i];
     if (!same) {
-        if (p->graph_exec) { hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }
+        retire_graph(h, p);                // (its last launch may still be running)
         if (p->dual && !h->side) VLSAT_HIP_CHECK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
         h->sync_ev.reserve(64);            // (events of the fork / join points are created on demand: fine during capture)
         VLSAT_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
@@ -562,8 +562,11 @@ int vlsat_forward_graph(vlsat_handle h, vlsat_plan p, const float* pts, const fl
         if (ei != hipSuccess) { p->graph_exec = nullptr; return fail(VLSAT_EHIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ei)); }
         for (int i = 0; i < 7; ++i) p->graph_ptrs[i] = ptrs[i];
         p->graph_epoch = h->config_epoch;
+        p->graph_done = take_event(h);
+        if (!p->graph_done) { retire_graph(h, p); return fail(VLSAT_EHIP, "vlsat_forward_graph: cannot create an event"); }
     }
     VLSAT_HIP_CHECK(hipGraphLaunch(p->graph_exec, s));
+    VLSAT_HIP_CHECK(hipEventRecord(p->graph_done, s));
     p->used = true;
     VLSAT_HIP_CHECK(hipEventRecord(p->last_use, s));
     return 0;

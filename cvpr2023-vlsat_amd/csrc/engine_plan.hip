@@ -45,7 +45,30 @@ static void sweep_trash(vlsat_ctx* h, bool force) {
     }
 }
 
+static void sweep_graphs(vlsat_ctx* h, bool force) {
+    for (size_t i = 0; i < h->graph_trash.size();) {
+        auto& d = h->graph_trash[i];
+        if (force || !d.done || hipEventQuery(d.done) == hipSuccess) {
+            hipGraphExecDestroy(d.g);
+            give_event(h, d.done);
+            h->graph_trash.erase(h->graph_trash.begin() + i);
+        } else {
+            ++i;
+        }
+    }
+}
+
+void retire_graph(vlsat_ctx* h, vlsat_plan_s* p) {
+    if (p->graph_exec) {
+        h->graph_trash.push_back({p->graph_exec, p->graph_done});
+        p->graph_exec = nullptr;
+        p->graph_done = nullptr;
+    }
+    sweep_graphs(h, false);
+}
+
 void release_plan_resources(vlsat_ctx* h) {
+    sweep_graphs(h, true);                 // (vlsat_destroy has waited for the device)
     sweep_trash(h, true);
     for (auto& a : h->arena_pool) { hipFree(a.p); if (a.last) hipEventDestroy(a.last); }
     h->arena_pool.clear();
@@ -323,7 +346,7 @@ int vlsat_plan_create(vlsat_handle h, const int64_t* bid, const int64_t* edges, 
 void vlsat_plan_destroy(vlsat_plan p) {
     if (!p) return;
     vlsat_ctx* h = p->h;
-    if (p->graph_exec) hipGraphExecDestroy(p->graph_exec);     // (a launch still in flight keeps what it needs)
+    retire_graph(h, p);                    // (a launch may still be in flight: destroyed when its event has completed)
     if (p->arena) {
         // The forward that used this workspace may still be in flight: the arena keeps the event of that forward (or
         // of the upload, if the plan never ran) and whoever takes it next waits for it ON THE DEVICE.  No host wait.

@@ -24,6 +24,13 @@ python tools/gemm_bench.py --prec 3 --only E --fmt 5 > "$OUT/gemm_bf16x3.txt" 2>
 python tools/gemm_bench.py --prec 3 --only E --fmt 4101 > "$OUT/gemm_bf16x3_no_p8.txt" 2>&1
 python tools/latency_probe.py > "$OUT/latency_fp32.txt" 2>&1
 python tools/latency_probe.py --gemm-precision bf16x3 > "$OUT/latency_bf16x3.txt" 2>&1
+python tools/latency_probe.py --gemm-precision bf16_mixed > "$OUT/latency_bf16_mixed.txt" 2>&1
+for hd in 4 16; do for on in 1 0; do   # NUM_HEADS 4 / 16: the MFMA gate (and the head-dim flash kernel) against the VALU gate of round 2
+  python bench.py --no-cpu --no-extra --steps 5 --warmup 2 --heads $hd --debug-option gate_heads_mfma=$on 2>/dev/null | grep "^{" | python -c "
+import sys, json
+d = json.loads(sys.stdin.read()); r = d['roofline']
+print('NUM_HEADS=$hd gate_heads_mfma=$on: %.1f scenes/s, %.2f ms/step; gate %.2f TF (%.0f %% of the step), edge attention %.1f TF (%.0f %%)' % (d['value'], d['ms_per_step'], r['class_tflops']['edge_gate'], 100 * r['time_share']['edge_gate'], r['class_tflops']['flash_attn_f32'], 100 * r['time_share']['flash_attn_f32']))"
+done; done > "$OUT/heads.txt" 2>&1
 python tools/eval_synth.py > "$OUT/eval_synth.txt" 2>&1
 python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -3 > "$OUT/tests_gpu.log"
 du -sh "$OUT"; ls "$OUT"

@@ -114,6 +114,48 @@ def main():
     print(f"  same graphs, hipGraph replay: forward {1e3 * np.mean(t_rep):6.2f} ms mean ({1e3 * np.median(t_rep):.2f} median; "
           f"vlsat_forward_graph, captured beforehand)")
     print(f"  plan cache: {model.plan_stats}")
+    # by scene size: what is launch-bound and what is compute-bound (flops of the minimal-algebra count, bench.py f_alg)
+    from bench import f_alg
+    print("  by scene size (same graphs again, plan cached):")
+    for lo, hi_ in ((9, 20), (21, 40), (41, 60), (61, 80)):
+        sel = [i for i, n in enumerate(sizes) if lo <= n <= hi_]
+        if not sel:
+            continue
+        ms = np.array([t_hot[i] for i in sel]) * 1e3
+        gf = np.array([f_alg(int(sizes[i]), a.points, int(sizes[i]) * (int(sizes[i]) - 1), a.layers) for i in sel]) / 1e9
+        print(f"    {lo:2d}..{hi_:2d} objects ({len(sel):2d} scenes): {ms.mean():5.2f} ms mean, {gf.mean():6.1f} GFLOP mean "
+              f"-> {gf.mean() / ms.mean():5.1f} TFLOP/s")
+    # per stage, one 40-object scene: vlsat_debug_stop_after(stage) returns from the forward after that stage; the table is
+    # the difference between consecutive cumulative times (mean of 30 calls each, plan cached)
+    it40 = to_dev(synth.collate([synth.make_scene(40, a.points, seed=777)]))
+    call(it40)
+    stages = [(1, "object encoder (PointNet)"), (2, "mlp_3d + spatial tail"), (3, "edge descriptor + relation encoders"),
+              (4, "adapter"), (5, "distance bias")]
+    for l in range(a.layers):
+        stages += [(10 + 10 * l, f"layer {l}: node self-attention"), (11 + 10 * l, f"layer {l}: node cross-attention"),
+                   (12 + 10 * l, f"layer {l}: gcn_3ds"), (13 + 10 * l, f"layer {l}: gcn_2ds"), (14 + 10 * l, f"layer {l}: edge cross-attention")]
+    stages += [(-1, "whole forward")]
+    prev, rows = 0.0, []
+    for sid, name in stages:
+        model.debug_stop_after(sid)
+        try:
+            for _ in range(3):
+                call(it40)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(30):
+                call(it40)
+                torch.cuda.synchronize()
+            cum = (time.perf_counter() - t0) / 30 * 1e3
+        finally:
+            model.debug_stop_after(-1)
+        rows.append((name, cum - prev, cum))
+        prev = cum
+    print("  per stage, one 40-object scene (E = 1560), ms (cumulative; a forward stopped at a stage runs on one stream, the whole")
+    print("  forward overlaps the 2D twin stages on the second stream -- hence the last line):")
+    for name, d_, cum in rows[:-1]:
+        print(f"    {name:40s} {d_:6.3f}  ({cum:6.3f})")
+    print(f"    {'whole forward incl. the four heads':40s}         ({rows[-1][2]:6.3f})")
     if a.single_only:
         return
     big = to_dev(synth.collate(scenes))
