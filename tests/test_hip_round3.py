@@ -190,3 +190,40 @@ def test_graph_replay_survives_plan_eviction_with_launches_in_flight():
         assert m.plan_stats["builds"] > 80          # the cache did evict
     finally:
         m.close()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_graphs_on_every_head_geometry_vs_oracle(seed):
+    """The head-geometry kernels on randomised batches: 1..5 scenes of 1..11 objects, arbitrary edge lists (unsorted, self
+    loops, duplicates, empty scenes -- a gate wave's 32 edges then name up to 32 different nodes), every aggregator,
+    USE_GCN_EDGE on and off, fp32 and split-bf16 GEMMs around them; against the fp64 oracle."""
+    from oracle import vlsat_oracle as O
+    g = np.random.default_rng(700 + seed)
+    heads, atten = [(4, 256), (16, 256), (8, 128), (8, 512), (4, 128), (16, 512)][seed]
+    cfg = VLSATConfig(N_LAYERS=int(g.integers(1, 3)), NUM_HEADS=heads, DIM_ATTEN=atten, GCN_AGGR=("max", "add", "mean")[seed % 3],
+                      USE_GCN_EDGE=bool(seed % 2 == 0))
+    n_pts = int(g.integers(2, 200))
+    scenes = []
+    for s in range(int(g.integers(1, 6))):
+        n = int(g.integers(1, 12))
+        sc = synth.make_scene(n, n_pts, 9700 + 10 * seed + s)
+        pairs = np.stack(np.meshgrid(np.arange(n), np.arange(n), indexing="ij"), 0).reshape(2, -1)
+        k = int(g.integers(0, pairs.shape[1] + 3))
+        pick = g.integers(0, pairs.shape[1], k) if k else np.zeros(0, np.int64)
+        sc["edge_indices"] = np.ascontiguousarray(pairs[:, pick]).astype(np.int64).reshape(2, -1)
+        scenes.append(sc)
+    b = synth.collate(scenes)
+    w = synth.make_weights(cfg)
+    c = {k: torch.from_numpy(v) for k, v in b.items()}
+    ref = O.forward(O.to_torch(w, torch.float64), cfg, c["obj_points"].double(), c["obj_2d_feats"].double(), c["edge_indices"],
+                    c["descriptor"].double(), c["batch_ids"])
+    for mode, tol in (("fp32", 1e-4), ("bf16x3", 1e-3)):
+        m = _model(cfg, w).set_gemm_precision(mode)
+        try:
+            got = _run(m, b)
+            for n, a, r in zip(NAMES, got, ref):
+                assert a.shape == r.shape
+                if a.numel():
+                    assert float((a - r.float()).abs().max()) < tol, (mode, heads, atten, n, float((a - r.float()).abs().max()))
+        finally:
+            m.close()
