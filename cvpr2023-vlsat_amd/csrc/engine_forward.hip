@@ -25,8 +25,9 @@ namespace {
 // Returns the format code: 0 fp32, 1 split-pair words (split-bf16 mode), 2 half rows = plain bf16 at half the HBM
 // traffic (single-rounding modes, whose kernels never read a low part).
 static int split_fmt(const vlsat_ctx* h) {
-    const bool on = h->prec_edge != 0 && h->split_fmt && h->flash_bf16 && h->flash_tr && !h->gemm_no_dma && !h->d.feature_transform &&
-                    default_heads(h);
+    // (head geometries other than 8 x 64: the chain tensors keep the format; Q / K|V / O of the edge attention and the gate's
+    //  kproj stay fp32 there, because those kernels are the fp32 ones -- see SA in the edge attention below)
+    const bool on = h->prec_edge != 0 && h->split_fmt && h->flash_bf16 && h->flash_tr && !h->gemm_no_dma && !h->d.feature_transform;
     if (!on) return 0;
     if (h->prec_edge == 3) return 1;
     return h->gate_bf16 && h->half_fmt ? 2 : 1;
@@ -435,12 +436,14 @@ static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const fl
         if (do2d) {   // :231 edge cross-attention: q = 2D edges, k = v = 3D edges (pre-activation)
             const AttnW& w = h->cross_rel[l];
             const float sc2e = 0.125f * 1.4426950408889634f;           // 1/sqrt(d_k) * log2(e): the attention works in exp2
+            const int dh = D / h->H;
+            const int SA = dh == 64 ? S : 0;                           // format of Q / K|V / O: the bf16 attention kernel is built for head dim 64
             GemmArgs gq = G(p->E2, D, w.wq, D, p->Qe, D, E, D, w.bq);
-            gq.a_split = S; gq.c_split = S;
-            if (S) gq.c_scale = sc2e;                                  // the split-format attention takes Q pre-scaled
+            gq.a_split = S; gq.c_split = SA;
+            if (SA) gq.c_scale = sc2e;                                 // the split-format attention takes Q pre-scaled
             RUN(gemm(h, t, gq));
             GemmArgs gkv = G(p->E3, D, w.wkv, D, p->KVe, 2 * D, E, 2 * D, w.bkv);
-            gkv.a_split = S; gkv.c_split = S;
+            gkv.a_split = S; gkv.c_split = SA;
             RUN(gemm(h, s, gkv));
             RUN(join());
             {
@@ -448,14 +451,13 @@ static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const fl
                 FlashSplit sp;
                 sp.parts = p->fa_parts; sp.krange = p->d_krange; sp.o_part = p->fa_opart; sp.m_part = p->fa_m;
                 sp.l_part = p->fa_l; sp.part_stride = (size_t)E * D; sp.rows = E; sp.heads = h->H;
-                const int dh = D / h->H;
                 if (dh != 32 && dh != 64 && dh != 128)   // any other head dim: VALU attention over the scenes' edge ranges (no bias)
                     RUN(launch_node_attn(p->Qe, D, p->KVe, 2 * D, p->KVe + D, 2 * D, p->Oe, D, nullptr, p->d_edge_ptr32, nullptr,
                                          h->edge_scope == 1 ? 1 : p->S, h->edge_scope == 1 ? E : p->max_e, h->H, D / h->H,
                                          1.f / std::sqrt((float)(D / h->H)), s, h->node_attn_split));
                 else if (h->prec_edge && h->flash_bf16 && dh == 64)
-                    RUN(launch_flash_attn_bf16(p->Qe, D, p->KVe, p->KVe + (S == 2 ? D / 2 : D), 2 * D, p->Oe, D, p->d_tiles, p->n_tiles,
-                                               sc2e, h->prec_edge == 3 ? 3 : 1, h->flash_tr, S, s, &sp, h->flash_pv_terms));    // (half rows: V starts at byte 2 D)
+                    RUN(launch_flash_attn_bf16(p->Qe, D, p->KVe, p->KVe + (SA == 2 ? D / 2 : D), 2 * D, p->Oe, D, p->d_tiles, p->n_tiles,
+                                               sc2e, h->prec_edge == 3 ? 3 : 1, h->flash_tr, SA, s, &sp, h->flash_pv_terms));    // (half rows: V starts at byte 2 D)
                 else
                     RUN(launch_flash_attn(p->Qe, D, p->KVe, p->KVe + D, 2 * D, p->Oe, D, p->d_tiles, p->n_tiles,
                                           (1.f / std::sqrt((float)dh)) * 1.4426950408889634f, s, &sp, dh));   // (head dims 32 / 128: NUM_HEADS 16 / 4)
@@ -469,7 +471,7 @@ static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const fl
             const bool ln_resid = (S == 1 || (S == 2 && !h->gemm_no_p8)) && h->ln_resid;
             GemmArgs o = G(p->Oe, D, w.wo, D, pre_ln, D, E, D, w.bo);
             if (!ln_resid) { o.resid = p->E2; o.ldr = D; o.r_split = S; }
-            o.a_split = S;
+            o.a_split = SA;
             RUN(gemm(h, s, o));
             Scope sc(h, s, PC_LAYERNORM, 0);
             RUN(launch_layernorm_to(pre_ln, D, p->E2, D, E, D, w.lng, w.lnb, inter, S, s, ln_resid ? p->E2 : nullptr, D, S));

@@ -231,14 +231,15 @@ def test_weights_can_be_reloaded():
 
 
 @pytest.mark.parametrize("h,a", [(4, 256), (16, 256), (8, 128), (8, 512)])
-@pytest.mark.parametrize("mode", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3", "bf16_mixed"])
 def test_num_heads_and_dim_atten_golden(golden_dir, h, a, mode):
     """MODEL.NUM_HEADS / MODEL.DIM_ATTEN other than the shipped 8 / 256 (reference network_MMG.py:48-50): head dims 128 / 32,
     gate output widths 64 / 16, through the generic per-head kernels, against the real reference run with that config."""
     z = np.load(os.path.join(golden_dir, f"heads_h{h}_a{a}.npz"))
     cfg = VLSATConfig(N_LAYERS=2, NUM_HEADS=h, DIM_ATTEN=a)
     m = _model(cfg, synth.make_weights(cfg)).set_gemm_precision(mode)
-    _check(_run(m, RAGGED()), [z[n] for n in NAMES], TIGHT if mode == "fp32" else TOL, f"H={h} A={a} {mode} vs reference golden")
+    tol = {"fp32": TIGHT, "bf16x3": TOL, "bf16_mixed": 1e-2}[mode]          # (BASELINE configs[2] tolerance for the single-rounding mode)
+    _check(_run(m, RAGGED()), [z[n] for n in NAMES], tol, f"H={h} A={a} {mode} vs reference golden")
     m.close()
 
 
