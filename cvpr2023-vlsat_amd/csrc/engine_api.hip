@@ -233,6 +233,15 @@ int vlsat_eval_ranks(const float* obj_logits, const float* obj_probs, const floa
                              static_cast<hipStream_t>(stream));
 }
 
+int vlsat_scene_checksums(const float* obj3d, const float* obj2d, int64_t n_nodes, int32_t n_obj_class, const float* rel3d,
+                          const float* rel2d, int64_t n_edges, int32_t n_rel_class, int32_t n_scenes, double* out9, double* scratch,
+                          void* stream) {
+    if (!obj3d || !obj2d || !out9 || !scratch || n_nodes < 0 || n_edges < 0) return fail(VLSAT_EINVAL, "scene_checksums: null argument");
+    if (n_edges > 0 && (!rel3d || !rel2d)) return fail(VLSAT_EINVAL, "scene_checksums: null relation outputs");
+    return launch_scene_checksums(obj3d, obj2d, (long)n_nodes, n_obj_class, rel3d, rel2d, (long)n_edges, n_rel_class, n_scenes, out9,
+                                  scratch, static_cast<hipStream_t>(stream));
+}
+
 int vlsat_k_layernorm(float* x, int32_t ld, int32_t rows, int32_t dim, const float* gamma, const float* beta,
                       int32_t relu, void* stream) {
     return launch_layernorm(x, ld, rows, dim, gamma, beta, relu, static_cast<hipStream_t>(stream));

@@ -173,6 +173,10 @@ int launch_eval_ranks(const float* obj_logits, const float* obj_probs, const flo
                       int topk_rel, int topk_tri, float thr, int32_t* obj_rank, int32_t* rel_rank, int32_t* tri_rank,
                       int32_t* cnt, hipStream_t s);
 
+// the additive metrics vector {scenes, N, E, four fp64 output sums, two top-1 agreement counts}; scratch: 256 * 6 doubles
+int launch_scene_checksums(const float* obj3d, const float* obj2d, long N, int C, const float* rel3d, const float* rel2d, long E, int R,
+                           int n_scenes, double* out9, double* scratch, hipStream_t s);
+
 // ---- per-object input preparation ----
 int launch_prepare_objects(const float* scene, const int32_t* choice, int N, int P, float* obj_points, float* desc,
                            hipStream_t s);

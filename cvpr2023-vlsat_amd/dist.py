@@ -51,6 +51,8 @@ def scene_metrics(outputs, n_scenes: int) -> torch.Tensor:
     src/model/model.py:214-242)."""
     obj3, obj2, rel3, rel2 = outputs
     dev = obj3.device
+    if obj3.is_cuda:                      # the library's two-launch reduction (vlsat_scene_checksums); below: its CPU twin
+        return _scene_metrics_hip(obj3, obj2, rel3, rel2, n_scenes)
     v = torch.zeros(len(METRIC_FIELDS), dtype=torch.float64, device=dev)
     v[0] = n_scenes
     v[1] = obj3.shape[0]
@@ -62,6 +64,28 @@ def scene_metrics(outputs, n_scenes: int) -> torch.Tensor:
     v[7] = (obj3.argmax(-1) == obj2.argmax(-1)).sum()
     if rel3.shape[0]:
         v[8] = (rel3.argmax(-1) == rel2.argmax(-1)).sum()
+    return v
+
+
+_CHECKSUM_SCRATCH = {}
+
+
+def _scene_metrics_hip(obj3, obj2, rel3, rel2, n_scenes: int) -> torch.Tensor:
+    from . import lib as L
+    lib = L.load()
+    dev = obj3.device
+    for t in (obj3, obj2, rel3, rel2):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.device != dev:
+            raise L.VlsatError("scene_metrics: outputs must be contiguous fp32 tensors on one GPU")
+    scratch = _CHECKSUM_SCRATCH.get(dev)
+    if scratch is None:
+        scratch = _CHECKSUM_SCRATCH[dev] = torch.empty(256 * 6, dtype=torch.float64, device=dev)
+    v = torch.empty(len(METRIC_FIELDS), dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        L.check(lib.vlsat_scene_checksums(obj3.data_ptr(), obj2.data_ptr(), obj3.shape[0], obj3.shape[1],
+                                          rel3.data_ptr() if rel3.shape[0] else None, rel2.data_ptr() if rel2.shape[0] else None,
+                                          rel3.shape[0], max(rel3.shape[1], 1), n_scenes, v.data_ptr(), scratch.data_ptr(),
+                                          L.stream_ptr()))
     return v
 
 

@@ -264,6 +264,16 @@ int vlsat_eval_ranks(const float* obj_logits, const float* obj_probs, const floa
                      int32_t topk_obj, int32_t topk_rel, int32_t topk_triplet, float threshold,
                      int32_t* obj_rank, int32_t* rel_rank, int32_t* tri_rank, int32_t* cnt, void* stream);
 
+/* The additive fp64 metrics vector of one rank's batch -- what the path's one all-reduce carries when no labels are at hand
+ * (bench.py; the label-based counts of validation(), reference src/model/model.py:214-242, come from vlsat_eval_ranks):
+ * out9 = {n_scenes, n_nodes, n_edges, sum obj3d, sum obj2d, sum rel3d, sum rel2d, #nodes whose 3D and 2D top-1 class agree,
+ * #edges whose 3D and 2D top-1 relation agree}.  All device pointers; the outputs are the dense [n_nodes, n_obj_class] /
+ * [n_edges, n_rel_class] tensors vlsat_forward wrote; scratch holds 256 * 6 doubles.  Two launches on `stream`, fixed
+ * summation order (no atomics): bit-reproducible. */
+int vlsat_scene_checksums(const float* obj3d, const float* obj2d, int64_t n_nodes, int32_t n_obj_class, const float* rel3d,
+                          const float* rel2d, int64_t n_edges, int32_t n_rel_class, int32_t n_scenes, double* out9, double* scratch,
+                          void* stream);
+
 /* -------- debug / test hooks (used by tests/ to localise a parity failure) -------------------- */
 /* Stop vlsat_forward after stage `stage` (-1 = run everything).  Stages: 1 object encoder,
  * 2 node embedding, 3 edge embedding, 4 adapter, 5 distance bias, then for layer l:

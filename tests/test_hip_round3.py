@@ -227,3 +227,23 @@ def test_random_graphs_on_every_head_geometry_vs_oracle(seed):
                     assert float((a - r.float()).abs().max()) < tol, (mode, heads, atten, n, float((a - r.float()).abs().max()))
         finally:
             m.close()
+
+
+def test_scene_checksums_kernel_equals_the_torch_reduction():
+    """vlsat_scene_checksums (the additive metrics vector bench.py all-reduces) against the PyTorch expressions it replaces,
+    on the outputs of a ragged batch, on a batch without edges, and twice in a row (bit-reproducible)."""
+    from vlsat_amd import dist as vdist
+    cfg = VLSATConfig(N_LAYERS=1)
+    m = _model(cfg, synth.make_weights(cfg))
+    try:
+        for scenes in ([synth.make_scene(n, 32, 6000 + n) for n in (7, 1, 12, 30)], [synth.make_scene(1, 32, 6100)]):
+            d = _dev(synth.collate(scenes))
+            out = m(d["obj_points"], d["obj_2d_feats"], d["edge_indices"], d["descriptor"], d["batch_ids"])
+            got = vdist.scene_metrics(out, len(scenes)).cpu()
+            again = vdist.scene_metrics(out, len(scenes)).cpu()
+            assert torch.equal(got, again)
+            want = vdist.scene_metrics([o.cpu() for o in out], len(scenes))           # the CPU twin: torch reductions
+            assert torch.equal(got[:3], want[:3]) and torch.equal(got[7:], want[7:]), (got, want)
+            assert torch.allclose(got[3:7], want[3:7], rtol=1e-12, atol=1e-9), (got, want)
+    finally:
+        m.close()
