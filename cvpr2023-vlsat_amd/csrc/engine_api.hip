@@ -60,7 +60,7 @@ int vlsat_debug_option(vlsat_handle h, const char* name, int32_t value) {
     else if (k == "gemm_p8") h->gemm_no_p8 = value == 0;
     else if (k == "gate_grid") h->gate_grid = value > 0 ? value : 0;
     else if (k == "gate_row_map") h->gate_row_map = value != 0;
-    else if (k == "gate_heads_mfma") h->gate_heads_mfma = value != 0;
+    else if (k == "gate_heads_mfma") h->gate_heads_mfma = value < 0 ? 0 : value > 2 ? 2 : value;
     else if (k == "gemm_splitk") h->gemm_splitk = value != 0;
     else if (k == "node_attn_split") h->node_attn_split = value;
     else if (k == "split_fmt") h->split_fmt = value != 0;

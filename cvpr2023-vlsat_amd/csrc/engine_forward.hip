@@ -161,7 +161,7 @@ int gcn_block(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const GcnW& w, float
         g.prob = p->prob; g.n_edges = E; g.use_edge = h->d.use_gcn_edge; g.grid_cap = h->gate_grid; g.row_map = h->gate_row_map;
         const double dk = D / h->H, dox = A / h->H;
         Scope scope(h, s, PC_GATE, (double)E * h->H * (2.0 * dk * 2 * dk + 2.0 * 2 * dk * dox));
-        if (!default_heads(h)) {
+        if (!default_heads(h) || (h->gate_heads_mfma == 2 && !gate16)) {     // (2: the shipped geometry on the template as well -- A/B)
             int r = h->gate_heads_mfma ? launch_edge_gate_heads(g, h->H, D / h->H, A / h->H, s) : 1;
             if (r < 0) return r;
             if (r) RUN(launch_edge_gate_generic(g, h->H, D / h->H, A / h->H, s));
