@@ -12,6 +12,8 @@ python bench.py --gemm-precision bf16_mixed --no-extra > "$OUT/bench_cfg3_bf16_m
 tools/profile_run.sh r03/prof_fp32 --no-extra > /dev/null 2>&1
 tools/profile_run.sh r03/prof_cfg3 --gemm-precision bf16x3 --no-extra > /dev/null 2>&1
 tools/profile_run.sh r03/prof_cfg3_mixed --gemm-precision bf16_mixed --no-extra > /dev/null 2>&1
+tools/profile_run.sh r03/prof_heads4 --heads 4 --no-extra > /dev/null 2>&1
+tools/profile_run.sh r03/prof_heads16 --heads 16 --no-extra > /dev/null 2>&1
 python tools/gemm_bench.py --only E > "$OUT/gemm_fp32.txt" 2>&1
 python tools/gemm_bench.py --only E --no-p8 > "$OUT/gemm_fp32_no_p8.txt" 2>&1
 python tools/p8_check.py --no-check > "$OUT/gemm_bf16_half.txt" 2>&1
