@@ -435,9 +435,11 @@ static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const fl
         STAGE(base + 3);
         if (do2d) {   // :231 edge cross-attention: q = 2D edges, k = v = 3D edges (pre-activation)
             const AttnW& w = h->cross_rel[l];
-            const float sc2e = 0.125f * 1.4426950408889634f;           // 1/sqrt(d_k) * log2(e): the attention works in exp2
+            const float sc2e = (1.f / std::sqrt((float)(D / h->H))) * 1.4426950408889634f;   // 1/sqrt(d_k) * log2(e): the attention works in exp2
             const int dh = D / h->H;
-            const int SA = dh == 64 ? S : 0;                           // format of Q / K|V / O: the bf16 attention kernel is built for head dim 64
+            // format of Q / K|V / O: that of the chain when the bf16 attention kernel is built for this head dim and mode, else fp32
+            const bool fa16 = h->prec_edge && h->flash_bf16 && (dh == 64 || (h->flash_heads_bf16 && S && flash_attn_bf16_supports(dh, h->prec_edge == 3 ? 3 : 1, h->flash_tr, S)));
+            const int SA = fa16 ? S : 0;
             GemmArgs gq = G(p->E2, D, w.wq, D, p->Qe, D, E, D, w.bq);
             gq.a_split = S; gq.c_split = SA;
             if (SA) gq.c_scale = sc2e;                                 // the split-format attention takes Q pre-scaled
@@ -455,12 +457,11 @@ static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const fl
                     RUN(launch_node_attn(p->Qe, D, p->KVe, 2 * D, p->KVe + D, 2 * D, p->Oe, D, nullptr, p->d_edge_ptr32, nullptr,
                                          h->edge_scope == 1 ? 1 : p->S, h->edge_scope == 1 ? E : p->max_e, h->H, D / h->H,
                                          1.f / std::sqrt((float)(D / h->H)), s, h->node_attn_split));
-                else if (h->prec_edge && h->flash_bf16 && dh == 64)
+                else if (fa16)
                     RUN(launch_flash_attn_bf16(p->Qe, D, p->KVe, p->KVe + (SA == 2 ? D / 2 : D), 2 * D, p->Oe, D, p->d_tiles, p->n_tiles,
-                                               sc2e, h->prec_edge == 3 ? 3 : 1, h->flash_tr, SA, s, &sp, h->flash_pv_terms));    // (half rows: V starts at byte 2 D)
+                                               sc2e, h->prec_edge == 3 ? 3 : 1, h->flash_tr, SA, s, &sp, h->flash_pv_terms, dh));    // (half rows: V starts at byte 2 D)
                 else
-                    RUN(launch_flash_attn(p->Qe, D, p->KVe, p->KVe + D, 2 * D, p->Oe, D, p->d_tiles, p->n_tiles,
-                                          (1.f / std::sqrt((float)dh)) * 1.4426950408889634f, s, &sp, dh));   // (head dims 32 / 128: NUM_HEADS 16 / 4)
+                    RUN(launch_flash_attn(p->Qe, D, p->KVe, p->KVe + D, 2 * D, p->Oe, D, p->d_tiles, p->n_tiles, sc2e, s, &sp, dh));   // (head dims 32 / 128: NUM_HEADS 16 / 4)
             }
             // out-projection + residual, then LayerNorm (+ inter-layer ReLU).  Split format: the GEMM reads O and the
             // residual as hi/lo pairs and writes plain fp32 into the (now dead) Q buffer; the LayerNorm packs E2 again.

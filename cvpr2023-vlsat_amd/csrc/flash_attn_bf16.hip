@@ -30,12 +30,10 @@ namespace vlsat {
 namespace {
 
 constexpr int FB_KV = 64;              // keys per tile
-constexpr int FB_D = 64;               // head dim
-constexpr int FB_KPITCH = 144;         // bytes per key row of a K plane (128 + 16: conflict-free ds_read_b128)
-constexpr int FB_KPLANE = FB_KV * FB_KPITCH;                  // 9216
 constexpr int FB_VSUB = FB_KV * 32 + 128;                     // 2176: one [64 keys][16 d] sub-tile + half a bank row
-constexpr int FB_VPLANE = 4 * FB_VSUB;                        // 8704
-constexpr int FB_OPITCH = 68;          // floats per query row of the output transpose
+// FB_D (template): head dim = 512 / MODEL.NUM_HEADS: 64 as shipped, 32 or 128 for 16 / 4 heads (round 3).  It sets the number
+// of 16-wide k-steps of QK^T (FB_D / 16), of 32-wide output blocks (FB_D / 32) and of V sub-tiles (FB_D / 16); K rows are
+// 2 FB_D + 16 bytes apart (80 / 144 / 272: every 16-lane group of a ds_read_b128 lands on 16 different 4-bank groups).
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
@@ -87,12 +85,17 @@ __device__ __forceinline__ void planes_of(const f32x4& x, bf16x4& hi, bf16x4& lo
 // scale * log2 e (the projection GEMM's epilogue did it)
 // PVT (split-bf16 mode only): MFMAs per P.V product.  3 = V_hi.P_hi + V_lo.P_hi + V_hi.P_lo; 2 drops the last term, i.e. the
 // probabilities enter the second product single-rounded (V stays exact) -- an experiment switch (flash_pv_terms).
-template <int TERMS, bool TR, int IO, int PVT = 3>
+template <int TERMS, bool TR, int IO, int PVT = 3, int FB_D = 64>
 __global__ __launch_bounds__(256, 2) void flash_attn_bf16_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
     float* __restrict__ O, int ldq, int ldkv, int ldo, const int4* __restrict__ tiles, int n_tiles,
     float scale_log2e, FlashSplit sp) {
     constexpr int PL = TERMS == 1 ? 1 : 2;
+    constexpr int NKS = FB_D / 16, NO = FB_D / 32, NSUB = FB_D / 16;
+    constexpr int FB_KPITCH = 2 * FB_D + 16;       // bytes per key row of a K plane (conflict-free ds_read_b128)
+    constexpr int FB_KPLANE = FB_KV * FB_KPITCH;
+    constexpr int FB_VPLANE = NSUB * FB_VSUB;
+    constexpr int FB_OPITCH = FB_D + 4;            // floats per query row of the output transpose
     constexpr int BUF = PL * (FB_KPLANE + FB_VPLANE);
     constexpr int SMEM = 2 * BUF > 4 * 32 * FB_OPITCH * 4 ? 2 * BUF : 4 * 32 * FB_OPITCH * 4;
     __shared__ __attribute__((aligned(16))) char smem[SMEM];
@@ -111,11 +114,11 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bf16_kernel(
     int qrow = q0 + wave * 32 + li;
     if (qrow >= n_tok) qrow = n_tok - 1;      // clamped rows are computed but never stored
     // ---- this lane's query: d = 16 ks + 8 hi + e, pre-scaled, split into bf16 hi / lo ----
-    bf16x8 qh[4], ql[4];
+    bf16x8 qh[NKS], ql[NKS];
     {
         const float* qrowp = Q + (size_t)(row_base + qrow) * ldq;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int ks = 0; ks < NKS; ++ks) {
             f32x4 x0 = load4<IO>(qrowp, col0 + 8 * hi + 16 * ks), x1 = load4<IO>(qrowp, col0 + 8 * hi + 16 * ks + 4);
             if (IO == 0) {
                 x0 *= scale_log2e;
@@ -129,37 +132,49 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bf16_kernel(
         }
     }
 
-    f32x16 o0, o1;
+    f32x16 o[NO];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    for (int b = 0; b < NO; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[b][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
     // ---- staging: K rows (tid>>4) + 16 i, four d per thread; V: wave-instruction = 4 keys x all 64 d, so that a
     //      16-lane write group fills 4 consecutive 32-byte rows of ONE sub-tile (conflict-free ds_write_b64) ----
-    const int krow = tid >> 4, kc4 = (tid & 15) * 4;
-    const int vkey = 4 * wave + ((lane >> 2) & 3), vsub = lane >> 4, vc4 = vsub * 16 + (lane & 3) * 4;
-    f32x4 rk[4], rv[4];
+    //      (FB_D / 4 threads per K row; per thread FB_D / 16 = NKS pieces of K and of V.  V at other head dims: 32 -> a wave
+    //      instruction = 8 keys x 32 d (lane groups 0, 1 = sub-tiles of keys 0..3, groups 2, 3 = of keys 4..7); 128 -> two
+    //      instructions per 4 keys, sub-tiles 0..3 and 4..7)
+    constexpr int TPR = FB_D / 4, RP = 256 / TPR;
+    const int krow = tid / TPR, kc4 = (tid % TPR) * 4;
+    const int vg = lane >> 4;
+    auto vsub_of = [&](int i) { return FB_D == 32 ? (vg & 1) : FB_D == 64 ? vg : vg + 4 * (i & 1); };
+    auto vkey_of = [&](int i) {
+        return FB_D == 32 ? 8 * wave + 4 * (vg >> 1) + ((lane >> 2) & 3) + 32 * i
+             : FB_D == 64 ? 4 * wave + ((lane >> 2) & 3) + 16 * i
+                          : 4 * wave + ((lane >> 2) & 3) + 16 * (i >> 1);
+    };
+    f32x4 rk[NKS], rv[NKS];
     auto load_tile = [&](int kv0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int r = kv0 + krow + 16 * i;
+        for (int i = 0; i < NKS; ++i) {
+            int r = kv0 + krow + RP * i;
             r = r < n_tok ? r : n_tok - 1;
             rk[i] = load4<IO>(K + (size_t)(row_base + r) * ldkv, col0 + kc4);
-            int rv_ = kv0 + vkey + 16 * i;
+            int rv_ = kv0 + vkey_of(i);
             rv_ = rv_ < n_tok ? rv_ : n_tok - 1;
-            rv[i] = load4<IO>(V + (size_t)(row_base + rv_) * ldkv, col0 + vc4);
+            rv[i] = load4<IO>(V + (size_t)(row_base + rv_) * ldkv, col0 + vsub_of(i) * 16 + (lane & 3) * 4);
         }
     };
     auto store_tile = [&](char* buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NKS; ++i) {
             bf16x4 h, l;
             planes_of<IO>(rk[i], h, l);
-            char* kp = buf + (krow + 16 * i) * FB_KPITCH + kc4 * 2;
+            char* kp = buf + (krow + RP * i) * FB_KPITCH + kc4 * 2;
             *reinterpret_cast<bf16x4*>(kp) = h;
             if (PL == 2) *reinterpret_cast<bf16x4*>(kp + FB_KPLANE) = l;
             planes_of<IO>(rv[i], h, l);
-            char* vp = buf + PL * FB_KPLANE + vsub * FB_VSUB + (vkey + 16 * i) * 32 + (lane & 3) * 8;
+            char* vp = buf + PL * FB_KPLANE + vsub_of(i) * FB_VSUB + vkey_of(i) * 32 + (lane & 3) * 8;
             *reinterpret_cast<bf16x4*>(vp) = h;
             if (PL == 2) *reinterpret_cast<bf16x4*>(vp + FB_VPLANE) = l;
         }
@@ -190,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bf16_kernel(
                 // the two 32-key blocks alternate, so consecutive MFMAs never wait for each other's accumulator
                 const char* kp = sK + li * FB_KPITCH + 16 * hi;
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
+                for (int ks = 0; ks < NKS; ++ks) {
                     const bf16x8 kh0 = *reinterpret_cast<const bf16x8*>(kp + 32 * ks);
                     const bf16x8 kh1 = *reinterpret_cast<const bf16x8*>(kp + 32 * FB_KPITCH + 32 * ks);
                     if (PL == 2) {
@@ -238,7 +253,9 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bf16_kernel(
             m_run = m_new;
             if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+                for (int b = 0; b < NO; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[b][r] *= alpha;
             }
             // ---- O^T[d][query] += sum_key V[key][d] * P[key][query] ----
 #pragma unroll
@@ -253,9 +270,9 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bf16_kernel(
                 const bf16x8 ph = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
                 const bf16x8 pl = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
                 const int k0 = 32 * kb + 16 * half + 4 * hi;          // first key of this lane half's k-slots (then +8)
-                bf16x8 vf[2][PL];
+                bf16x8 vf[NO][PL];
 #pragma unroll
-                for (int db = 0; db < 2; ++db)
+                for (int db = 0; db < NO; ++db)
 #pragma unroll
                     for (int pln = 0; pln < PL; ++pln) {
                         const char* vb = sV + pln * FB_VPLANE + (2 * db + ((lane >> 4) & 1)) * FB_VSUB;
@@ -276,17 +293,17 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bf16_kernel(
                             vf[db][pln] = __builtin_bit_cast(bf16x8, u);
                         }
                     }
-                // the two d-blocks alternate (independent accumulators back to back)
+                // the d-blocks alternate (independent accumulators back to back)
                 if (PL == 2) {
-                    o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0][PL - 1], ph, o0, 0, 0, 0);
-                    o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1][PL - 1], ph, o1, 0, 0, 0);
+#pragma unroll
+                    for (int db = 0; db < NO; ++db) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db][PL - 1], ph, o[db], 0, 0, 0);
                     if (PVT == 3) {
-                        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0][0], pl, o0, 0, 0, 0);
-                        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1][0], pl, o1, 0, 0, 0);
+#pragma unroll
+                        for (int db = 0; db < NO; ++db) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db][0], pl, o[db], 0, 0, 0);
                     }
                 }
-                o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0][0], ph, o0, 0, 0, 0);
-                o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1][0], ph, o1, 0, 0, 0);
+#pragma unroll
+                for (int db = 0; db < NO; ++db) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db][0], ph, o[db], 0, 0, 0);
             }
         }   // wave_active
         if (more) store_tile(smem + ((kt + 1) & 1) * BUF);
@@ -308,16 +325,17 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bf16_kernel(
     }
     float* so = reinterpret_cast<float*>(smem) + wave * (32 * FB_OPITCH);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const float a = o0[r] * inv_l, b = o1[r] * inv_l;
-        so[li * FB_OPITCH + crow32(r, hi)] = (IO == 1 && !split) ? pack_split(a) : a;       // (split-key partials stay fp32: the merge packs)
-        so[li * FB_OPITCH + 32 + crow32(r, hi)] = (IO == 1 && !split) ? pack_split(b) : b;
-    }
+    for (int b = 0; b < NO; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float a = o[b][r] * inv_l;
+            so[li * FB_OPITCH + 32 * b + crow32(r, hi)] = (IO == 1 && !split) ? pack_split(a) : a;   // (split-key partials stay fp32: the merge packs)
+        }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int idx = lane + 64 * i;             // 512 float4 = 32 rows x 16
-        const int r = idx >> 4, c4 = (idx & 15) * 4;
+    for (int i = 0; i < FB_D / 8; ++i) {
+        const int idx = lane + 64 * i;             // 8 FB_D float4 = 32 rows x FB_D / 4
+        const int r = idx / (FB_D / 4), c4 = (idx % (FB_D / 4)) * 4;
         const int qr = q0 + wave * 32 + r;
         if (qr < n_tok) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(so + r * FB_OPITCH + c4);
@@ -332,10 +350,22 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bf16_kernel(
 
 }  // namespace
 
+// head dims other than 64 exist for the tensor formats of the bf16 modes only (io_split 1 | 2, transpose read), and
+// split-bf16 (two LDS planes) not at 128, where the tile buffers of two blocks no longer fit a CU
+bool flash_attn_bf16_supports(int head_dim, int terms, int use_tr, int io_split) {
+    if (head_dim == 64) return true;
+    if (head_dim != 32 && head_dim != 128) return false;
+    if (!use_tr || !io_split) return false;
+    if (io_split == 2 && terms != 1) return false;
+    return head_dim == 32 || terms == 1;
+}
+
 int launch_flash_attn_bf16(const float* Q, int ldq, const float* K, const float* V, int ldkv, float* O, int ldo,
                            const int4* tiles, int n_tiles, float scale_log2e, int terms, int use_tr, int io_split,
-                           hipStream_t s, const FlashSplit* split, int pv_terms) {
+                           hipStream_t s, const FlashSplit* split, int pv_terms, int head_dim) {
     if (n_tiles <= 0) return 0;
+    const int FB_D = head_dim;
+    if (!flash_attn_bf16_supports(head_dim, terms, use_tr, io_split)) return fail(-1, "flash_attn_bf16: head dim / format combination not built");
     if ((ldq | ldkv | ldo) & 3) return fail(-1, "flash_attn: leading dims must be multiples of 4");
     if (terms != 1 && terms != 3) return fail(-1, "flash_attn_bf16: terms must be 1 or 3");
     FlashSplit sp{};
@@ -345,6 +375,17 @@ int launch_flash_attn_bf16(const float* Q, int ldq, const float* K, const float*
             return fail(-1, "flash_attn: incomplete split-key workspace");
     }
 #define VLSAT_FA(T, R, S) hipLaunchKernelGGL((flash_attn_bf16_kernel<T, R, S>), dim3(n_tiles), dim3(256), 0, s, Q, K, V, O, ldq, ldkv, ldo, tiles, n_tiles, scale_log2e, sp)
+#define VLSAT_FAD(T, S, P, D) hipLaunchKernelGGL((flash_attn_bf16_kernel<T, true, S, P, D>), dim3(n_tiles), dim3(256), 0, s, Q, K, V, O, ldq, ldkv, ldo, tiles, n_tiles, scale_log2e, sp)
+    if (FB_D != 64) {          // 16 / 4 heads: the formats the forward uses (the transpose-read path; split-bf16 only at 32)
+        if (FB_D == 32) {
+            if (io_split == 2) VLSAT_FAD(1, 2, 3, 32);
+            else if (terms == 3 && pv_terms == 2) VLSAT_FAD(3, 1, 2, 32);
+            else if (terms == 3) VLSAT_FAD(3, 1, 3, 32);
+            else VLSAT_FAD(1, 1, 3, 32);
+        } else {
+            if (io_split == 2) VLSAT_FAD(1, 2, 3, 128); else VLSAT_FAD(1, 1, 3, 128);
+        }
+    } else
     if (io_split == 2) {
         if (!use_tr || terms != 1) return fail(-1, "flash_attn_bf16: half-row tensors need terms = 1 and the transpose-read path");
         VLSAT_FA(1, true, 2);
@@ -356,8 +397,9 @@ int launch_flash_attn_bf16(const float* Q, int ldq, const float* K, const float*
     } else if (terms == 3) { if (use_tr) VLSAT_FA(3, true, 0); else VLSAT_FA(3, false, 0); }
     else                   { if (use_tr) VLSAT_FA(1, true, 0); else VLSAT_FA(1, false, 0); }
 #undef VLSAT_FA
+#undef VLSAT_FAD
     VLSAT_LAUNCH_CHECK("flash_attn_bf16");
-    if (sp.parts > 1) return launch_flash_merge(O, ldo, sp, s, io_split);
+    if (sp.parts > 1) return launch_flash_merge(O, ldo, sp, s, io_split, FB_D);
     return 0;
 }
 

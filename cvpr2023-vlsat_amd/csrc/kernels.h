@@ -90,7 +90,8 @@ int launch_flash_merge(float* O, int ldo, const FlashSplit& sp, hipStream_t s, i
 // scaled), K, V and O are in the split-pair format of the bf16 modes (common.h pack_split)
 int launch_flash_attn_bf16(const float* Q, int ldq, const float* K, const float* V, int ldkv, float* O, int ldo,
                            const int4* tiles, int n_tiles, float scale_log2e, int terms, int use_tr, int io_split,
-                           hipStream_t s, const FlashSplit* split = nullptr, int pv_terms = 3);
+                           hipStream_t s, const FlashSplit* split = nullptr, int pv_terms = 3, int head_dim = 64);
+bool flash_attn_bf16_supports(int head_dim, int terms, int use_tr, int io_split);   // which (head dim, format) combinations are built
 constexpr int FLASH_BQ = 128;   // queries per block
 
 // ---- node attention with distance bias (per scene, per head) ----

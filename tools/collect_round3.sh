@@ -33,6 +33,12 @@ import sys, json
 d = json.loads(sys.stdin.read()); r = d['roofline']
 print('NUM_HEADS=$hd gate_heads_mfma=$on: %.1f scenes/s, %.2f ms/step; gate %.2f TF (%.0f %% of the step), edge attention %.1f TF (%.0f %%)' % (d['value'], d['ms_per_step'], r['class_tflops']['edge_gate'], 100 * r['time_share']['edge_gate'], r['class_tflops']['flash_attn_f32'], 100 * r['time_share']['flash_attn_f32']))"
 done; done > "$OUT/heads.txt" 2>&1
+for m in bf16_mixed bf16x3; do for hd in 4 16; do
+  python bench.py --no-cpu --no-extra --steps 5 --warmup 2 --heads $hd --gemm-precision $m 2>/dev/null | grep "^{" | python -c "
+import sys, json
+d = json.loads(sys.stdin.read()); r = d['roofline']
+print('NUM_HEADS=$hd $m: %.1f scenes/s, %.2f ms/step; edge attention %.1f TF (%.0f %% of the step), gate %.1f TF (%.0f %%)' % (d['value'], d['ms_per_step'], r['class_tflops']['flash_attn_f32'], 100 * r['time_share']['flash_attn_f32'], r['class_tflops']['edge_gate'], 100 * r['time_share']['edge_gate']))"
+done; done >> "$OUT/heads.txt" 2>&1
 python tools/eval_synth.py > "$OUT/eval_synth.txt" 2>&1
 python tools/switch_scan.py > "$OUT/switch_scan.txt" 2>&1
 python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -3 > "$OUT/tests_gpu.log"
