@@ -41,5 +41,6 @@ print('NUM_HEADS=$hd $m: %.1f scenes/s, %.2f ms/step; edge attention %.1f TF (%.
 done; done >> "$OUT/heads.txt" 2>&1
 python tools/eval_synth.py > "$OUT/eval_synth.txt" 2>&1
 python tools/switch_scan.py > "$OUT/switch_scan.txt" 2>&1
+python tools/fuzz_forward.py --iters 120 > "$OUT/fuzz_forward.txt" 2>&1
 python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -3 > "$OUT/tests_gpu.log"
 du -sh "$OUT"; ls "$OUT"

@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Randomised end-to-end check of the HIP forward against the fp64 oracle: random MODEL.* configurations (layers, heads,
+DIM_ATTEN, aggregator, USE_GCN_EDGE, WITH_BN, multi_rel_outputs, colour / normal channels), random ragged batches with
+arbitrary edge lists (unsorted, self loops, duplicates, empty scenes, scenes of one object), random precision mode.
+
+    python tools/fuzz_forward.py [--iters 60] [--seed 0]
+
+Exit code 1 on the first configuration outside its tolerance: max-abs 1e-4 (fp32), 1e-3 (bf16x3), 1e-2 (bf16_mixed, Xavier-scale
+weights) relative to max(1, max |reference|) of the output -- the log_softmax heads (multi_rel_outputs = False) reach 5 in
+magnitude, and the single-rounding mode is 3e-3 of that off (first found by this tool; the same with every kernel choice)."""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import vlsat_amd  # noqa: E402,F401
+from vlsat_amd import VLSATConfig, synth  # noqa: E402
+from vlsat_amd.model import VLSATModel  # noqa: E402
+from oracle import vlsat_oracle as O  # noqa: E402  (the checker; tools/ is test infrastructure)
+
+NAMES = ("obj3d", "obj2d", "rel3d", "rel2d")
+TOL = {"fp32": 1e-4, "bf16x3": 1e-3, "bf16_mixed": 1e-2}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=60)
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+    g = np.random.default_rng(a.seed)
+    worst = {m: 0.0 for m in TOL}
+    for it in range(a.iters):
+        heads = int(g.choice([4, 8, 16]))
+        kw = dict(N_LAYERS=int(g.integers(1, 4)), NUM_HEADS=heads, DIM_ATTEN=int(g.choice([128, 256, 512])),
+                  GCN_AGGR=str(g.choice(["max", "add", "mean"])), USE_GCN_EDGE=bool(g.integers(0, 2)),
+                  WITH_BN=bool(g.integers(0, 2)), multi_rel_outputs=bool(g.integers(0, 4) > 0),
+                  USE_RGB=bool(g.integers(0, 3) == 0), USE_NORMAL=bool(g.integers(0, 3) == 0))
+        cfg = VLSATConfig(**kw)
+        n_pts = int(g.integers(1, 300))
+        scenes = []
+        for s in range(int(g.integers(1, 6))):
+            n = int(g.integers(1, 14))
+            sc = synth.make_scene(n, n_pts, 20000 + 100 * it + s)
+            if cfg.dim_point > 3:
+                sc["obj_points"] = np.concatenate([sc["obj_points"], g.uniform(-1, 1, (n, cfg.dim_point - 3, n_pts)).astype(np.float32)], 1)
+            if g.integers(0, 3):          # arbitrary edge list (else: the fully connected one)
+                pairs = np.stack(np.meshgrid(np.arange(n), np.arange(n), indexing="ij"), 0).reshape(2, -1)
+                k = int(g.integers(0, pairs.shape[1] + 3))
+                pick = g.integers(0, pairs.shape[1], k) if k else np.zeros(0, np.int64)
+                sc["edge_indices"] = np.ascontiguousarray(pairs[:, pick]).astype(np.int64).reshape(2, -1)
+            scenes.append(sc)
+        b = synth.collate(scenes)
+        w = synth.make_weights(cfg)
+        c = {k: torch.from_numpy(v) for k, v in b.items()}
+        ref = O.forward(O.to_torch(w, torch.float64), cfg, c["obj_points"].double(), c["obj_2d_feats"].double(), c["edge_indices"],
+                        c["descriptor"].double(), c["batch_ids"])
+        mode = str(g.choice(list(TOL)))
+        m = VLSATModel(cfg, "cuda:0").load_state(w).eval().set_gemm_precision(mode)
+        try:
+            d = {k: v.to("cuda:0") for k, v in c.items()}
+            got = [o.cpu() for o in m(d["obj_points"], d["obj_2d_feats"], d["edge_indices"], d["descriptor"], d["batch_ids"])]
+        finally:
+            m.close()
+        err = 0.0
+        for n_, x, r in zip(NAMES, got, ref):
+            assert x.shape == r.shape, (n_, x.shape, r.shape)
+            if x.numel():
+                assert torch.isfinite(x).all(), (it, kw, n_)
+                err = max(err, float((x - r.float()).abs().max()) / max(1.0, float(r.abs().max())))
+        worst[mode] = max(worst[mode], err)
+        flag = "" if err < TOL[mode] else "   <-- OUTSIDE TOLERANCE"
+        print(f"#{it:3d} {mode:10s} L={kw['N_LAYERS']} H={heads:2d} A={kw['DIM_ATTEN']} {kw['GCN_AGGR']:4s} edge={int(kw['USE_GCN_EDGE'])} bn={int(kw['WITH_BN'])} "
+              f"multi={int(kw['multi_rel_outputs'])} ch={cfg.dim_point} P={n_pts:3d} N={b['obj_points'].shape[0]:2d} E={b['edge_indices'].shape[1]:3d}: {err:.2e}{flag}", flush=True)
+        if flag:
+            sys.exit(1)
+    print("worst per mode:", {k: f"{v:.2e}" for k, v in worst.items()})
+
+
+if __name__ == "__main__":
+    main()

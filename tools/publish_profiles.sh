@@ -16,7 +16,7 @@ cp $S/prof_cfg3/kernel_stats.md $D/${R}_cfg3_bf16x3_kernel_stats.md;  cp $S/prof
 cp $S/prof_cfg3_mixed/kernel_stats.md $D/${R}_cfg3_bf16_mixed_kernel_stats.md; cp $S/prof_cfg3_mixed/pmc.md $D/${R}_cfg3_bf16_mixed_pmc.md
 for hd in 4 16; do cp $S/prof_heads$hd/kernel_stats.md $D/${R}_heads${hd}_kernel_stats.md; cp $S/prof_heads$hd/pmc.md $D/${R}_heads${hd}_pmc.md; done
 for m in fp32 bf16x3 bf16_mixed; do grep -v amdgpu.ids $S/latency_$m.txt > $D/${R}_latency_$m.txt; done
-for f in gemm_fp32 gemm_fp32_no_p8 gemm_bf16_half gemm_bf16_half_cold gemm_p8_ablation gemm_p8_ablation_cold gemm_p8_gather_ablation heads switch_scan gemm_bf16x3 gemm_bf16x3_no_p8 eval_synth; do
+for f in gemm_fp32 gemm_fp32_no_p8 gemm_bf16_half gemm_bf16_half_cold gemm_p8_ablation gemm_p8_ablation_cold gemm_p8_gather_ablation heads switch_scan fuzz_forward gemm_bf16x3 gemm_bf16x3_no_p8 eval_synth; do
   grep -v amdgpu.ids $S/$f.txt > $P/$f.txt
 done
 cp $S/tests_gpu.log $D/${R}_tests_gpu.txt
