@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised end-to-end check of the HIP forward against the fp64 oracle: random MODEL.* configurations (layers, heads,
-DIM_ATTEN, aggregator, USE_GCN_EDGE, WITH_BN, multi_rel_outputs, colour / normal channels), random ragged batches with
+DIM_ATTEN, aggregator, USE_GCN_EDGE, WITH_BN, multi_rel_outputs, colour / normal channels, feature_transform), random ragged batches with
 arbitrary edge lists (unsorted, self loops, duplicates, empty scenes, scenes of one object), random precision mode.
 
     python tools/fuzz_forward.py [--iters 60] [--seed 0]
@@ -37,7 +37,8 @@ def main():
         kw = dict(N_LAYERS=int(g.integers(1, 4)), NUM_HEADS=heads, DIM_ATTEN=int(g.choice([128, 256, 512])),
                   GCN_AGGR=str(g.choice(["max", "add", "mean"])), USE_GCN_EDGE=bool(g.integers(0, 2)),
                   WITH_BN=bool(g.integers(0, 2)), multi_rel_outputs=bool(g.integers(0, 4) > 0),
-                  USE_RGB=bool(g.integers(0, 3) == 0), USE_NORMAL=bool(g.integers(0, 3) == 0))
+                  USE_RGB=bool(g.integers(0, 3) == 0), USE_NORMAL=bool(g.integers(0, 3) == 0),
+                  feature_transform=bool(g.integers(0, 6) == 0))
         cfg = VLSATConfig(**kw)
         n_pts = int(g.integers(1, 300))
         scenes = []
@@ -73,7 +74,7 @@ def main():
         worst[mode] = max(worst[mode], err)
         flag = "" if err < TOL[mode] else "   <-- OUTSIDE TOLERANCE"
         print(f"#{it:3d} {mode:10s} L={kw['N_LAYERS']} H={heads:2d} A={kw['DIM_ATTEN']} {kw['GCN_AGGR']:4s} edge={int(kw['USE_GCN_EDGE'])} bn={int(kw['WITH_BN'])} "
-              f"multi={int(kw['multi_rel_outputs'])} ch={cfg.dim_point} P={n_pts:3d} N={b['obj_points'].shape[0]:2d} E={b['edge_indices'].shape[1]:3d}: {err:.2e}{flag}", flush=True)
+              f"multi={int(kw['multi_rel_outputs'])} ft={int(kw['feature_transform'])} ch={cfg.dim_point} P={n_pts:3d} N={b['obj_points'].shape[0]:2d} E={b['edge_indices'].shape[1]:3d}: {err:.2e}{flag}", flush=True)
         if flag:
             sys.exit(1)
     print("worst per mode:", {k: f"{v:.2e}" for k, v in worst.items()})
