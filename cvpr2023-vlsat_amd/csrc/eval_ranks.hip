@@ -174,14 +174,30 @@ __device__ __forceinline__ void row_stats(const float* __restrict__ a, const flo
 __global__ __launch_bounds__(256) void checksum_partial_kernel(const float* __restrict__ o3, const float* __restrict__ o2, long N, int C,
                                                                const float* __restrict__ r3, const float* __restrict__ r2, long E, int R,
                                                                double* __restrict__ part) {
+    // relation rows (R <= 32 floats, E of them): 256 rows at a time are one contiguous piece of each tensor -- staged through
+    // LDS with coalesced loads, then one thread per row (a thread walking its own 104-byte row in HBM is latency-bound: 60 us)
+    __shared__ float sa[256 * 32], sb[256 * 32];
     __shared__ double sh[6][256];
     double s[4] = {0, 0, 0, 0};
     int ag[2] = {0, 0};
-    const long stride = (long)gridDim.x * 256, t0 = (long)blockIdx.x * 256 + threadIdx.x;
-    for (long n = t0; n < N; n += stride) row_stats(o3 + n * C, o2 + n * C, C, s[0], s[1], ag[0]);
-    if (r3 && r2)
-        for (long e = t0; e < E; e += stride) row_stats(r3 + e * R, r2 + e * R, R, s[2], s[3], ag[1]);
     const int t = threadIdx.x;
+    const long stride = (long)gridDim.x * 256, t0 = (long)blockIdx.x * 256 + t;
+    for (long n = t0; n < N; n += stride) row_stats(o3 + n * C, o2 + n * C, C, s[0], s[1], ag[0]);
+    if (r3 && r2) {
+        if (R <= 32) {
+            for (long c0 = (long)blockIdx.x * 256; c0 < E; c0 += stride) {
+                const int rows = (int)(E - c0 < 256 ? E - c0 : 256), nfl = rows * R;
+                const float* pa = r3 + c0 * R;
+                const float* pb = r2 + c0 * R;
+                for (int i = t; i < nfl; i += 256) { sa[i] = pa[i]; sb[i] = pb[i]; }
+                __syncthreads();
+                if (t < rows) row_stats(sa + t * R, sb + t * R, R, s[2], s[3], ag[1]);
+                __syncthreads();
+            }
+        } else {
+            for (long e = t0; e < E; e += stride) row_stats(r3 + e * R, r2 + e * R, R, s[2], s[3], ag[1]);
+        }
+    }
     sh[0][t] = s[0]; sh[1][t] = s[1]; sh[2][t] = s[2]; sh[3][t] = s[3]; sh[4][t] = ag[0]; sh[5][t] = ag[1];
     __syncthreads();
     for (int w = 128; w > 0; w >>= 1) {            // fixed tree: thread t adds slot t + w
@@ -193,16 +209,22 @@ __global__ __launch_bounds__(256) void checksum_partial_kernel(const float* __re
     if (t < 6) part[(size_t)blockIdx.x * 6 + t] = sh[t][0];
 }
 
-__global__ __launch_bounds__(64) void checksum_final_kernel(const double* __restrict__ part, int n_blocks, double n_scenes, double N, double E,
-                                                            double* __restrict__ out) {
+// n_blocks <= 256 partials per quantity, added by the same fixed tree
+__global__ __launch_bounds__(256) void checksum_final_kernel(const double* __restrict__ part, int n_blocks, double n_scenes, double N, double E,
+                                                             double* __restrict__ out) {
+    __shared__ double sh[6][256];
     const int t = threadIdx.x;
-    if (t < 6) {
-        double a = 0;
-        for (int b = 0; b < n_blocks; ++b) a += part[(size_t)b * 6 + t];
-        out[3 + t] = a;
-    } else if (t == 6) {
-        out[0] = n_scenes; out[1] = N; out[2] = E;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) sh[k][t] = t < n_blocks ? part[(size_t)t * 6 + k] : 0.0;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (t < w)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) sh[k][t] += sh[k][t + w];
+        __syncthreads();
     }
+    if (t < 6) out[3 + t] = sh[t][0];
+    else if (t == 6) { out[0] = n_scenes; out[1] = N; out[2] = E; }
 }
 
 int launch_scene_checksums(const float* obj3d, const float* obj2d, long N, int C, const float* rel3d, const float* rel2d, long E, int R,
@@ -211,7 +233,7 @@ int launch_scene_checksums(const float* obj3d, const float* obj2d, long N, int C
     constexpr int B = 256;
     hipLaunchKernelGGL(checksum_partial_kernel, dim3(B), dim3(256), 0, s, obj3d, obj2d, N, C, E > 0 ? rel3d : nullptr, E > 0 ? rel2d : nullptr, E, R, scratch);
     VLSAT_LAUNCH_CHECK("checksum_partial");
-    hipLaunchKernelGGL(checksum_final_kernel, dim3(1), dim3(64), 0, s, scratch, B, (double)n_scenes, (double)N, (double)E, out9);
+    hipLaunchKernelGGL(checksum_final_kernel, dim3(1), dim3(256), 0, s, scratch, B, (double)n_scenes, (double)N, (double)E, out9);
     VLSAT_LAUNCH_CHECK("checksum_final");
     return 0;
 }
