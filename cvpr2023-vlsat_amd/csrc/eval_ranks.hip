@@ -182,7 +182,32 @@ __global__ __launch_bounds__(256) void checksum_partial_kernel(const float* __re
     int ag[2] = {0, 0};
     const int t = threadIdx.x;
     const long stride = (long)gridDim.x * 256, t0 = (long)blockIdx.x * 256 + t;
-    for (long n = t0; n < N; n += stride) row_stats(o3 + n * C, o2 + n * C, C, s[0], s[1], ag[0]);
+    {   // object rows (C = 160 floats): a wave per row, coalesced loads, fixed shuffle trees; lane 0 keeps the row's result
+        const int lane = t & 63;
+        const long wave0 = (long)blockIdx.x * 4 + (t >> 6), n_waves = (long)gridDim.x * 4;
+        for (long n = wave0; n < N; n += n_waves) {
+            const float* a = o3 + n * C;
+            const float* b = o2 + n * C;
+            double xa = 0, xb = 0;
+            float ma = -INFINITY, mb = -INFINITY;
+            int ia = 0x7fffffff, ib = 0x7fffffff;
+            for (int c = lane; c < C; c += 64) {
+                const float va = a[c], vb = b[c];
+                xa += va; xb += vb;
+                if (va > ma) { ma = va; ia = c; }      // (ascending c per lane: the first maximum of the lane's elements)
+                if (vb > mb) { mb = vb; ib = c; }
+            }
+#pragma unroll
+            for (int w = 32; w > 0; w >>= 1) {
+                xa += __shfl_xor(xa, w); xb += __shfl_xor(xb, w);
+                const float oa = __shfl_xor(ma, w), ob = __shfl_xor(mb, w);
+                const int ja = __shfl_xor(ia, w), jb = __shfl_xor(ib, w);
+                if (oa > ma || (oa == ma && ja < ia)) { ma = oa; ia = ja; }     // ties: the lowest class index, like torch.argmax
+                if (ob > mb || (ob == mb && jb < ib)) { mb = ob; ib = jb; }
+            }
+            if (lane == 0) { s[0] += xa; s[1] += xb; ag[0] += ia == ib; }
+        }
+    }
     if (r3 && r2) {
         if (R <= 32) {
             for (long c0 = (long)blockIdx.x * 256; c0 < E; c0 += stride) {
