@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libvlsat_hip.so")
-SOURCES = ["engine_weights.hip", "engine_plan.hip", "engine_forward.hip", "engine_api.hip", "gemm_f32.hip", "gemm_bf16_ring.hip", "gemm_bf16_p8.hip", "gemm_splitk.hip", "flash_attn_f32.hip", "flash_attn_bf16.hip", "pointnet.hip", "pointnet_bf16.hip", "edge_gate.hip", "edge_gate_bf16.hip", "edge_gate_heads.hip", "small_ops.hip", "stn.hip", "eval_ranks.hip", "prep.hip", "comm.hip"]
+SOURCES = ["engine_weights.hip", "engine_plan.hip", "engine_forward.hip", "engine_api.hip", "gemm_f32.hip", "gemm_bf16_ring.hip", "gemm_bf16_p8.hip", "gemm_splitk.hip", "flash_attn_f32.hip", "flash_attn_bf16.hip", "pointnet.hip", "pointnet_bf16.hip", "edge_gate.hip", "edge_gate_bf16.hip", "edge_gate_heads.hip", "edge_gate_bf16_heads.hip", "small_ops.hip", "stn.hip", "eval_ranks.hip", "prep.hip", "comm.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 
 

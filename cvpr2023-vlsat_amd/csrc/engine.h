@@ -82,7 +82,7 @@ struct vlsat_ctx {
     int64_t acc_n[vlsat::PC_COUNT] = {0};
     double acc_fl[vlsat::PC_COUNT] = {0};
     int debug_stop = -1;
-    int gemm_no_dma = 0, gate_grid = 0, gate_row_map = 1, gate_heads_mfma = 1, flash_heads_bf16 = 1;      // vlsat_debug_option
+    int gemm_no_dma = 0, gate_grid = 0, gate_row_map = 1, gate_heads_mfma = 1, flash_heads_bf16 = 1, gate_heads_bf16 = 1;      // vlsat_debug_option
     int gemm_no_p8 = 0;                      // vlsat_debug_option "gemm_p8": 0 keeps half-row launches off the 8-phase kernel
     int node_attn_split = 1024;              // node attention: sixteen lanes per query when the plan has fewer waves than this
     long config_epoch = 0;                   // bumped by every call that changes what a forward launches (graphs are re-captured)

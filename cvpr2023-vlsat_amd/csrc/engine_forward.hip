@@ -138,6 +138,8 @@ int gcn_block(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const GcnW& w, float
     RUN(gemm(h, s, G(x, LDX, w.wnode, D, sc.NP, NPC, N, NPC, w.bnode)));
     const int S = split_fmt(h);
     const bool gate16 = h->prec_edge && h->gate_bf16 && default_heads(h);
+    const bool gate16h = h->prec_edge && h->gate_bf16 && !default_heads(h) && h->gate_heads_mfma && h->gate_heads_bf16 &&
+                         edge_gate_bf16_heads_supports(D / h->H, A / h->H, h->prec_edge == 3 ? 3 : 1);   // other head geometries, bf16 kernel
     GemmArgs e1 = G(e, D, w.we1, D, sc.Hbig, 2 * D, E, 2 * D, nullptr, ACT_RELU);
     e1.relu_a = e_relu_pending;
     e1.a_split = S; e1.c_split = S;
@@ -148,7 +150,7 @@ int gcn_block(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const GcnW& w, float
         GemmArgs kp = G(e, D, w.wpe, D, sc.KP, D, E, D, w.bpe);
         kp.relu_a = e_relu_pending;
         kp.a_split = S;
-        kp.c_split = gate16 ? S : 0;      // (the fp32 gate kernel reads plain fp32)
+        kp.c_split = (gate16 || gate16h) ? S : 0;      // (the fp32 gate kernels read plain fp32)
         RUN(gemm(h, s, kp));
     }
     GemmArgs e2 = G(sc.Hbig, 2 * D, w.we2, 2 * D, e, D, E, D, w.be2);       // e <- nn_edge output (pre-activation)
@@ -161,7 +163,9 @@ int gcn_block(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const GcnW& w, float
         g.prob = p->prob; g.n_edges = E; g.use_edge = h->d.use_gcn_edge; g.grid_cap = h->gate_grid; g.row_map = h->gate_row_map;
         const double dk = D / h->H, dox = A / h->H;
         Scope scope(h, s, PC_GATE, (double)E * h->H * (2.0 * dk * 2 * dk + 2.0 * 2 * dk * dox));
-        if (!default_heads(h) || (h->gate_heads_mfma == 2 && !gate16)) {     // (2: the shipped geometry on the template as well -- A/B)
+        if (gate16h) {
+            RUN(launch_edge_gate_bf16_heads(g, h->H, D / h->H, A / h->H, h->prec_edge == 3 ? 3 : 1, S, s));
+        } else if (!default_heads(h) || (h->gate_heads_mfma == 2 && !gate16)) {     // (2: the shipped geometry on the template as well -- A/B)
             int r = h->gate_heads_mfma ? launch_edge_gate_heads(g, h->H, D / h->H, A / h->H, s) : 1;
             if (r < 0) return r;
             if (r) RUN(launch_edge_gate_generic(g, h->H, D / h->H, A / h->H, s));

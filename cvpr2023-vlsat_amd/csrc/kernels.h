@@ -155,6 +155,9 @@ int launch_edge_gate_generic(const GateArgs& a, int n_heads, int dk, int dox, hi
 // the head geometries of MODEL.NUM_HEADS in {4, 8, 16} x DIM_ATTEN in {128, 256, 512} on the fp32 matrix cores
 // (edge_gate_heads.hip); returns 1 when (dk, dox) is not one of them (-> the VALU kernel)
 int launch_edge_gate_heads(const GateArgs& a, int n_heads, int dk, int dox, hipStream_t s);
+// ... and on the bf16 matrix cores (edge_gate_bf16_heads.hip); split-bf16 (terms = 3) not at dk = 128
+bool edge_gate_bf16_heads_supports(int dk, int dox, int terms);
+int launch_edge_gate_bf16_heads(const GateArgs& a, int n_heads, int dk, int dox, int terms, int kproj_split, hipStream_t s);
 // the same on the bf16 matrix cores (edge_gate_bf16.hip): terms = 3 split-bf16 | 1 single-rounded; kproj_split = 1: kproj is
 // in the split-pair format of the bf16 modes (common.h pack_split)
 int launch_edge_gate_bf16(const GateArgs& a, int terms, int kproj_split, hipStream_t s);
