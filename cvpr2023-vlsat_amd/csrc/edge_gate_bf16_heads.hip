@@ -224,7 +224,7 @@ int pick(const GateArgs& a, int n_heads, int terms, int ks, hipStream_t s) {
 }  // namespace
 
 bool edge_gate_bf16_heads_supports(int dk, int dox, int terms) {
-    const bool geo = (dk == 32 && (dox == 8 || dox == 16 || dox == 32)) || (dk == 64 && (dox == 16 || dox == 64)) ||
+    const bool geo = (dk == 32 && (dox == 8 || dox == 16 || dox == 32)) || (dk == 64 && (dox == 16 || dox == 32 || dox == 64)) ||
                      (dk == 128 && (dox == 32 || dox == 64 || dox == 128));
     return geo && (terms == 1 || (terms == 3 && dk != 128));
 }
@@ -240,7 +240,7 @@ int launch_edge_gate_bf16_heads(const GateArgs& a, int n_heads, int dk, int dox,
     int r = 1;
 #define VLSAT_GH(DK, DOX) if (dk == DK && dox == DOX) r = pick<DK, DOX>(a, n_heads, terms, kproj_split, s)
     VLSAT_GH(32, 8); VLSAT_GH(32, 16); VLSAT_GH(32, 32);
-    VLSAT_GH(64, 16); VLSAT_GH(64, 64);
+    VLSAT_GH(64, 16); VLSAT_GH(64, 32); VLSAT_GH(64, 64);
     VLSAT_GH(128, 32); VLSAT_GH(128, 64); VLSAT_GH(128, 128);
 #undef VLSAT_GH
     if (r) return r;

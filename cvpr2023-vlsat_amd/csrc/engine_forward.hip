@@ -138,7 +138,7 @@ int gcn_block(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const GcnW& w, float
     RUN(gemm(h, s, G(x, LDX, w.wnode, D, sc.NP, NPC, N, NPC, w.bnode)));
     const int S = split_fmt(h);
     const bool gate16 = h->prec_edge && h->gate_bf16 && default_heads(h);
-    const bool gate16h = h->prec_edge && h->gate_bf16 && !default_heads(h) && h->gate_heads_mfma && h->gate_heads_bf16 &&
+    const bool gate16h = h->prec_edge && h->gate_bf16 && (!default_heads(h) || h->gate_heads_mfma == 2) && h->gate_heads_mfma && h->gate_heads_bf16 &&
                          edge_gate_bf16_heads_supports(D / h->H, A / h->H, h->prec_edge == 3 ? 3 : 1);   // other head geometries, bf16 kernel
     GemmArgs e1 = G(e, D, w.we1, D, sc.Hbig, 2 * D, E, 2 * D, nullptr, ACT_RELU);
     e1.relu_a = e_relu_pending;
