@@ -235,11 +235,11 @@ def main():
     evaluation, plain = None, None
     if not args.no_extra:                                # collectives: every rank takes part
         if prof:
-            # The same K steps again without the per-class HIP events: the instrumented run above (the headline `value`)
-            # serialises the 2D twin stages on the launch stream so that class times are attributable; a deployment runs them
-            # on the library's second stream.
+            # The same K steps again without the per-class HIP events (both runs execute the 2D twin stages on the library's
+            # second stream; the instrumented one, the headline `value`, records an event per kernel-class change on either
+            # stream and charges a class the union of its intervals).
             r2 = timed_run(model, d, n_scenes, args.steps, args.warmup, False, dev)
-            plain = {"what": "same batch and steps, no HIP-event instrumentation, 2D twin stages on the library's second stream",
+            plain = {"what": "same batch and steps without the per-class HIP events (cost of the instrumentation: ~150 event records per step)",
                      "value": None, "ms_per_step": round(r2["dt"] / args.steps * 1e3, 3), "median_ms_per_step": round(r2["median_ms"], 3),
                      "_dt": r2["dt"]}
         evaluation = eval_leg(model, list(scenes), d, args.objects, dev)

@@ -74,8 +74,11 @@ struct vlsat_ctx {
     bool prof = false;
     struct Rec { int cls; hipEvent_t a, b; double flops; long kernels; };
     std::vector<Rec> recs;
-    Rec open{};              // interval of the kernel class currently being launched (see Scope)
-    bool open_ok = false;
+    Rec open[2] = {};        // per stream (0 launch stream, 1 side stream): interval of the kernel class being launched (see Scope)
+    bool open_ok[2] = {false, false};
+    hipEvent_t prof_base = nullptr;       // time origin of the current batch of records (intervals of the two streams are
+    bool prof_base_set = false;           // put on one timeline and a class's time is the length of their UNION)
+    int prof_dual = 1;                    // keep the two-stream execution while profiling (vlsat_debug_option "prof_dual")
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
     double acc_ms[vlsat::PC_COUNT] = {0};

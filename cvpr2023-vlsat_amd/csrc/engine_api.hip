@@ -40,6 +40,7 @@ int vlsat_set_edge_attention_scope(vlsat_handle h, int32_t scope) {
 //   "gemm_dma"    0|1   LDS-direct staging of fp32 GEMM operands (0: VGPR-staged)
 //   "gemm_p8"     0|1   single-rounding bf16 modes: large half-row launches on the 256 x 256 8-phase kernel (0: ring kernel)
 //   "gate_grid"   n     persistent grid of the gate kernel (0: default)
+//   "prof_dual"   0|1   per-class profiling keeps the two-stream execution (1, default) or serialises on the launch stream
 //   "gate_heads_bf16" 0|1   bf16 modes at other head geometries: the gate on the bf16 kernel (1, default) or the fp32 one
 //   "flash_heads_bf16" 0|1  bf16 modes at 4 / 16 heads: edge attention on the bf16 kernel (1, default) or the fp32 one
 //   "gate_heads_mfma" 0|1  non-default head geometries: the MFMA gate kernel (1, default) or the VALU one
@@ -62,6 +63,7 @@ int vlsat_debug_option(vlsat_handle h, const char* name, int32_t value) {
     else if (k == "gemm_p8") h->gemm_no_p8 = value == 0;
     else if (k == "gate_grid") h->gate_grid = value > 0 ? value : 0;
     else if (k == "gate_row_map") h->gate_row_map = value != 0;
+    else if (k == "prof_dual") h->prof_dual = value != 0;
     else if (k == "gate_heads_bf16") h->gate_heads_bf16 = value != 0;
     else if (k == "flash_heads_bf16") h->flash_heads_bf16 = value != 0;
     else if (k == "gate_heads_mfma") h->gate_heads_mfma = value < 0 ? 0 : value > 2 ? 2 : value;

@@ -42,38 +42,47 @@ hipEvent_t next_event(vlsat_ctx* h) {
     }
     return h->ev_pool[h->ev_used++];
 }
-// Per-class timing with as few events as possible: an event is recorded only where the kernel CLASS changes
-// (a run of consecutive launches of one class is one interval), plus one at the end of the forward.
+// Per-class timing with as few events as possible: on each stream an event is recorded only where the kernel CLASS changes
+// (a run of consecutive launches of one class is one interval), plus one where the stream's work ends (join / end of the
+// forward).  With the 2D twin stages on the side stream the intervals of the two streams overlap; vlsat_profile_read puts
+// them on one timeline (a base event per batch of records) and charges a class the length of the UNION of its intervals.
+static inline int prof_lane(const vlsat_ctx* h, hipStream_t s) { return (h->side && s == h->side) ? 1 : 0; }
 struct Scope {
     vlsat_ctx* h;
     hipStream_t s;
-    int cls;
+    int cls, w;
     double flops;
     long k0 = 0;
-    Scope(vlsat_ctx* h_, hipStream_t s_, int cls_, double fl) : h(h_), s(s_), cls(cls_), flops(fl) {
+    Scope(vlsat_ctx* h_, hipStream_t s_, int cls_, double fl) : h(h_), s(s_), cls(cls_), w(prof_lane(h_, s_)), flops(fl) {
         k0 = h->gemm_launches;
         if (!h->prof) return;
-        if (h->open_ok && h->open.cls == cls) return;              // same class: the open interval continues
+        if (h->open_ok[w] && h->open[w].cls == cls) return;        // same class: the open interval continues
+        if (!h->prof_base_set) {                                   // first record of a batch: the time origin
+            if (!h->prof_base) hipEventCreate(&h->prof_base);
+            hipEventRecord(h->prof_base, s);
+            h->prof_base_set = true;
+        }
         hipEvent_t e = next_event(h);
         hipEventRecord(e, s);
-        if (h->open_ok) { h->open.b = e; h->recs.push_back(h->open); }
-        h->open = {cls, e, e, 0.0, 0};
-        h->open_ok = true;
+        if (h->open_ok[w]) { h->open[w].b = e; h->recs.push_back(h->open[w]); }
+        h->open[w] = {cls, e, e, 0.0, 0};
+        h->open_ok[w] = true;
     }
     ~Scope() {
         if (!h->prof) return;
-        h->open.flops += flops;
-        h->open.kernels += cls == PC_GEMM ? h->gemm_launches - k0 : 1;
+        h->open[w].flops += flops;
+        h->open[w].kernels += cls == PC_GEMM ? h->gemm_launches - k0 : 1;
     }
 };
-// end of a forward (or of a debug-stopped one): close the open interval
+// end of a stream's work (join, end of a forward, a debug-stopped one): close its open interval
 static void profile_close(vlsat_ctx* h, hipStream_t s) {
-    if (!h->prof || !h->open_ok) return;
+    const int w = prof_lane(h, s);
+    if (!h->prof || !h->open_ok[w]) return;
     hipEvent_t e = next_event(h);
     hipEventRecord(e, s);
-    h->open.b = e;
-    h->recs.push_back(h->open);
-    h->open_ok = false;
+    h->open[w].b = e;
+    h->recs.push_back(h->open[w]);
+    h->open_ok[w] = false;
 }
 
 // Every nn.Linear of the path.  Operand precision follows the handle's mode: node-row launches (M == number of nodes
@@ -285,7 +294,7 @@ static int forward_impl(vlsat_handle h, vlsat_plan p, const float* pts, const fl
                 hipEventDestroy(e);                                   // (destruction is deferred until the event completes)
             }
         }
-        h->open_ok = false;                                           // a profiling interval left open is dropped
+        h->open_ok[0] = h->open_ok[1] = false;                        // profiling intervals left open are dropped
         hipEventRecord(p->last_use, s);
         set_error(msg);
     }
@@ -320,7 +329,7 @@ static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const fl
     // Two-stream mode (small plans only; not while profiling or stopping at a debug stage): `t` carries the 2D twin
     // of a stage while `s` carries the 3D one.  fork(): t waits for everything enqueued on s so far; join(): s waits
     // for t.  Every forward ends joined, so the caller only ever sees its own stream.
-    const bool dual = p->dual && do2d && (!h->prof || capture) && stop < 0 && !tr;
+    const bool dual = p->dual && do2d && (!h->prof || capture || h->prof_dual) && stop < 0 && !tr;
     hipStream_t t = s;
     size_t ev_i = 0;
     if (dual) {
@@ -345,7 +354,10 @@ static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const fl
         return 0;
     };
     auto fork = [&]() { return order(s, t); };
-    auto join = [&]() { return order(t, s); };
+    auto join = [&]() {
+        if (dual && !capture) profile_close(h, t);          // the side stream's open interval ends with its work
+        return order(t, s);
+    };
     const Scratch sc3 = scratch_of(p, 0), sc2 = scratch_of(p, dual ? 1 : 0);
     const int S = split_fmt(h);            // edge tensors in the split-pair format (bf16 modes)
 
@@ -589,16 +601,30 @@ const char* vlsat_profile_class_name(int32_t c) { return (c >= 0 && c < PC_COUNT
 
 static int profile_drain(vlsat_handle h) {
     if (h->recs.empty()) return 0;
-    VLSAT_HIP_CHECK(hipEventSynchronize(h->recs.back().b));
+    struct Iv { float a, b; };
+    std::vector<Iv> iv[PC_COUNT];
     for (auto& r : h->recs) {
-        float ms = 0.f;
-        VLSAT_HIP_CHECK(hipEventElapsedTime(&ms, r.a, r.b));
-        h->acc_ms[r.cls] += ms;
+        VLSAT_HIP_CHECK(hipEventSynchronize(r.b));
+        Iv x{0.f, 0.f};
+        VLSAT_HIP_CHECK(hipEventElapsedTime(&x.a, h->prof_base, r.a));
+        VLSAT_HIP_CHECK(hipEventElapsedTime(&x.b, h->prof_base, r.b));
+        iv[r.cls].push_back(x);
         h->acc_n[r.cls] += r.kernels;
         h->acc_fl[r.cls] += r.flops;
     }
+    for (int c = 0; c < PC_COUNT; ++c) {                 // length of the union of the class's intervals (two streams may overlap)
+        auto& v = iv[c];
+        std::sort(v.begin(), v.end(), [](const Iv& x, const Iv& y) { return x.a < y.a; });
+        double tot = 0, end = -1e30;
+        for (const Iv& x : v) {
+            if (x.a > end) { tot += x.b - x.a; end = x.b; }
+            else if (x.b > end) { tot += x.b - end; end = x.b; }
+        }
+        h->acc_ms[c] += tot;
+    }
     h->recs.clear();
     h->ev_used = 0;
+    h->prof_base_set = false;
     return 0;
 }
 int vlsat_profile_read(vlsat_handle h, int32_t cls, double* total_ms, int64_t* launches, double* flops) {

@@ -270,6 +270,7 @@ void vlsat_destroy(vlsat_handle h) {
     free_device_weights(h);
     release_plan_resources(h);
     for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
+    if (h->prof_base) hipEventDestroy(h->prof_base);
     for (hipEvent_t e : h->sync_ev) hipEventDestroy(e);
     if (h->side) hipStreamDestroy(h->side);
     if (h->copy) hipStreamDestroy(h->copy);

@@ -294,7 +294,7 @@ int vlsat_debug_gemm_clock_probe(int64_t* buf);
 /* Experiment switches of one handle; defaults are the measured-best settings and none changes results beyond
  * fp32 summation order.  "dual_stream" 0|1|2: 2D twin stages on a second stream (1: launch-bound plans only, 2 = default: every plan); "flash_split" 0|1:
  * split-key edge attention for plans that cannot fill the chip (both: plans created afterwards); "gemm_dma" 0|1:
- * LDS-direct staging of fp32 GEMM operands; "gate_grid" n: persistent grid of the gate kernel (0 = default); "gate_heads_bf16" 0|1: bf16 modes at head geometries other than 8 x (64, 32), the gate on the bf16 kernel (1, default) or the fp32 one; "flash_heads_bf16" 0|1: bf16 modes at NUM_HEADS 4 / 16, edge attention on the bf16 kernel (1, default) or the fp32 one; "gate_heads_mfma" 0|1|2: NUM_HEADS / DIM_ATTEN other than 8 / 256 on the MFMA gate kernel (1, default) or the VALU one; "gate_row_map" 0|1: a gate wave owns 32 edges of one head (1, default) or 4 edges x 8 heads;
+ * LDS-direct staging of fp32 GEMM operands; "gate_grid" n: persistent grid of the gate kernel (0 = default); "prof_dual" 0|1: per-class profiling keeps the two-stream execution (1, default) or serialises the forward on the launch stream; "gate_heads_bf16" 0|1: bf16 modes at head geometries other than 8 x (64, 32), the gate on the bf16 kernel (1, default) or the fp32 one; "flash_heads_bf16" 0|1: bf16 modes at NUM_HEADS 4 / 16, edge attention on the bf16 kernel (1, default) or the fp32 one; "gate_heads_mfma" 0|1|2: NUM_HEADS / DIM_ATTEN other than 8 / 256 on the MFMA gate kernel (1, default) or the VALU one; "gate_row_map" 0|1: a gate wave owns 32 edges of one head (1, default) or 4 edges x 8 heads;
  * "split_fmt" 0|1: in the bf16 modes, edge tensors between matrix kernels as bf16 hi/lo pairs (0: fp32, split on read);
  * "half_fmt" 0|1: in the single-rounding modes, those tensors as plain bf16 at half the traffic (0: hi/lo pairs);
  * "ln_resid" 0|1: split-bf16 mode, residual of the edge attention added by the LayerNorm kernel (0: by the out-projection);

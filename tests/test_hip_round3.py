@@ -247,3 +247,39 @@ def test_scene_checksums_kernel_equals_the_torch_reduction():
             assert torch.allclose(got[3:7], want[3:7], rtol=1e-12, atol=1e-9), (got, want)
     finally:
         m.close()
+
+
+def test_per_class_profile_on_two_streams_accounts_like_one_stream():
+    """The per-class HIP-event profile (what bench.py's roofline is made of) with the 2D twin stages on the second stream:
+    launches and flops per class are what the serialised forward reports, every class has time, and no class is charged
+    more than the wall time of the profiled forwards (its time is the UNION of its intervals over both streams)."""
+    cfg = VLSATConfig(N_LAYERS=2)
+    m = _model(cfg, synth.make_weights(cfg))
+    try:
+        d = _dev(synth.collate([synth.make_scene(40, 128, 7000 + s) for s in range(16)]))
+        args = (d["obj_points"], d["obj_2d_feats"], d["edge_indices"], d["descriptor"], d["batch_ids"])
+        res = {}
+        for dual in (0, 1):
+            m.debug_option("prof_dual", dual)
+            m(*args)
+            torch.cuda.synchronize()
+            m.profile_enable(True)
+            m.profile_read()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                out = m(*args)
+            e1.record()
+            torch.cuda.synchronize()
+            res[dual] = (m.profile_read(), e0.elapsed_time(e1), [o.clone() for o in out])
+            m.profile_enable(False)
+        (one, wall1, out1), (two, wall2, out2) = res[0], res[1]
+        assert all(torch.equal(a, b) for a, b in zip(out1, out2))
+        for k in one:
+            assert one[k]["launches"] == two[k]["launches"] and one[k]["flops"] == two[k]["flops"], k
+            if one[k]["launches"]:
+                assert 0 < two[k]["ms"] <= wall2 * 1.02, (k, two[k]["ms"], wall2)
+        assert sum(v["ms"] for v in one.values()) <= wall1 * 1.02                 # one stream: the classes partition the time
+        assert wall2 <= wall1 * 1.05
+    finally:
+        m.close()
