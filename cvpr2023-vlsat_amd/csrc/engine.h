@@ -46,7 +46,10 @@ struct Arena { char* p = nullptr; size_t bytes = 0; hipEvent_t last = nullptr; }
 struct vlsat_ctx {
     VlsatDims d{};
     int dual_stream = 2;     // 2D twin stages on a second stream: 0 never, 1 launch-bound plans only (E <= 8192), 2 every plan
-                             // (vlsat_debug_option "dual_stream"; never while the per-class HIP-event profiling is on)
+                             // (vlsat_debug_option "dual_stream").  A two-stream plan carries a second scratch set (NP2, Hbig2,
+                             // KP2, G2, T768b, H2b: +7.3 KB per edge, 0.73 GB at the bench batch); plans whose workspace would pass
+                             // DUAL_WS_BUDGET with it fall back to one stream (engine_plan.hip).  The per-class profiling keeps the
+                             // two streams unless "prof_dual" is 0.
     hipStream_t side = nullptr;
     hipStream_t copy = nullptr;          // plan index uploads (non-blocking stream)
     std::vector<hipEvent_t> sync_ev;     // fork/join events (timing disabled), created on first use
@@ -153,7 +156,8 @@ struct vlsat_plan_s {
     bool dual = false;
     // hipGraph replay (vlsat_forward_graph): the captured forward of this plan for ONE set of tensor addresses
     hipGraphExec_t graph_exec = nullptr;
-    hipEvent_t graph_done = nullptr;        // recorded behind every launch of graph_exec
+    hipEvent_t graph_done = nullptr;        // recorded behind every launch of graph_exec; the next launch -- on whatever stream --
+    bool graph_launched = false;            // waits for it first, so the event always covers EVERY launch still in flight
     const void* graph_ptrs[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     long graph_epoch = -1;                  // handle configuration (weights / precision / options) it was captured under
     float *NP2 = nullptr, *Hbig2 = nullptr, *KP2 = nullptr, *G2 = nullptr, *T768b = nullptr, *rs2 = nullptr, *H2b = nullptr;
@@ -171,6 +175,8 @@ struct Scratch { float *NP, *Hbig, *KP, *G, *T768, *R1, *R2, *rs, *H2; };
 inline int ldx_of(const vlsat_ctx* h) { return h->D + h->A; }
 inline int npc_of(const vlsat_ctx* h) { return 6 * h->D + h->A; }
 inline bool default_heads(const vlsat_ctx* h) { return h->H == 8 && h->A == 256; }
+// a plan whose workspace would exceed this with the second scratch set of the two-stream mode runs on one stream
+constexpr size_t DUAL_WS_BUDGET = size_t(48) << 30;
 
 #define RUN(expr)                  \
     do {                           \

@@ -1,4 +1,6 @@
 // Kernel-level C entry points (unit tests and tools drive single kernels through these) and debug hooks.
+#include <climits>
+#include <cstdint>
 #include <cstring>
 #include <vector>
 
@@ -246,6 +248,138 @@ int vlsat_scene_checksums(const float* obj3d, const float* obj2d, int64_t n_node
     if (n_edges > 0 && (!rel3d || !rel2d)) return fail(VLSAT_EINVAL, "scene_checksums: null relation outputs");
     return launch_scene_checksums(obj3d, obj2d, (long)n_nodes, n_obj_class, rel3d, rel2d, (long)n_edges, n_rel_class, n_scenes, out9,
                                   scratch, static_cast<hipStream_t>(stream));
+}
+
+// -------------------------------------------------------------------------------------------
+// Kernel-level entry points of the non-GEMM kernels of the GCN block and the node attention (SURVEY 8b's per-kernel list):
+// test entry points like vlsat_k_flash_attn -- small index tables are built on the host, uploaded, and the call
+// synchronises before it frees them.
+namespace {
+struct DevTable {                       // a host table copied to the device for the duration of one call
+    void* d = nullptr;
+    ~DevTable() { if (d) hipFree(d); }
+    int put(const void* host, size_t bytes) {
+        if (!bytes) return 0;
+        VLSAT_HIP_CHECK(hipMalloc(&d, bytes));
+        VLSAT_HIP_CHECK(hipMemcpy(d, host, bytes, hipMemcpyHostToDevice));
+        return 0;
+    }
+};
+// node offsets of the scenes (int64 host, like batch_ids run lengths) -> int32 scene_ptr, int64 bias_ptr, largest scene
+static int scene_tables(const int64_t* node_ptr, int n_scenes, int n_heads, std::vector<int32_t>& sp, std::vector<int64_t>& bp, int* max_n) {
+    if (!node_ptr || n_scenes <= 0) return fail(VLSAT_EINVAL, "bad scene table");
+    sp.resize(n_scenes + 1);
+    bp.resize(n_scenes);
+    int64_t off = 0;
+    *max_n = 0;
+    for (int s = 0; s <= n_scenes; ++s) {
+        if (node_ptr[s] < 0 || node_ptr[s] > INT32_MAX || (s && node_ptr[s] < node_ptr[s - 1])) return fail(VLSAT_EINVAL, "scene table must be ascending int32 offsets");
+        sp[s] = (int32_t)node_ptr[s];
+        if (s < n_scenes) {
+            const int64_t n = node_ptr[s + 1] - node_ptr[s];
+            bp[s] = off;
+            off += (int64_t)n_heads * n * n;
+            if (n > *max_n) *max_n = (int)n;
+        }
+    }
+    return 0;
+}
+}  // namespace
+
+int vlsat_k_edge_gate(const float* kproj, const float* node, int32_t ld_node, int32_t gq_off, int32_t v_off, const int32_t* src,
+                      const int32_t* dst, const float* w0k, const float* w3, const float* b3, float* gated, float* prob,
+                      int32_t n_edges, int32_t n_heads, int32_t dk, int32_t dox, int32_t use_edge, int32_t variant, void* stream) {
+    if (!node || !src || !dst || !w3 || !b3 || !gated || (use_edge && (!kproj || !w0k))) return fail(VLSAT_EINVAL, "edge_gate: null argument");
+    if (n_edges < 0 || n_heads <= 0 || dk <= 0 || dox <= 0) return fail(VLSAT_EINVAL, "edge_gate: bad geometry");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    GateArgs g{};
+    g.kproj = kproj; g.node = node; g.ld_node = ld_node; g.gq_off = gq_off; g.v_off = v_off; g.src = src; g.dst = dst;
+    g.w0k = w0k; g.w3 = w3; g.b3 = b3; g.gated = gated; g.prob = prob; g.n_edges = n_edges; g.use_edge = use_edge != 0;
+    const bool def = n_heads == 8 && dk == 64 && dox == 32;
+    switch (variant) {
+        case 0:                                                  // what the fp32 forward launches for this geometry
+            if (def) return launch_edge_gate(g, s);
+            {
+                const int r = launch_edge_gate_heads(g, n_heads, dk, dox, s);
+                if (r <= 0) return r;
+            }
+            return launch_edge_gate_generic(g, n_heads, dk, dox, s);
+        case 1: return launch_edge_gate_generic(g, n_heads, dk, dox, s);
+        case 2: {
+            const int r = launch_edge_gate_heads(g, n_heads, dk, dox, s);
+            return r > 0 ? fail(VLSAT_EINVAL, "edge_gate: head geometry not built on the MFMA template") : r;
+        }
+        case 3: case 4: {
+            const int terms = variant == 3 ? 3 : 1;
+            if (def) return launch_edge_gate_bf16(g, terms, 0, s);
+            if (!edge_gate_bf16_heads_supports(dk, dox, terms)) return fail(VLSAT_EINVAL, "edge_gate: head geometry / terms not built on the bf16 template");
+            const int r = launch_edge_gate_bf16_heads(g, n_heads, dk, dox, terms, 0, s);
+            return r > 0 ? fail(VLSAT_EINVAL, "edge_gate: head geometry not built on the bf16 template") : r;
+        }
+        default: return fail(VLSAT_EINVAL, "edge_gate: variant 0..4");
+    }
+}
+
+int vlsat_k_aggregate(const float* gated, int32_t n_ch, const int64_t* index_host, int64_t n_edges, int32_t n_nodes, int32_t aggr,
+                      float* out, int32_t ldo, int32_t col0, void* stream) {
+    if (!out || n_nodes < 0 || n_edges < 0 || n_ch <= 0 || (n_edges > 0 && (!gated || !index_host))) return fail(VLSAT_EINVAL, "aggregate: bad argument");
+    if (aggr < 0 || aggr > 2) return fail(VLSAT_EINVAL, "aggregate: aggr 0 max | 1 add | 2 mean");
+    if (n_edges > INT32_MAX) return fail(VLSAT_EINVAL, "aggregate: too many rows");
+    std::vector<int32_t> rowptr(n_nodes + 1, 0), order((size_t)n_edges);
+    for (int64_t e = 0; e < n_edges; ++e) {
+        if (index_host[e] < 0 || index_host[e] >= n_nodes) return fail(VLSAT_EINVAL, "aggregate: index out of range");
+        ++rowptr[index_host[e] + 1];
+    }
+    for (int n = 0; n < n_nodes; ++n) rowptr[n + 1] += rowptr[n];
+    std::vector<int32_t> fill(rowptr.begin(), rowptr.end() - 1);
+    for (int64_t e = 0; e < n_edges; ++e) order[fill[index_host[e]]++] = (int32_t)e;      // stable: rows of a segment in input order
+    DevTable dr, dord;
+    RUN(dr.put(rowptr.data(), rowptr.size() * sizeof(int32_t)));
+    RUN(dord.put(order.data(), order.size() * sizeof(int32_t)));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int r = launch_aggregate(gated, n_ch, static_cast<const int32_t*>(dr.d), static_cast<const int32_t*>(dord.d), n_nodes, aggr, out, ldo, col0, s);
+    hipStreamSynchronize(s);
+    return r;
+}
+
+int vlsat_k_node_attn(const float* Q, int32_t ldq, const float* K, int32_t ldk, const float* V, int32_t ldv, float* O, int32_t ldo,
+                      const float* bias, const int64_t* node_ptr_host, int32_t n_scenes, int32_t n_heads, float scale,
+                      int32_t lanes_per_query, void* stream) {
+    if (!Q || !K || !V || !O) return fail(VLSAT_EINVAL, "node_attn: null argument");
+    if (n_heads <= 0 || 512 % n_heads) return fail(VLSAT_EINVAL, "node_attn: n_heads must divide 512");
+    if (lanes_per_query != 0 && lanes_per_query != 1 && lanes_per_query != 16) return fail(VLSAT_EINVAL, "node_attn: lanes_per_query 0 (auto) | 1 | 16");
+    std::vector<int32_t> sp;
+    std::vector<int64_t> bp;
+    int max_n = 0;
+    RUN(scene_tables(node_ptr_host, n_scenes, n_heads, sp, bp, &max_n));
+    DevTable dsp, dbp;
+    RUN(dsp.put(sp.data(), sp.size() * sizeof(int32_t)));
+    RUN(dbp.put(bp.data(), bp.size() * sizeof(int64_t)));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int split_below = lanes_per_query == 16 ? INT32_MAX : lanes_per_query == 1 ? 0 : 1024;
+    const int r = launch_node_attn(Q, ldq, K, ldk, V, ldv, O, ldo, bias, static_cast<const int32_t*>(dsp.d), static_cast<const int64_t*>(dbp.d),
+                                   n_scenes, max_n, n_heads, 512 / n_heads, scale, s, split_below);
+    hipStreamSynchronize(s);
+    return r;
+}
+
+int vlsat_k_dist_bias(const float* desc, int32_t ld_desc, const int64_t* node_ptr_host, int32_t n_scenes, int32_t n_heads,
+                      const float* w0, const float* b0, const float* ln2_w, const float* ln2_b, const float* w3, const float* b3,
+                      const float* ln5_w, const float* ln5_b, const float* w6, const float* b6, float* bias, void* stream) {
+    if (!desc || !w0 || !b0 || !ln2_w || !ln2_b || !w3 || !b3 || !ln5_w || !ln5_b || !w6 || !b6 || !bias) return fail(VLSAT_EINVAL, "dist_bias: null argument");
+    if (n_heads <= 0 || ld_desc < 3) return fail(VLSAT_EINVAL, "dist_bias: bad geometry");
+    std::vector<int32_t> sp;
+    std::vector<int64_t> bp;
+    int max_n = 0;
+    RUN(scene_tables(node_ptr_host, n_scenes, n_heads, sp, bp, &max_n));
+    DevTable dsp, dbp;
+    RUN(dsp.put(sp.data(), sp.size() * sizeof(int32_t)));
+    RUN(dbp.put(bp.data(), bp.size() * sizeof(int64_t)));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const DistBiasW w{w0, b0, ln2_w, ln2_b, w3, b3, ln5_w, ln5_b, w6, b6};
+    const int r = launch_dist_bias(desc, ld_desc, static_cast<const int32_t*>(dsp.d), static_cast<const int64_t*>(dbp.d), n_scenes, max_n, n_heads, w, bias, s);
+    hipStreamSynchronize(s);
+    return r;
 }
 
 int vlsat_k_layernorm(float* x, int32_t ld, int32_t rows, int32_t dim, const float* gamma, const float* beta,

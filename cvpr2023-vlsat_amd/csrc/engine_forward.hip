@@ -582,8 +582,14 @@ int vlsat_forward_graph(vlsat_handle h, vlsat_plan p, const float* pts, const fl
         for (int i = 0; i < 7; ++i) p->graph_ptrs[i] = ptrs[i];
         p->graph_epoch = h->config_epoch;
         p->graph_done = take_event(h);
+        p->graph_launched = false;
         if (!p->graph_done) { retire_graph(h, p); return fail(VLSAT_EHIP, "vlsat_forward_graph: cannot create an event"); }
     }
+    // One event per executable: a replay on ANOTHER stream first waits (on the device) for the previous launch, so that
+    // graph_done, re-recorded below, still stands for every launch in flight when retire_graph / plan_destroy test it
+    // (the workspace is not re-entrant anyway: two overlapping replays of one plan would race on it).
+    if (p->graph_launched) VLSAT_HIP_CHECK(hipStreamWaitEvent(s, p->graph_done, 0));
+    p->graph_launched = true;
     VLSAT_HIP_CHECK(hipGraphLaunch(p->graph_exec, s));
     VLSAT_HIP_CHECK(hipEventRecord(p->graph_done, s));
     p->used = true;

@@ -63,6 +63,7 @@ void retire_graph(vlsat_ctx* h, vlsat_plan_s* p) {
         h->graph_trash.push_back({p->graph_exec, p->graph_done});
         p->graph_exec = nullptr;
         p->graph_done = nullptr;
+        p->graph_launched = false;
     }
     sweep_graphs(h, false);
 }
@@ -257,6 +258,12 @@ int vlsat_plan_create(vlsat_handle h, const int64_t* bid, const int64_t* edges, 
     want(&p->Qe, Es * 512); want(&p->KVe, Es * 1024); want(&p->Oe, Es * 512);
     // launch-bound plans (every edge GEMM fits one round of the grid): second scratch set for the 2D twin stages
     p->dual = h->dual_stream && E > 0 && (h->dual_stream > 1 || E <= 8192);      // (dual_stream = 2: every plan)
+    if (p->dual) {                         // ... unless the second scratch set would take the plan past the budget
+        size_t base = 0;
+        for (auto& it : items) base += it.bytes;
+        const size_t extra = (Ns * (size_t)(NPC + LDX + 1) + Es * (size_t)(1024 + 512 + A + 128)) * sizeof(float);
+        if (base + extra > DUAL_WS_BUDGET) p->dual = false;
+    }
     if (p->dual) {
         want(&p->NP2, Ns * NPC); want(&p->Hbig2, Es * 1024); want(&p->KP2, Es * 512); want(&p->G2, Es * A);
         want(&p->T768b, Ns * LDX); want(&p->rs2, Ns); want(&p->H2b, Es * 128);

@@ -373,7 +373,9 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmArgs p, int n_tiles
                         // write of them ONLY when the store has no SGPR soffset (LLVM's hazard rule assumes the register form is
                         // safe) -- on gfx950 it is not: split-pair epilogues, whose pack code reuses the registers at once, stored
                         // garbage in one dword of some lanes until this pad went in (found with the bit-identity test).
-                        asm volatile("s_nop 3" ::: "memory");
+                        // (the data registers are named as an input so that they stay allocated across the pad: a side-effecting asm
+                        //  orders memory operations only, and `r` is otherwise dead after the store)
+                        asm volatile("s_nop 3" ::"v"(r) : "memory");
                     } else
                         asm volatile("" ::"v"(r));
                 }
@@ -531,6 +533,9 @@ int launch_gemm_p8(const GemmArgs& a, int n_tiles, int grid, hipStream_t s) {
     const int add = (a.resid ? 1 : 0) | (a.g0 ? 2 : 0) | (a.g1 ? 4 : 0);
     const bool f32 = a.prec == 0, x3 = a.prec == 3;
     if (a.rowscale || a.act == ACT_SIGMOID || (add != 0 && add != 1 && add != 6)) return 1;
+    // the fp32 / split-bf16 epilogues read the bias as float4 (the half-row one as scalars): an unaligned bias pointer of a
+    // caller of vlsat_k_gemm goes to the older kernels, which have the scalar fallback
+    if ((f32 || x3) && a.bias && (reinterpret_cast<uintptr_t>(a.bias) & 15)) return 1;
     if (f32 ? (a.a_split || a.c_split || a.r_split || a.c_scale != 1.f)
             : x3 ? (a.a_split != 1 || a.c_split == 2 || !a.Wlo) : (a.prec != 1 || a.a_split != 2 || a.c_split == 1)) return 1;
     const int kt = (f32 || x3) ? 32 : P8_BK;          // an output tile is an even number (>= 4) of K-tiles

@@ -62,6 +62,11 @@ _SIGNATURES = {
     "vlsat_k_flash_attn": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _f32, _vp]),
     "vlsat_k_flash_attn_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _f32, _i32, _i32, _vp]),
     "vlsat_k_layernorm": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
+    "vlsat_k_edge_gate": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32,
+                                    _i32, _i32, _vp]),
+    "vlsat_k_aggregate": (C.c_int, [_vp, _i32, _vp, _i64, _i32, _i32, _vp, _i32, _i32, _vp]),
+    "vlsat_k_node_attn": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _f32, _i32, _vp]),
+    "vlsat_k_dist_bias": (C.c_int, [_vp, _i32, _vp, _i32, _i32] + [_vp] * 10 + [_vp, _vp]),
     "vlsat_prepare_objects": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "vlsat_fc_edges": (C.c_int, [_vp, _vp, _i32, _i64, _i64, _vp, _vp, _vp]),
     "vlsat_k_softmax_rows": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp]),

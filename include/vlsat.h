@@ -25,7 +25,8 @@
  *     vlsat_load_weight (when it replaces an already finalised set), vlsat_set_gemm_precision, vlsat_destroy and the
  *     vlsat_debug_* readers.
  *   - a handle (weights) may be shared by several plans; a plan owns its workspace and is NOT
- *     re-entrant (one forward at a time per plan), mirroring one nn.Module instance; a handle is driven from one
+ *     re-entrant (one forward at a time per plan; a hipGraph replay of a plan on another stream waits on the device for the
+ *     previous replay), mirroring one nn.Module instance; a handle is driven from one
  *     host thread at a time, and its forwards are ordered on ONE stream at a time (small scratch buffers -- the split-K
  *     workspace of small GEMM launches -- belong to the handle: moving to another stream needs an event / sync between
  *     the last forward on the old stream and the first on the new one; separate handles are independent).
@@ -229,6 +230,48 @@ int vlsat_k_flash_attn_bf16(const float* Q, const float* K, const float* V, floa
 int vlsat_k_layernorm(float* x, int32_t ld, int32_t rows, int32_t dim, const float* gamma,
                       const float* beta, int32_t relu, void* stream);
 
+/* The 'fat' gate of MultiHeadedEdgeAttention.forward (reference network_MMG.py:96-104): per (edge e, head h)
+ *     hidden = relu(Gq[src[e], h, :] + W0k . kproj[e, h, :]);  prob = softmax(W3 . hidden + b3);  gated = prob * value[dst[e], h, :]
+ * on the operands the forward prepares: kproj [E, H*dk] = proj_edge output HEAD-MAJOR (column h*dk + c
+ * is the reference's k.view(E,dk,H)[e,c,h]); `node` = the node-side buffer with row pitch ld_node holding, at column gq_off,
+ * Gq[n, h*2dk + o] = b0[o] + sum_c W0[o,c] q.view(N,dk,H)[n,c,h] (the query half of nn.0 applied per node, bias included)
+ * and, at column v_off, value[n, h*dox + m] = proj_value output head-major; src / dst [E] int32 (ei[0] / ei[1]);
+ * w0k [2dk, dk] = nn.0.weight[:, dk:2dk], w3 [dox, 2dk] = nn.3.weight, b3 [dox].  Outputs: gated [E, H*dox] head-major
+ * (column h*dox + m; the reference's is m*H + h) and, if not NULL, prob [E, dox, H] in the REFERENCE layout.
+ * use_edge = 0: MODEL.USE_GCN_EDGE false (hidden = relu(Gq), kproj / w0k unread).  ld_node, gq_off, v_off % 4 == 0.
+ * variant: 0 = the kernel the fp32 forward picks for the geometry, 1 = VALU kernel (any geometry), 2 = fp32 MFMA template
+ * (NUM_HEADS in {4,8,16} x DIM_ATTEN in {128,256,512}), 3 / 4 = bf16 matrix cores, split-bf16 / single-rounded (kproj fp32).
+ * All device pointers; asynchronous. */
+int vlsat_k_edge_gate(const float* kproj, const float* node, int32_t ld_node, int32_t gq_off, int32_t v_off,
+                      const int32_t* src, const int32_t* dst, const float* w0k, const float* w3, const float* b3,
+                      float* gated, float* prob, int32_t n_edges, int32_t n_heads, int32_t dk, int32_t dox,
+                      int32_t use_edge, int32_t variant, void* stream);
+
+/* Aggre_Index (reference network_util.py:64-73, torch_scatter semantics): out[n, col0 + c] = reduce over the rows e of
+ * gated [E, n_ch] (dense) with index[e] == n; aggr 0 max | 1 add | 2 mean (MODEL.GCN_AGGR); empty segment -> 0.
+ * index_host: HOST int64 [E] (ei[0] under flow = target_to_source).  Deterministic (CSR, no atomics).  Synchronises. */
+int vlsat_k_aggregate(const float* gated, int32_t n_ch, const int64_t* index_host, int64_t n_edges, int32_t n_nodes,
+                      int32_t aggr, float* out, int32_t ldo, int32_t col0, void* stream);
+
+/* ScaledDotProductAttention core of the node self / cross attention (reference attention.py:60-76 as called from
+ * network_MMG.py:217-218) with the additive distance bias and the block-diagonal scene mask of network_MMG.py:188-203:
+ * per scene s, head h: O = softmax(scale * Q K^T + bias[s,h]) V over the scene's nodes; head h = columns h*dk.. of Q/K/V/O
+ * with dk = 512 / n_heads in {32, 64, 128}.  node_ptr_host: HOST int64 [n_scenes+1]; bias (may be NULL): scene s at float
+ * offset sum_{t<s} H n_t^2, layout [H][n_s][n_s] (query-major) -- what vlsat_k_dist_bias writes.  lanes_per_query: 0 = the
+ * forward's choice, 1 / 16 = force the one-query-per-lane / sixteen-lanes-per-query kernel.  Synchronises. */
+int vlsat_k_node_attn(const float* Q, int32_t ldq, const float* K, int32_t ldk, const float* V, int32_t ldv,
+                      float* O, int32_t ldo, const float* bias, const int64_t* node_ptr_host, int32_t n_scenes,
+                      int32_t n_heads, float scale, int32_t lanes_per_query, void* stream);
+
+/* The distance-bias MLP MMG.forward runs once per call (reference network_MMG.py:190-203, self_attn_fc :165-173):
+ * bias[s][h][a][b] = Linear(32,H)(LN(relu(Linear(32,32)(LN(relu(Linear(4,32)([c_b - c_a, |c_b - c_a|]))))))) for the nodes a, b
+ * of scene s; c = desc[:, 0:3] (row pitch ld_desc).  Weights in the reference layout (self_attn_fc.{0,2,3,5,6}).
+ * Output layout as vlsat_k_node_attn reads it.  Synchronises. */
+int vlsat_k_dist_bias(const float* desc, int32_t ld_desc, const int64_t* node_ptr_host, int32_t n_scenes, int32_t n_heads,
+                      const float* w0, const float* b0, const float* ln2_w, const float* ln2_b, const float* w3,
+                      const float* b3, const float* ln5_w, const float* ln5_b, const float* w6, const float* b6,
+                      float* bias, void* stream);
+
 /* -------- input preparation (the step BEFORE the path: the data loader, reference dataset_3dssg.py:279-294) --- */
 
 /* Per object n: gather P sampled points scene_points[choice[n, :]] ([Npts,3] fp32, choice int32 [N,P]),
@@ -292,7 +335,11 @@ int vlsat_debug_read(vlsat_plan p, const char* name, float* dst, int64_t dst_ld)
 int vlsat_debug_gemm_clock_probe(int64_t* buf);
 
 /* Experiment switches of one handle; defaults are the measured-best settings and none changes results beyond
- * fp32 summation order.  "dual_stream" 0|1|2: 2D twin stages on a second stream (1: launch-bound plans only, 2 = default: every plan); "flash_split" 0|1:
+ * fp32 summation order.  "dual_stream" 0|1|2: 2D twin stages on a second stream (1: launch-bound plans only, 2 = default: every plan;
+ * a two-stream plan owns a second scratch set, +7.3 KB per edge = 0.73 GB at the 64-scene bench batch, and falls back to one stream
+ * when its workspace would pass 48 GiB with it); "gemm_p8" 0|1: large edge-row GEMM launches on the 256 x 256 8-phase kernel in
+ * every precision mode (1, default; 0: the older 128 x 128 / ring kernels -- in the half-row mode the edge-attention residual then
+ * goes back from the LayerNorm kernel into the out-projection); "flash_split" 0|1:
  * split-key edge attention for plans that cannot fill the chip (both: plans created afterwards); "gemm_dma" 0|1:
  * LDS-direct staging of fp32 GEMM operands; "gate_grid" n: persistent grid of the gate kernel (0 = default); "prof_dual" 0|1: per-class profiling keeps the two-stream execution (1, default) or serialises the forward on the launch stream; "gate_heads_bf16" 0|1: bf16 modes at head geometries other than 8 x (64, 32), the gate on the bf16 kernel (1, default) or the fp32 one; "flash_heads_bf16" 0|1: bf16 modes at NUM_HEADS 4 / 16, edge attention on the bf16 kernel (1, default) or the fp32 one; "gate_heads_mfma" 0|1|2: NUM_HEADS / DIM_ATTEN other than 8 / 256 on the MFMA gate kernel (1, default) or the VALU one; "gate_row_map" 0|1: a gate wave owns 32 edges of one head (1, default) or 4 edges x 8 heads;
  * "split_fmt" 0|1: in the bf16 modes, edge tensors between matrix kernels as bf16 hi/lo pairs (0: fp32, split on read);
