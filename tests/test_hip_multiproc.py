@@ -48,6 +48,31 @@ def test_two_ranks_on_one_gpu_reproduce_the_single_process_metrics():
         assert abs(a[k] - b[k]) <= 2, (k, a[k], b[k])
 
 
+def test_eight_ranks_dry_run_of_the_drivers_scaling_command():
+    """BASELINE configs[3] as the driver launches it -- `torch.distributed.run --nproc-per-node 8 bench.py --gpus 8`, 64 scenes
+    per rank = 512 scenes -- with the eight ranks sharing the one GPU of the test box and gloo for the one all-reduce: shard
+    sizes, the 512-scene total and the all-reduced counts are those of the real run, so the first 8-GPU run cannot fail on
+    host logic (RCCL itself needs one device per rank: test_two_gpus_over_rccl_native_allreduce).  The checksums of an
+    eight-rank run are then compared with ONE process over the same scenes (8 x 8 scenes against 64)."""
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: the HIP path cannot run and there is no fallback")
+    eight = _bench(8, 64, 29651, extra=["--no-extra"])
+    assert eight["n_gpus"] == 8 and eight["scaling"] == "weak" and eight["config"]["scenes_per_gpu"] == 64
+    assert eight["config"]["parallelism"] == "scene-sharded x8" and eight["value"] > 0 and eight["steps"] == 2
+    a = eight["metrics_allreduced"]
+    assert a["scenes"] == 512 and a["nodes"] == 512 * 40 and a["edges"] == 512 * 1560
+    lo, hi = eight["rank_ms_per_step_min_max"]
+    assert 0 < lo <= hi
+    small = _bench(8, 8, 29661, extra=["--no-extra"])      # ranks own scenes 0..7, 8..15, ... 56..63
+    one = _bench(1, 64, 0, extra=["--no-extra"])           # the same 64 scenes in one process
+    a, b = small["metrics_allreduced"], one["metrics_allreduced"]
+    assert a["scenes"] == b["scenes"] == 64 and a["nodes"] == b["nodes"] and a["edges"] == b["edges"]
+    for k in ("sum_obj3d", "sum_obj2d", "sum_rel3d", "sum_rel2d"):
+        assert abs(a[k] - b[k]) <= 1e-3 * max(1.0, abs(b[k])), (k, a[k], b[k])
+    for k in ("top1_agree_obj", "top1_agree_rel"):
+        assert abs(a[k] - b[k]) <= 4, (k, a[k], b[k])
+
+
 def test_two_gpus_over_rccl_native_allreduce():
     """The run the driver launches on a multi-GPU node, at N = 2: one rank per GPU, RCCL for torch.distributed AND for the
     library's own collective (bench.py --native-allreduce -> vlsat_metrics_allreduce on a 2-rank communicator).  Needs two

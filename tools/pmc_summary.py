@@ -35,6 +35,29 @@ def load(d):
     return per
 
 
+CLASS_OF = {"layernorm512": "layernorm512", "row_invnorm512": "misc", "desc_tail": "misc", "edge_embed": "misc",
+            "dist_bias": "misc", "gemm_ring": "gemm_f32", "gemm_p8": "gemm_f32", "gemm_splitk": "gemm_f32", "flash_attn_bf16": "flash_attn_f32",
+            "flash_merge": "flash_attn_f32", "pointnet_bf16": "pointnet", "edge_gate_bf16": "edge_gate", "edge_gate_hd": "edge_gate",
+            "edge_gate_bf16_hd": "edge_gate", "edge_gate_generic": "edge_gate", "node_attn_split": "node_attn"}     # bench.py's class names
+
+
+def class_of(name):
+    import re
+    m = re.search(r"vlsat::(\w+?)(_kernel)?(<|$)", name)
+    key = m.group(1) if m else name
+    return CLASS_OF.get(key, key)
+
+
+def class_bytes(per, counter):
+    """bytes per launch of every kernel CLASS from one loaded counter pass (FETCH_SIZE is doubled: gfx950 tallies 128-B requests as 64 B)"""
+    tot, n = collections.defaultdict(float), collections.defaultdict(float)
+    k = 2.0 if counter == "FETCH_SIZE" else 1.0
+    for name, c in per.items():
+        tot[class_of(name)] += k * c[counter] * 1024
+        n[class_of(name)] += c["_launches"]
+    return {c: tot[c] / max(n[c], 1) for c in tot}
+
+
 def main(sq, fetch, write, out, l2=None):
     a, f, w = load(sq), load(fetch), load(write)
     h = load(l2) if l2 and os.path.isdir(l2) else {}
@@ -57,15 +80,9 @@ def main(sq, fetch, write, out, l2=None):
     print("\n".join(lines))
     # per kernel CLASS (all template instantiations together): HBM bytes per launch for bench.py's roofline.traffic
     import json
-    import re
     cls = {}
     for name in a:
-        m = re.search(r"vlsat::(\w+?)(_kernel)?(<|$)", name)
-        key = m.group(1) if m else name
-        key = {"layernorm512": "layernorm512", "row_invnorm512": "misc", "desc_tail": "misc", "edge_embed": "misc",
-               "dist_bias": "misc", "gemm_ring": "gemm_f32", "gemm_p8": "gemm_f32", "gemm_splitk": "gemm_f32", "flash_attn_bf16": "flash_attn_f32",
-               "flash_merge": "flash_attn_f32", "pointnet_bf16": "pointnet", "edge_gate_bf16": "edge_gate",
-               "edge_gate_generic": "edge_gate", "node_attn_split": "node_attn"}.get(key, key)     # bench.py's class names
+        key = class_of(name)
         d = cls.setdefault(key, {"launches": 0, "hbm_read_bytes": 0.0, "hbm_write_bytes": 0.0, "kernel_ns": 0.0})
         d["launches"] += int(a[name]["_launches"])
         d["kernel_ns"] += a[name]["_dur_ns"]

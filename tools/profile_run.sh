@@ -13,7 +13,11 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d "$OUT/kt" -o bench -- python "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu "$@" > "$OUT/bench.json" 2> "$OUT/kt.log"
-python "$ROOT/tools/rocprof_summary.py" "$OUT"/kt/bench_results.db "$OUT/kernel_stats.md" > /dev/null 2>> "$OUT/kt.log"
+python "$ROOT/tools/rocprof_summary.py" "$OUT"/kt/bench_results.db "$OUT/kernel_stats.md" "$OUT/bench.json" > /dev/null 2>> "$OUT/kt.log"
+# 1b. the same trace SERIALISED (one stream): kernel durations are then the kernels' own, and the footer of the table
+#     recomputes the bench line's roofline from the trace alone                         -> <tag>/kernel_stats_serial.md
+rocprofv3 --kernel-trace --stats -d "$OUT/kts" -o bench -- python "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu --debug-option dual_stream=0 "$@" > "$OUT/bench_serial.json" 2> "$OUT/kts.log"
+python "$ROOT/tools/rocprof_summary.py" "$OUT"/kts/bench_results.db "$OUT/kernel_stats_serial.md" "$OUT/bench_serial.json" > /dev/null 2>> "$OUT/kts.log"
 pass() {  # name, counters...
     local name=$1; shift
     rocprofv3 --kernel-trace --pmc "$@" -d "$OUT/pmc_$name" -o p --output-format csv -- python "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu --no-profile "${ARGS[@]}" > "$OUT/pmc_$name.log" 2>&1
@@ -25,5 +29,5 @@ pass write WRITE_SIZE
 pass l2 TCC_HIT TCC_MISS TCC_REQ TCC_EA0_RDREQ
 python "$ROOT/tools/pmc_summary.py" "$OUT/pmc_sq" "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc.md" "$OUT/pmc_l2" > /dev/null 2> "$OUT/pmc_summary.err"
 # the raw traces are tens of MB; gpurun merges at most 64 MiB back (KEEP_RAW=1 keeps them)
-[ "${KEEP_RAW:-0}" = 1 ] || rm -rf "$OUT/kt" "$OUT"/pmc_sq "$OUT"/pmc_fetch "$OUT"/pmc_write "$OUT"/pmc_l2
+[ "${KEEP_RAW:-0}" = 1 ] || rm -rf "$OUT/kt" "$OUT/kts" "$OUT"/pmc_sq "$OUT"/pmc_fetch "$OUT"/pmc_write "$OUT"/pmc_l2
 ls "$OUT"
