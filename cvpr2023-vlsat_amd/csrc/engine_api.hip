@@ -108,6 +108,8 @@ int vlsat_k_gemm(const float* A, int32_t lda, const float* W, int32_t ldw, float
     if (relu_a & 2) a.prefetch = 0;             // (bit 1 of relu_a: no A-panel prefetch -- benchmarking)
     if (relu_a & 4) RUN(test_splitk_ws(a));     // (bit 2: small launches may take the split-K kernel)
     if (relu_a & 8) a.no_p8 = 1;                // (bit 3: large launches stay off the 256 x 256 8-phase kernel)
+    a.force_tile = (relu_a >> 4) & 7;           // (bits 4..6: tile of gemm_f32_kernel, GemmArgs::force_tile -- benchmarking)
+    if (a.force_tile) { a.no_p8 = 1; a.no_ring = 1; }
     return launch_gemm(a, static_cast<hipStream_t>(stream));
 }
 
@@ -140,6 +142,8 @@ int vlsat_k_gemm_planes(const float* A, int32_t lda, const float* W, const uint1
     a.ring_bk32 = (fmt >> 10) & 1;             // (bit 10: half-row ring kernel with 32-wide k slices)
     a.ring_nodb = (fmt >> 11) & 1;             // (bit 11: ... without the double-buffered fragment sets)
     a.no_p8 = (fmt >> 12) & 1;                 // (bit 12: half-row launches skip the 256 x 256 8-phase kernel)
+    a.force_tile = (fmt >> 19) & 7;            // (bits 19..21: tile of gemm_f32_kernel, GemmArgs::force_tile -- benchmarking)
+    if (a.force_tile) { a.no_p8 = 1; a.no_ring = 1; }
     if ((fmt >> 6) & 1) RUN(test_splitk_ws(a));    // (bit 6: small launches may take the split-K kernel)
     return launch_gemm(a, static_cast<hipStream_t>(stream));
 }
@@ -239,6 +243,19 @@ int vlsat_eval_ranks(const float* obj_logits, const float* obj_probs, const floa
     return launch_eval_ranks(obj_logits, obj_probs, rel_probs, gt_class, gt_rel, edges, n_nodes, n_edges, n_obj_class,
                              n_rel_class, topk_obj, topk_rel, topk_triplet, threshold, obj_rank, rel_rank, tri_rank, cnt,
                              static_cast<hipStream_t>(stream));
+}
+
+int vlsat_eval_counts(const int32_t* obj_rank_3d, const int32_t* obj_rank_2d, const int32_t* rel_rank_3d, const int32_t* rel_rank_2d,
+                      const int32_t* tri_rank_3d, const int32_t* tri_rank_2d, const int32_t* cnt, const int64_t* gt_class,
+                      const int64_t* gt_rel, const int64_t* edges, int32_t n_nodes, int32_t n_edges, int32_t n_rel_class,
+                      int32_t n_scenes, uint64_t* counts, void* stream) {
+    if (!counts || n_nodes < 0 || n_edges < 0) return fail(VLSAT_EINVAL, "eval_counts: bad argument");
+    if (n_nodes > 0 && (!obj_rank_3d || !obj_rank_2d || !gt_class)) return fail(VLSAT_EINVAL, "eval_counts: null node argument");
+    if (n_edges > 0 && (!rel_rank_3d || !rel_rank_2d || !tri_rank_3d || !tri_rank_2d || !cnt || !gt_rel || !edges || !gt_class || !obj_rank_3d))
+        return fail(VLSAT_EINVAL, "eval_counts: null edge argument");
+    return launch_eval_counts(obj_rank_3d, obj_rank_2d, rel_rank_3d, rel_rank_2d, tri_rank_3d, tri_rank_2d, cnt, gt_class, gt_rel, edges,
+                              n_nodes, n_edges, n_rel_class, n_scenes, reinterpret_cast<unsigned long long*>(counts),
+                              static_cast<hipStream_t>(stream));
 }
 
 int vlsat_scene_checksums(const float* obj3d, const float* obj2d, int64_t n_nodes, int32_t n_obj_class, const float* rel3d,

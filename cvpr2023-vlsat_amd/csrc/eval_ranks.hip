@@ -263,6 +263,114 @@ int launch_scene_checksums(const float* obj3d, const float* obj2d, long N, int C
     return 0;
 }
 
+// ---- rank arrays -> the additive counts vector of evaluate.validation (what its one all-reduce carries) ----
+// What MMGNet.validation derives from the concatenated rank lists of all scenes (reference src/model/model.py:214-242,
+// 267-282), get_mean_recall (eva_utils_acc.py:224-237) and compute_mean_predicate (model.py:364-388) only needs COUNTS,
+// additive over scenes (cvpr2023-vlsat_amd/evaluate.py: fields()):
+//   [0] scenes | [1..R] cm_ge{k}: entries of the cls_matrix rows (sub_gt, sub_rank, obj_gt, obj_rank, predicate | -1) that are
+//   >= k, clipped to R (the reference loops `range(int(cls_matrix.max()))` over the WHOLE matrix) | per branch (3D, 2D):
+//   obj_n, obj_hit@{1,5,10}, rel_n, rel_hit@{1,3,5}, tri_n, tri_hit@{50,100}, then per predicate class c:
+//   n, tri@{50,100}, rel@{1,3,5}.
+// One thread per edge walks the edge's used rank slots (slot j = its j-th gt predicate in ascending class order, or the one
+// "no relation" slot with predicate -1), one thread per node the object ranks; a block histogram in LDS, flushed with
+// 64-bit integer atomics: the result does not depend on timing, so scenes may be accumulated from concurrent streams.
+// The host path (evaluate.accumulate, numpy) stays as the reference-compatible one; this kernel keeps a one-scene-per-call
+// evaluation loop free of host round trips.  Integer / latency work.
+constexpr int CNT_MAX_R = 32;
+__global__ __launch_bounds__(256) void eval_counts_kernel(const int32_t* __restrict__ obj_rank3, const int32_t* __restrict__ obj_rank2,
+                                                          const int32_t* __restrict__ rel_rank3, const int32_t* __restrict__ rel_rank2,
+                                                          const int32_t* __restrict__ tri_rank3, const int32_t* __restrict__ tri_rank2,
+                                                          const int32_t* __restrict__ cnt, const int64_t* __restrict__ gt_cls,
+                                                          const int64_t* __restrict__ gt_rel, const int64_t* __restrict__ edges,
+                                                          int N, int E, int R, int n_scenes, unsigned long long* __restrict__ out) {
+    extern __shared__ unsigned s_h[];                    // [1 + R + 2 * (11 + 6 R)] counters + [R + 1] histogram of cls_matrix entries
+    const int per_br = 11 + 6 * R, n_out = 1 + R + 2 * per_br;
+    unsigned* s_cm = s_h + n_out;
+    for (int i = threadIdx.x; i < n_out + R + 1; i += blockDim.x) s_h[i] = 0;
+    __syncthreads();
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) s_h[0] = (unsigned)n_scenes;
+    if (t < N) {
+        const int32_t* ranks[2] = {obj_rank3, obj_rank2};
+#pragma unroll
+        for (int br = 0; br < 2; ++br) {
+            unsigned* b = s_h + 1 + R + br * per_br;
+            const int r = ranks[br][t];
+            atomicAdd(b + 0, 1u);
+            if (r <= 1) atomicAdd(b + 1, 1u);
+            if (r <= 5) atomicAdd(b + 2, 1u);
+            if (r <= 10) atomicAdd(b + 3, 1u);
+        }
+    }
+    if (t < E) {
+        const int a = (int)edges[2 * (size_t)t], bn = (int)edges[2 * (size_t)t + 1];
+        int head[4] = {(int)gt_cls[a], obj_rank3[a], (int)gt_cls[bn], obj_rank3[bn]};     // obj_topk = the 3D ranks for both branches
+#pragma unroll
+        for (int i = 0; i < 4; ++i) head[i] = head[i] < 0 ? 0 : head[i] > R ? R : head[i];
+        const int n = cnt[t];
+        const int64_t* g = gt_rel + (size_t)t * R;
+        int k = -1;                                      // class of the current slot: the next set column of gt_rel[t], or -1
+        for (int j = 0; j < n; ++j) {
+            int pred = -1;
+            for (int q = k + 1; q < R; ++q)
+                if (g[q] == 1) { pred = q; break; }
+            k = pred >= 0 ? pred : R;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) atomicAdd(s_cm + head[i], 1u);
+            atomicAdd(s_cm + (pred < 0 ? 0 : pred), 1u);                                   // (pred <= R - 1: never clipped from above)
+            const int32_t* rr[2] = {rel_rank3, rel_rank2};
+            const int32_t* tt[2] = {tri_rank3, tri_rank2};
+#pragma unroll
+            for (int br = 0; br < 2; ++br) {
+                unsigned* b = s_h + 1 + R + br * per_br;
+                const int r = rr[br][(size_t)t * R + j], tr = tt[br][(size_t)t * R + j];
+                atomicAdd(b + 4, 1u);
+                if (r <= 1) atomicAdd(b + 5, 1u);
+                if (r <= 3) atomicAdd(b + 6, 1u);
+                if (r <= 5) atomicAdd(b + 7, 1u);
+                atomicAdd(b + 8, 1u);
+                if (tr <= 50) atomicAdd(b + 9, 1u);
+                if (tr <= 100) atomicAdd(b + 10, 1u);
+                if (pred >= 0) {
+                    unsigned* c = b + 11 + 6 * pred;
+                    atomicAdd(c + 0, 1u);
+                    if (tr <= 50) atomicAdd(c + 1, 1u);
+                    if (tr <= 100) atomicAdd(c + 2, 1u);
+                    if (r <= 1) atomicAdd(c + 3, 1u);
+                    if (r <= 3) atomicAdd(c + 4, 1u);
+                    if (r <= 5) atomicAdd(c + 5, 1u);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {                              // cm_ge{k} = #entries >= k: suffix sums of the block's histogram
+        unsigned run = 0;
+        for (int v = R; v >= 1; --v) {
+            run += s_cm[v];
+            s_h[v] = run;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_out; i += blockDim.x)
+        if (s_h[i]) atomicAdd(out + i, (unsigned long long)s_h[i]);
+}
+
+int launch_eval_counts(const int32_t* obj_rank3, const int32_t* obj_rank2, const int32_t* rel_rank3, const int32_t* rel_rank2,
+                       const int32_t* tri_rank3, const int32_t* tri_rank2, const int32_t* cnt, const int64_t* gt_cls,
+                       const int64_t* gt_rel, const int64_t* edges, int N, int E, int R, int n_scenes, unsigned long long* out,
+                       hipStream_t s) {
+    if (R <= 0 || R > CNT_MAX_R) return fail(-1, "eval_counts: at most 32 relation classes");
+    const int n = N > E ? N : E;
+    if (n <= 0 && n_scenes <= 0) return 0;
+    const int n_out = 1 + R + 2 * (11 + 6 * R);
+    const int grid = n > 0 ? (n + 255) / 256 : 1;
+    hipLaunchKernelGGL(eval_counts_kernel, dim3(grid), dim3(256), (n_out + R + 1) * sizeof(unsigned), s, obj_rank3, obj_rank2, rel_rank3,
+                       rel_rank2, tri_rank3, tri_rank2, cnt, gt_cls, gt_rel, edges, N, E, R, n_scenes, out);
+    VLSAT_LAUNCH_CHECK("eval_counts");
+    return 0;
+}
+
 int launch_softmax_rows(const float* x, int ld, int rows, int cols, float* out, int log_out, hipStream_t s) {
     if (rows <= 0) return 0;
     if (x == out && ld != cols) return fail(-1, "softmax_rows: in-place needs ld == cols");

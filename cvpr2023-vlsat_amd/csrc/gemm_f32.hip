@@ -314,6 +314,13 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
             break;
         }
     }
+    switch (a.force_tile) {                       // (experiment switch: the tile the sweep asks for)
+        case 1: return run_tiled<128, 128>(a, s);
+        case 2: return run_tiled<128, 64>(a, s);
+        case 3: return run_tiled<64, 128>(a, s);
+        case 4: return run_tiled<64, 64>(a, s);
+        default: break;
+    }
     // Largest tile that still gives every resident slot a tile; small problems (and the tails
     // of big ones) take smaller tiles so the launch covers as many CUs as the problem allows.
     if (a.N > 64 && blocks(128, 128) >= G) return run_tiled<128, 128>(a, s);

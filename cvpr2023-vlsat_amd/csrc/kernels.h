@@ -36,6 +36,7 @@ struct GemmArgs {
     int ring_wide = 0;                          // experiment: bf16 ring kernel with 128 x 256 tiles where N allows (measured equal)
     int no_ring = 0;                            // debug: keep large bf16 launches on the two-stage 128 x 128 kernel
     int no_p8 = 0;                              // debug: large launches skip the 256 x 256 8-phase kernel (gemm_bf16_p8.hip)
+    int force_tile = 0;                         // experiment (tools/gemm_tile_sweep.py): 1 = 128x128, 2 = 128x64, 3 = 64x128, 4 = 64x64 tiles of gemm_f32_kernel, whatever the heuristic says
     int prefetch = -1;                          // bf16 LDS-direct pipe: slices of look-ahead of the A-panel prefetch (0 off, -1 default)
     int no_dma = 0;                             // debug: VGPR-staged fp32 operands instead of LDS-direct (vlsat_debug_option "gemm_dma")
     long* launches = nullptr;                   // optional host counter, +1 per kernel launched (profiling)
@@ -176,6 +177,13 @@ int launch_eval_ranks(const float* obj_logits, const float* obj_probs, const flo
                       const int64_t* gt_rel, const int64_t* edges, int N, int E, int C, int R, int topk_obj,
                       int topk_rel, int topk_tri, float thr, int32_t* obj_rank, int32_t* rel_rank, int32_t* tri_rank,
                       int32_t* cnt, hipStream_t s);
+
+// rank arrays of one batch -> += the additive counts vector of evaluate.validation (uint64 [1 + R + 2 (11 + 6 R)]; layout:
+// evaluate.fields()); integer atomics only, safe from concurrent streams
+int launch_eval_counts(const int32_t* obj_rank3, const int32_t* obj_rank2, const int32_t* rel_rank3, const int32_t* rel_rank2,
+                       const int32_t* tri_rank3, const int32_t* tri_rank2, const int32_t* cnt, const int64_t* gt_cls,
+                       const int64_t* gt_rel, const int64_t* edges, int N, int E, int R, int n_scenes, unsigned long long* out,
+                       hipStream_t s);
 
 // the additive metrics vector {scenes, N, E, four fp64 output sums, two top-1 agreement counts}; scratch: 256 * 6 doubles
 int launch_scene_checksums(const float* obj3d, const float* obj2d, long N, int C, const float* rel3d, const float* rel2d, long E, int R,

@@ -106,12 +106,79 @@ def summarize(vec: np.ndarray, n_rel: int = N_REL) -> Dict[str, float]:
     return out
 
 
+def _n_scenes(b) -> int:
+    if "n_scenes" in b:
+        return int(b["n_scenes"])
+    if "fc_sizes" in b:
+        return len(b["fc_sizes"])
+    return int(b["batch_ids"].max().item()) + 1 if b["batch_ids"].numel() else 0
+
+
 @torch.no_grad()
-def validation(model, batches: Iterable[dict], device=None) -> Dict[str, float]:
-    """``batches`` yields this rank's dicts with the reference loader's item names
-    (obj_points [N,3,P], obj_2d_feats, gt_class, gt_rel_cls, edge_indices [E,2], descriptor, batch_ids).
-    One collective at the very end."""
+def _validation_pipelined(model, batches: Iterable[dict], device, workers: int) -> np.ndarray:
+    """The counts vector of this rank's batches with NO host round trip per batch and ``workers`` batches in flight:
+    every worker thread owns a replica of the model (its own library handle: a handle is driven by one host thread and one
+    stream at a time) and a stream; forward, ranking and counting of a batch are enqueued back to back
+    (``metrics.process_val_counts``) and the counts accumulate on the device with integer atomics.  One scene per batch --
+    validation()'s own pattern (batch_size = 1, reference src/model/model.py:185,201-211) -- leaves most of the 256 CUs idle
+    when scenes run one after the other (a 40-object forward is ~115 dependent kernels of 5-20 us); several in flight fill
+    them.  The host side scales too: the library call that enqueues a forward releases the GIL (ctypes)."""
+    import threading
     from . import metrics as M
+    dev = torch.device(device)
+    models = [model] + [model.replicate() for _ in range(workers - 1)]
+    counts = [torch.zeros(len(fields()), dtype=torch.int64, device=dev) for _ in range(workers)]
+    it, lock, errors = iter(batches), threading.Lock(), []
+
+    def work(k):
+        try:
+            torch.cuda.set_device(dev)
+            stream = torch.cuda.Stream(device=dev) if workers > 1 else torch.cuda.current_stream(dev)
+            with torch.cuda.stream(stream):
+                while not errors:
+                    with lock:
+                        b = next(it, None)
+                    if b is None:
+                        break
+                    M.process_val_counts(models[k], counts[k], b["obj_points"], b["obj_2d_feats"], b["gt_class"], b["descriptor"],
+                                         b["gt_rel_cls"], b["edge_indices"], b.get("batch_ids"), _n_scenes(b), b.get("fc_sizes"))
+            stream.synchronize()
+        except BaseException as ex:             # (re-raised in the caller's thread)
+            errors.append(ex)
+
+    if workers == 1:
+        work(0)
+    else:
+        cur = torch.cuda.current_stream(dev)
+        cur.synchronize()                       # inputs produced on the caller's stream are complete before the workers read them
+        ts = [threading.Thread(target=work, args=(k,), daemon=True) for k in range(workers)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+    for m in models[1:]:
+        m.close()
+    if errors:
+        raise errors[0]
+    return torch.stack(counts).sum(0).cpu().numpy().astype(np.float64)
+
+
+@torch.no_grad()
+def validation(model, batches: Iterable[dict], device=None, workers: int = 0) -> Dict[str, float]:
+    """``batches`` yields this rank's dicts with the reference loader's item names
+    (obj_points [N,3,P], obj_2d_feats, gt_class, gt_rel_cls, edge_indices [E,2], descriptor, batch_ids; optionally
+    ``fc_sizes``: objects per scene when edge_indices is the canonical fully-connected list, which spares the graph plan a
+    read-back of the edge list).  One collective at the very end.
+    workers = 0: the reference-compatible path -- ``process_val`` per batch (numpy rank lists on the host, like
+    ``Mmgnet.process_val``) and host-side accumulation.  workers >= 1: counts accumulated on the device, no host round trip
+    per batch, ``workers`` batches in flight on as many streams and model replicas (for one-scene-per-call loops)."""
+    from . import metrics as M
+    if workers > 0:
+        if device is None:
+            raise ValueError("validation(workers > 0) needs the device")
+        vec = _validation_pipelined(model, batches, device, int(workers))
+        t = vdist.allreduce_metrics(torch.from_numpy(vec).to(device))
+        return summarize(t.cpu().numpy())
     vec = np.zeros(len(fields()), dtype=np.float64)
     for b in batches:
         out = M.process_val(model, b["obj_points"], b["obj_2d_feats"], b["gt_class"], b["descriptor"], b["gt_rel_cls"],

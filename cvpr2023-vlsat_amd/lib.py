@@ -71,6 +71,7 @@ _SIGNATURES = {
     "vlsat_fc_edges": (C.c_int, [_vp, _vp, _i32, _i64, _i64, _vp, _vp, _vp]),
     "vlsat_k_softmax_rows": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "vlsat_eval_ranks": (C.c_int, [_vp] * 6 + [_i32] * 7 + [_f32] + [_vp] * 4 + [_vp]),
+    "vlsat_eval_counts": (C.c_int, [_vp] * 10 + [_i32] * 4 + [_vp, _vp]),
     "vlsat_scene_checksums": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
     "vlsat_comm_unique_id": (C.c_int, [_vp]),
     "vlsat_comm_init": (C.c_int, [_vp, _i32, _i32, C.POINTER(_vp)]),

@@ -75,6 +75,69 @@ def eval_ranks(obj_logits: torch.Tensor, rel_probs: torch.Tensor, gt_class: torc
             "obj_probs": obj_probs}
 
 
+def rank_tables(obj_logits: torch.Tensor, rel_probs: torch.Tensor, gt_class: torch.Tensor, gt_rel: torch.Tensor,
+                edges: torch.Tensor, multi_rel_outputs: bool = True) -> Dict[str, torch.Tensor]:
+    """``eval_ranks`` without its variable-length outputs: the rank TABLES as the kernels write them -- obj_rank [N],
+    rel_rank / tri_rank [E,R] (first cnt[e] slots of row e used), cnt [E] -- all on the device, nothing that depends on
+    their values (no boolean indexing, hence no host synchronisation).  Inputs must already be contiguous, gt_rel the
+    multi-hot int64 [E,R] target, edges int64 [E,2].  What ``eval_counts`` consumes."""
+    lib = L.load()
+    n, c = obj_logits.shape
+    e, r = rel_probs.shape
+    dev = obj_logits.device
+    obj_probs = softmax_rows(obj_logits)
+    obj_rank = torch.empty(n, dtype=torch.int32, device=dev)
+    rel_rank = torch.empty(e, r, dtype=torch.int32, device=dev)
+    tri_rank = torch.empty(e, r, dtype=torch.int32, device=dev)
+    cnt = torch.empty(e, dtype=torch.int32, device=dev)
+    L.check(lib.vlsat_eval_ranks(obj_logits.data_ptr(), obj_probs.data_ptr(), rel_probs.data_ptr(), gt_class.data_ptr(),
+                                 gt_rel.data_ptr(), edges.data_ptr(), n, e, c, r, TOPK_OBJ, TOPK_REL, TOPK_TRIPLET,
+                                 THRESHOLD, obj_rank.data_ptr(), rel_rank.data_ptr(), tri_rank.data_ptr(), cnt.data_ptr(),
+                                 L.stream_ptr()))
+    if not multi_rel_outputs:            # triplet scores use exp(log_softmax); the predicate ranks above used the raw values
+        tri_rank = torch.empty(e, r, dtype=torch.int32, device=dev)
+        rel_exp = rel_probs.exp()
+        L.check(lib.vlsat_eval_ranks(obj_logits.data_ptr(), obj_probs.data_ptr(), rel_exp.data_ptr(), gt_class.data_ptr(),
+                                     gt_rel.data_ptr(), edges.data_ptr(), n, e, c, r, TOPK_OBJ, TOPK_REL, TOPK_TRIPLET,
+                                     THRESHOLD, torch.empty_like(obj_rank).data_ptr(), torch.empty_like(rel_rank).data_ptr(),
+                                     tri_rank.data_ptr(), torch.empty_like(cnt).data_ptr(), L.stream_ptr()))
+    return {"obj_rank": obj_rank, "rel_rank": rel_rank, "tri_rank": tri_rank, "cnt": cnt}
+
+
+def eval_counts(counts: torch.Tensor, t3: Dict[str, torch.Tensor], t2: Dict[str, torch.Tensor], gt_class: torch.Tensor,
+                gt_rel: torch.Tensor, edges: torch.Tensor, n_scenes: int) -> torch.Tensor:
+    """counts (device int64 [len(evaluate.fields())], zeroed once by the caller) += the additive counts of one batch, from the
+    rank tables of its 3D (``t3``) and 2D (``t2``) outputs: ``vlsat_eval_counts`` -- the device twin of
+    ``evaluate.accumulate`` (integer atomics: exact, order-independent, safe from several streams).  No synchronisation."""
+    lib = L.load()
+    e, r = t3["rel_rank"].shape
+    n = t3["obj_rank"].numel()
+    if counts.dtype != torch.int64 or counts.numel() != 1 + r + 2 * (11 + 6 * r) or not counts.is_contiguous():
+        raise L.VlsatError("eval_counts: counts must be a contiguous int64 vector of 1 + R + 2 (11 + 6 R) entries")
+    L.check(lib.vlsat_eval_counts(t3["obj_rank"].data_ptr(), t2["obj_rank"].data_ptr(), t3["rel_rank"].data_ptr(), t2["rel_rank"].data_ptr(),
+                                  t3["tri_rank"].data_ptr(), t2["tri_rank"].data_ptr(), t3["cnt"].data_ptr(), gt_class.data_ptr(),
+                                  gt_rel.data_ptr(), edges.data_ptr(), n, e, r, int(n_scenes), counts.data_ptr(), L.stream_ptr()))
+    return counts
+
+
+@torch.no_grad()
+def process_val_counts(model, counts: torch.Tensor, obj_points, obj_2d_feats, gt_cls, descriptor, gt_rel_cls, edge_indices,
+                       batch_ids=None, n_scenes: int = 1, fc_sizes=None):
+    """``process_val`` for an evaluation LOOP: forward + both ranking passes + the counts, all enqueued on the current stream,
+    nothing read back (``Mmgnet.process_val`` returns numpy rank lists, i.e. four host round trips per scene, reference
+    SGFN_MMG/model.py:463-480; ``validation()`` only ever turns them into the counts accumulated here).
+    ``edge_indices`` is [E,2] as the data loader yields it, on the device."""
+    multi = bool(getattr(getattr(model, "config", None), "multi_rel_outputs", True))
+    edges = edge_indices.to(torch.int64).contiguous()
+    ei_t = edges.t().contiguous()
+    obj3, obj2, rel3, rel2 = model(obj_points, obj_2d_feats, ei_t, descriptor, batch_ids, istrain=False, fc_sizes=fc_sizes)
+    gt_rel = multihot_targets(gt_rel_cls, rel3.shape[1]).to(torch.int64).contiguous()
+    gt_cls = gt_cls.to(torch.int64).contiguous().view(-1)
+    t3 = rank_tables(obj3, rel3, gt_cls, gt_rel, edges, multi)
+    t2 = rank_tables(obj2, rel2, gt_cls, gt_rel, edges, multi)
+    return eval_counts(counts, t3, t2, gt_cls, gt_rel, edges, n_scenes)
+
+
 def cls_matrix(gt_class: torch.Tensor, gt_rel: torch.Tensor, edges: torch.Tensor, obj_topk: torch.Tensor) -> torch.Tensor:
     """[n,5] rows (sub_gt, sub_pred_rank, obj_gt, obj_pred_rank, predicate | -1) in the order
     evaluate_triplet_topk appends them (eva_utils_acc.py:185-199): per edge its gt predicates in

@@ -164,7 +164,23 @@ class VLSATModel:
                 L.check(self._lib.vlsat_load_weight(self._h, k.encode(), v.ctypes.data, v.size))
             L.check(self._lib.vlsat_finalize_weights(self._h))
         self._loaded = True
+        self._host_weights = host               # (kept for replicate(): 136 MB of host memory at the default sizes)
         return self
+
+    def replicate(self) -> "VLSATModel":
+        """A second model with the same configuration, weights, precision and batch mode on the same GPU: its own library
+        handle, plans and scratch, so it can be driven from another host thread on another stream at the same time
+        (a handle serves one thread and one stream at a time, include/vlsat.h).  evaluate.validation(workers=K) uses K - 1."""
+        if not self._loaded:
+            raise L.VlsatError("replicate(): load weights first")
+        m = VLSATModel(self.config, str(self.device)).load_state(self._host_weights)
+        m._host_weights = self._host_weights
+        if self.gemm_precision != "fp32":
+            m.set_gemm_precision(self.gemm_precision)
+        if self.batch_mode != "per_scene":
+            m.set_batch_mode(self.batch_mode)
+        m.training = self.training
+        return m
 
     def load(self, ckpt_dir: str, best: bool = False) -> bool:
         """``BaseModel.load(best)`` on the reference's checkpoint directory (one ``.pth`` per sub-module,

@@ -218,3 +218,87 @@ def test_model_object_surface_like_the_reference(tmp_path, golden_dir):
     o = m(x["obj_points"], x["obj_2d_feats"], x["edge_indices"], x["descriptor"], x["batch_ids"])
     assert float(np.abs(o[0].cpu().numpy() - z["obj3d"]).max()) < 1e-4
     m.close()
+
+
+def _label_batches(n_batches, scenes_per_batch, seed, n_layers=1):
+    """(cfg, weights, loader-style batch dicts on the GPU) with random labels; some edges carry no gt relation, some several"""
+    from vlsat_amd import VLSATConfig, synth
+    cfg = VLSATConfig(N_LAYERS=n_layers)
+    w = synth.make_weights(cfg)
+    g = torch.Generator().manual_seed(seed)
+    batches = []
+    for s in range(n_batches):
+        sizes = [int(torch.randint(3, 12, (1,), generator=g)) for _ in range(scenes_per_batch)]
+        b = synth.collate([synth.make_scene(n, 32, 9100 + 10 * s + i) for i, n in enumerate(sizes)])
+        n, e = b["obj_points"].shape[0], b["edge_indices"].shape[1]
+        item = {k: torch.from_numpy(v).to(DEV) for k, v in b.items() if k != "edge_indices"}
+        item.update(gt_class=torch.randint(0, 160, (n,), generator=g).to(DEV),
+                    gt_rel_cls=(torch.rand(e, 26, generator=g) < 0.06).long().to(DEV),
+                    edge_indices=torch.from_numpy(b["edge_indices"]).t().contiguous().to(DEV), fc_sizes=sizes)
+        batches.append(item)
+    return cfg, w, batches
+
+
+def test_device_counts_equal_the_host_accumulation():
+    """vlsat_eval_counts (rank tables -> the 361 additive counts, on the device) against evaluate.accumulate (numpy, pinned to
+    the reference's functions in tests/test_evaluate_cpu.py) on the SAME forward outputs: integer counts, exactly equal."""
+    _need_gpu()
+    from vlsat_amd import evaluate as EV, metrics as M
+    from vlsat_amd.model import VLSATModel
+    cfg, w, batches = _label_batches(3, 2, 11)
+    model = VLSATModel(cfg, DEV).load_state(w).eval()
+    vec = np.zeros(len(EV.fields()))
+    counts = torch.zeros(len(EV.fields()), dtype=torch.int64, device=DEV)
+    for b in batches:
+        out = M.process_val(model, b["obj_points"], b["obj_2d_feats"], b["gt_class"], b["descriptor"], b["gt_rel_cls"],
+                            b["edge_indices"], b["batch_ids"], use_triplet=True)
+        EV.accumulate(vec, dict(top_k_obj=out[0], top_k_obj_2d=out[1], top_k_rel=out[2], top_k_rel_2d=out[3],
+                                top_k_triplet=out[4], top_k_triplet_2d=out[5]), out[6], 2)
+        M.process_val_counts(model, counts, b["obj_points"], b["obj_2d_feats"], b["gt_class"], b["descriptor"], b["gt_rel_cls"],
+                             b["edge_indices"], b["batch_ids"], 2)
+    got = counts.cpu().numpy().astype(np.float64)
+    bad = [(f, g, v) for f, g, v in zip(EV.fields(), got, vec) if g != v]
+    assert not bad, bad[:10]
+    assert got[0] == 6 and got.sum() > 1000
+
+
+def test_device_counts_no_relations_and_single_label():
+    """edges without any gt relation (one 'no relation' slot each, predicate -1) and the single-label setting"""
+    _need_gpu()
+    from vlsat_amd import VLSATConfig, synth, evaluate as EV, metrics as M
+    from vlsat_amd.model import VLSATModel
+    cfg = VLSATConfig(N_LAYERS=1, multi_rel_outputs=False, num_rel_class=27)
+    w = synth.make_weights(cfg)
+    model = VLSATModel(cfg, DEV).load_state(w).eval()
+    b = synth.collate([synth.make_scene(6, 32, 77)])
+    g = torch.Generator().manual_seed(5)
+    n, e = 6, 30
+    item = {k: torch.from_numpy(v).to(DEV) for k, v in b.items() if k != "edge_indices"}
+    edges = torch.from_numpy(b["edge_indices"]).t().contiguous().to(DEV)
+    gt_cls = torch.randint(0, 160, (n,), generator=g).to(DEV)
+    gt_rel = torch.randint(0, 27, (e,), generator=g)
+    gt_rel[::3] = 0                                                   # 'none'
+    gt_rel = gt_rel.to(DEV)
+    out = M.process_val(model, item["obj_points"], item["obj_2d_feats"], gt_cls, item["descriptor"], gt_rel, edges, item["batch_ids"], use_triplet=True)
+    vec = EV.accumulate(np.zeros(len(EV.fields(27))), dict(top_k_obj=out[0], top_k_obj_2d=out[1], top_k_rel=out[2], top_k_rel_2d=out[3],
+                                                           top_k_triplet=out[4], top_k_triplet_2d=out[5]), out[6], 1, n_rel=27)
+    counts = torch.zeros(len(EV.fields(27)), dtype=torch.int64, device=DEV)
+    M.process_val_counts(model, counts, item["obj_points"], item["obj_2d_feats"], gt_cls, item["descriptor"], gt_rel, edges, item["batch_ids"], 1)
+    assert np.array_equal(counts.cpu().numpy().astype(np.float64), vec)
+
+
+@pytest.mark.parametrize("workers", [1, 3])
+def test_pipelined_validation_equals_the_reference_compatible_loop(workers):
+    """evaluate.validation(workers=K): one scene per call (validation()'s batch_size = 1), K scenes in flight on K streams and
+    model replicas, counts on the device -- the same summary, to the last count, as the host-synchronous loop."""
+    _need_gpu()
+    from vlsat_amd import evaluate as EV
+    from vlsat_amd.model import VLSATModel
+    cfg, w, batches = _label_batches(14, 1, 23)
+    model = VLSATModel(cfg, DEV).load_state(w).eval()
+    want = EV.validation(model, batches, device=DEV)
+    got = EV.validation(model, batches, device=DEV, workers=workers)
+    assert got["scenes"] == 14 and got == want
+    for b in batches:                                                 # without the fully-connected hint: the edge list is hashed
+        b.pop("fc_sizes")
+    assert EV.validation(model, batches, device=DEV, workers=workers) == want
