@@ -11,7 +11,8 @@
 //   * K in tiles of 64; LDS holds two K-tiles (2 x 64 KB), each as four HALF-TILES of 128 rows x 128 bytes:
 //       A_h = rows {wr*128 + h*64 + i} of the block's A panel,  W_h = rows {wc*64 + h*32 + j} of its weight panel,
 //     i.e. half-tile h is what quadrant h of EVERY wave reads.  Rows are 128 bytes, 16-byte chunks XOR-swizzled with
-//     (row >> 1) & 7 on the global side of the LDS-direct loads and on the fragment reads (0 bank conflicts).
+//     (row >> 1) & 7 on the global side of the LDS-direct loads and on the fragment reads (0 bank conflicts in the K loop;
+//     the epilogue's transposition buffer has its own swizzle, see epi_t).
 //   * A K-tile is FOUR PHASES, one per quadrant of the wave tile, in the order (a0,w0) (a0,w1) (a1,w1) (a1,w0); a phase is
 //         ds_read the operands the quadrant does not hold yet (12 / 4 / 8 / 0 ds_read_b128)
 //         issue ONE half-tile of LDS-direct loads (2 x buffer_load_dwordx4 ... lds per lane)
@@ -288,7 +289,10 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmArgs p, int n_tiles
     // wave-private LDS buffer of 32 rows x 128 bytes (16-byte chunks XOR-swizzled with row & 7) so that lane l then holds
     // 16 consecutive bytes of row 8j + (l >> 3), chunk l & 7: one store instruction writes 8 full 128-byte rows.
     char* const tbuf = smem + P8_TBASE + wave * 4096;
-    const int t_wr = li * 128 + hi * (CF == 2 ? 8 : 0), t_x = (li & 7) << 4;
+    // (half rows: a lane writes 8 bytes; rows li and li + 8 of a 16-lane write group name the same chunk, so the upper eight
+    //  rows take the chunk's OTHER half -- 32 distinct banks per group instead of a 2-way conflict (PMC, round 3: 10-12 % of the
+    //  LDS cycles of the half-row launches) -- and the reader swaps the halves back for those rows, a register renaming)
+    const int t_wr = li * 128 + (CF == 2 ? (hi ^ ((li >> 3) & 1)) * 8 : 0), t_x = (li & 7) << 4;
     const int t_rd = (lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 3) & 7)) << 4);
     const unsigned ldc4 = (unsigned)p.ldc * 4u;
     const unsigned vst = (unsigned)(lane >> 3) * ldc4 + (unsigned)(lane & 7) * 16u;
@@ -343,6 +347,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmArgs p, int n_tiles
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     u32x4 r = rj[j];
+                    if (CF == 2 && (j & 1)) r = u32x4{rj[j][2], rj[j][3], rj[j][0], rj[j][1]};      // rows 8 j + (lane >> 3): halves stored swapped
                     if (WORDS) {               // lane: row 8j + (l >> 3), columns tn*32 + 4 (l & 7) .. +3
                         f32x4 x = __builtin_bit_cast(f32x4, r) + biasr[tn];
 #pragma unroll

@@ -126,7 +126,7 @@ def _validation_pipelined(model, batches: Iterable[dict], device, workers: int) 
     import threading
     from . import metrics as M
     dev = torch.device(device)
-    models = [model] + [model.replicate() for _ in range(workers - 1)]
+    models = [model] + model.replicas(workers - 1)        # (kept by the model: building one uploads and prepares every weight)
     counts = [torch.zeros(len(fields()), dtype=torch.int64, device=dev) for _ in range(workers)]
     it, lock, errors = iter(batches), threading.Lock(), []
 
@@ -156,8 +156,6 @@ def _validation_pipelined(model, batches: Iterable[dict], device, workers: int) 
             t.start()
         for t in ts:
             t.join()
-    for m in models[1:]:
-        m.close()
     if errors:
         raise errors[0]
     return torch.stack(counts).sum(0).cpu().numpy().astype(np.float64)

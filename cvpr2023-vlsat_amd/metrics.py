@@ -129,7 +129,8 @@ def process_val_counts(model, counts: torch.Tensor, obj_points, obj_2d_feats, gt
     ``edge_indices`` is [E,2] as the data loader yields it, on the device."""
     multi = bool(getattr(getattr(model, "config", None), "multi_rel_outputs", True))
     edges = edge_indices.to(torch.int64).contiguous()
-    ei_t = edges.t().contiguous()
+    # with the fully-connected hint the plan never reads the edge list: the [2,E] view is enough (no transpose kernel)
+    ei_t = edges.t() if fc_sizes is not None else edges.t().contiguous()
     obj3, obj2, rel3, rel2 = model(obj_points, obj_2d_feats, ei_t, descriptor, batch_ids, istrain=False, fc_sizes=fc_sizes)
     gt_rel = multihot_targets(gt_rel_cls, rel3.shape[1]).to(torch.int64).contiguous()
     gt_cls = gt_cls.to(torch.int64).contiguous().view(-1)

@@ -79,7 +79,39 @@ class VLSATModel:
             raise L.VlsatError(f"gemm precision must be one of {sorted(self.PRECISIONS)}")
         L.check(self._lib.vlsat_set_gemm_precision(self._h, self.PRECISIONS[mode]))
         self.gemm_precision = mode
+        self._drop_replicas()
         return self
+
+    @torch.no_grad()
+    def auto_precision(self, obj_points, obj_2d_feats, edge_indices, descriptor=None, batch_ids=None, tol: float = 1e-2,
+                       margin: float = 0.5, candidates: Sequence[str] = ("bf16_mixed", "bf16x3")) -> dict:
+        """Pick the fastest bf16 mode whose outputs stay inside ``tol`` on THIS checkpoint: one calibration batch is run in
+        split-bf16 ('bf16x3', ~1e-5 from fp32 at Xavier scale and 1e-3 up to twice that) as the
+        reference and in each faster candidate; the first candidate whose largest output difference is below ``margin * tol``
+        is set (the margin covers batches the calibration did not see).  'bf16_mixed' holds BASELINE configs[2]'s 1e-2 on
+        Xavier-scale weights with a 2x margin but not on a network whose weights amplify roundoff (LayerNorm gains above
+        ~1.5, section 8): the error of the single-rounding modes is the rounding of the MFMA operands themselves (storing the
+        edge tensors as hi/lo pairs instead of bf16 leaves it unchanged, measured), so the remedy is the mode, not a format.
+        Returns {'mode', 'errors': {candidate: max-abs difference}}.  Costs one forward per candidate plus one reference."""
+        prev = self.gemm_precision
+        self.set_gemm_precision("bf16x3")
+        ref = [o.clone() for o in self.forward(obj_points, obj_2d_feats, edge_indices, descriptor, batch_ids)]
+        errors, chosen = {}, "bf16x3"
+        for mode in candidates:
+            if mode == "bf16x3":
+                errors[mode] = 0.0
+                chosen = mode
+                break
+            self.set_gemm_precision(mode)
+            got = self.forward(obj_points, obj_2d_feats, edge_indices, descriptor, batch_ids)
+            errors[mode] = max(float((g - r).abs().max()) if g.numel() else 0.0 for g, r in zip(got, ref))
+            if errors[mode] <= margin * tol:
+                chosen = mode
+                break
+        else:
+            chosen = "bf16x3" if "bf16x3" in candidates else prev
+        self.set_gemm_precision(chosen)
+        return {"mode": chosen, "errors": errors, "tol": tol, "margin": margin}
 
     BATCH_MODES = {"per_scene": 0, "reference": 1}
 
@@ -93,6 +125,7 @@ class VLSATModel:
         L.check(self._lib.vlsat_set_edge_attention_scope(self._h, self.BATCH_MODES[mode]))
         self._drop_plans()                      # plans bake the attention tile table in
         self.batch_mode = mode
+        self._drop_replicas()
         return self
 
     def debug_option(self, name: str, value: int):
@@ -125,6 +158,7 @@ class VLSATModel:
         return self.forward(*a, **k)
 
     def close(self):
+        self._drop_replicas()
         self._drop_plans()
         if getattr(self, "_h", None):
             self._lib.vlsat_destroy(self._h)
@@ -159,6 +193,7 @@ class VLSATModel:
                 raise L.VlsatError(f"weight {k}: shape {v.shape}, expected {shape}")
             host[k] = v
         self._loaded = False                    # until the finalize below succeeds, forward() refuses to run
+        self._drop_replicas()                   # (they hold the previous weights)
         with torch.cuda.device(self.device):
             for k, v in host.items():
                 L.check(self._lib.vlsat_load_weight(self._h, k.encode(), v.ctypes.data, v.size))
@@ -181,6 +216,21 @@ class VLSATModel:
             m.set_batch_mode(self.batch_mode)
         m.training = self.training
         return m
+
+    def replicas(self, k: int) -> list:
+        """``k`` replicas (``replicate()``), built on first use and kept until ``close()`` / the next ``load_state`` /
+        a precision or batch-mode change; evaluate.validation(workers=K) takes K - 1 of them on every call."""
+        cur = getattr(self, "_replicas", None)
+        if cur is None:
+            cur = self._replicas = []
+        while len(cur) < k:
+            cur.append(self.replicate())
+        return cur[:k]
+
+    def _drop_replicas(self):
+        for m in getattr(self, "_replicas", None) or []:
+            m.close()
+        self._replicas = []
 
     def load(self, ckpt_dir: str, best: bool = False) -> bool:
         """``BaseModel.load(best)`` on the reference's checkpoint directory (one ``.pth`` per sub-module,

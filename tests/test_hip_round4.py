@@ -1,0 +1,40 @@
+"""Round-4 cases of the HIP path: choosing the bf16 mode per checkpoint.  Needs an MI355X."""
+import pytest
+import torch
+
+import vlsat_amd  # noqa: F401
+from vlsat_amd import VLSATConfig, synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _model(cfg, weights):
+    from vlsat_amd.model import VLSATModel
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: the HIP path cannot run and there is no fallback")
+    return VLSATModel(cfg, DEV).load_state(weights).eval()
+
+
+@pytest.mark.parametrize("scale,want", [(1.0, "bf16_mixed"), (2.0, "bf16x3")])
+def test_auto_precision_picks_the_fastest_mode_inside_the_tolerance(scale, want):
+    """VLSATModel.auto_precision (BASELINE configs[2], tolerance 1e-2): on Xavier-scale weights the single-rounding mode stays
+    within half the tolerance of the split-bf16 outputs and is chosen; on weights that amplify roundoff (GCN matrices x 2,
+    LayerNorm gains from U(0.3, 3): 6e-2 in bf16_mixed) it is not, and split-bf16 is set instead.
+    Whatever is chosen is then checked against the fp64 oracle on one scene of the batch."""
+    from oracle import vlsat_oracle as O
+    cfg = VLSATConfig(N_LAYERS=3)
+    w = synth.make_weights_stress(cfg, scale) if scale != 1.0 else synth.make_weights(cfg)
+    scenes = [synth.make_scene(24, 128, 4000 + s) for s in range(8)]
+    d = {k: torch.from_numpy(v).to(DEV) for k, v in synth.collate(scenes).items()}
+    m = _model(cfg, w)
+    r = m.auto_precision(d["obj_points"], d["obj_2d_feats"], d["edge_indices"], d["descriptor"], d["batch_ids"], tol=1e-2)
+    assert r["mode"] == want and m.gemm_precision == want, r
+    got = [o.cpu() for o in m(d["obj_points"], d["obj_2d_feats"], d["edge_indices"], d["descriptor"], d["batch_ids"])]
+    c = {k: torch.from_numpy(v) for k, v in synth.collate([scenes[0]]).items()}
+    ref = O.forward(O.to_torch(w, torch.float64), cfg, c["obj_points"].double(), c["obj_2d_feats"].double(), c["edge_indices"],
+                    c["descriptor"].double(), c["batch_ids"])
+    n, e = 24, 24 * 23
+    err = max(float((g[:k] - x.float()).abs().max()) for g, x, k in zip(got, ref, (n, n, e, e)))
+    assert err < 1e-2, (r, err)
+    m.close()

@@ -77,9 +77,9 @@ def main():
         assert got == ref, "summaries differ"
         print(f"  one scene per call, counts on the device, {k} in flight              {a.scenes / t:8.1f} scenes/s   {t / a.scenes * 1e3:6.3f} ms/scene")
     t, got = timed(lambda: EV.validation(model, [big], device=dev, workers=1))
-    same = all(abs(got[k] - ref[k]) < 1e-9 for k in ref)
+    worst = max(abs(got[k] - ref[k]) for k in ref)      # (batched and one-scene forwards differ in the last bits: a near-tie may move a rank)
     print(f"  all {a.scenes} scenes in ONE call (batched)                               {a.scenes / t:8.1f} scenes/s   {t / a.scenes * 1e3:6.3f} ms/scene"
-          f"   summaries {'identical' if same else 'DIFFER'}")
+          f"   largest difference of a summary percentage: {worst:.4f}")
     print("  " + ", ".join(f"{k} {ref[k]:.3f}" for k in ("obj_acc@1_3d", "rel_acc@1_3d", "tri_acc@50_3d", "mean_recall@100_3d", "tri_acc@50_2d")))
 
 
