@@ -321,6 +321,11 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
         case 4: return run_tiled<64, 64>(a, s);
         default: break;
     }
+    // split-bf16 node-row launches with 1024..2048 output columns (self-attention QKV, cross-attention KV at the bench batch):
+    // one round of 64 x 128 tiles beats two rounds of 64 x 64 by 6-8 us per launch (tools/gemm_tile_sweep.py, round 4:
+    // 30.1 -> 24.2 us and 29.4 -> 22.0 us; every other node-row shape is best on what the rule below picks, fp32 within 2-4 us)
+    if (a.prec == 3 && !a.a_split && a.N >= 1024 && a.N <= 2048 && blocks(64, 128) <= G && blocks(64, 128) >= G / 2)
+        return run_tiled<64, 128>(a, s);
     // Largest tile that still gives every resident slot a tile; small problems (and the tails
     // of big ones) take smaller tiles so the launch covers as many CUs as the problem allows.
     if (a.N > 64 && blocks(128, 128) >= G) return run_tiled<128, 128>(a, s);
