@@ -541,6 +541,10 @@ int launch_gemm_p8(const GemmArgs& a, int n_tiles, int grid, hipStream_t s) {
     // the fp32 / split-bf16 epilogues read the bias as float4 (the half-row one as scalars): an unaligned bias pointer of a
     // caller of vlsat_k_gemm goes to the older kernels, which have the scalar fallback
     if ((f32 || x3) && a.bias && (reinterpret_cast<uintptr_t>(a.bias) & 15)) return 1;
+    // (round 4, measured and dropped: loading the accumulator inits of the wave tile's second row half one phase later, under
+    //  the MFMAs of phases 1 / 2 -- fp32 nn_edge.0 + gathered rows 923 vs 917 us, out-projection + residual 480 vs 483: the
+    //  cost of additive operands is not latency at the start of a tile; it is consistent with every CU pulling its 256-512 KB at the same
+    //  moment: 64-128 MB per round of tiles at what the memory system delivers)
     if (f32 ? (a.a_split || a.c_split || a.r_split || a.c_scale != 1.f)
             : x3 ? (a.a_split != 1 || a.c_split == 2 || !a.Wlo) : (a.prec != 1 || a.a_split != 2 || a.c_split == 1)) return 1;
     const int kt = (f32 || x3) ? 32 : P8_BK;          // an output tile is an even number (>= 4) of K-tiles
