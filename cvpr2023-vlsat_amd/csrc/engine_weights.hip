@@ -228,7 +228,7 @@ int split_all_weights(vlsat_ctx* h) {
 // ============================================================================================
 extern "C" {
 
-const char* vlsat_version(void) { return "vlsat-hip gfx950 r3 (fp32-mfma | bf16x3 | bf16_mixed | bf16)"; }
+const char* vlsat_version(void) { return "vlsat-hip gfx950 r4 (fp32-mfma | bf16x3 | bf16_mixed | bf16)"; }
 
 int vlsat_create(const VlsatDims* d, vlsat_handle* out) {
     if (!d || !out) return fail(VLSAT_EINVAL, "vlsat_create: null argument");

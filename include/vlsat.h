@@ -69,7 +69,7 @@ typedef struct {
 } VlsatDims;
 
 const char* vlsat_last_error(void);
-/* library / build identification, e.g. "vlsat-hip gfx950 r3 (fp32-mfma | bf16x3 | bf16_mixed | bf16)" */
+/* library / build identification, e.g. "vlsat-hip gfx950 r4 (fp32-mfma | bf16x3 | bf16_mixed | bf16)" */
 const char* vlsat_version(void);
 
 /* Mmgnet.__init__ (module construction), reference SGFN_MMG/model.py:20-159. */
