@@ -467,6 +467,7 @@ static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const fl
             {
                 Scope sc(h, s, PC_FLASH, p->flash_flops);
                 FlashSplit sp;
+                sp.ablate = h->flash_ablate;
                 sp.parts = p->fa_parts; sp.krange = p->d_krange; sp.o_part = p->fa_opart; sp.m_part = p->fa_m;
                 sp.l_part = p->fa_l; sp.part_stride = (size_t)E * D; sp.rows = E; sp.heads = h->H;
                 if (dh != 32 && dh != 64 && dh != 128)   // any other head dim: VALU attention over the scenes' edge ranges (no bias)
@@ -475,7 +476,7 @@ static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const fl
                                          1.f / std::sqrt((float)(D / h->H)), s, h->node_attn_split));
                 else if (fa16)
                     RUN(launch_flash_attn_bf16(p->Qe, D, p->KVe, p->KVe + (SA == 2 ? D / 2 : D), 2 * D, p->Oe, D, p->d_tiles, p->n_tiles,
-                                               sc2e, h->prec_edge == 3 ? 3 : 1, h->flash_tr, SA, s, &sp, h->flash_pv_terms, dh));    // (half rows: V starts at byte 2 D)
+                                               sc2e, h->prec_edge == 3 ? 3 : 1, h->flash_tr ? (h->flash_dma ? 1 : 2) : 0, SA, s, &sp, h->flash_pv_terms, dh));    // (half rows: V starts at byte 2 D)
                 else
                     RUN(launch_flash_attn(p->Qe, D, p->KVe, p->KVe + D, 2 * D, p->Oe, D, p->d_tiles, p->n_tiles, sc2e, s, &sp, dh));   // (head dims 32 / 128: NUM_HEADS 16 / 4)
             }

@@ -85,7 +85,15 @@ __device__ __forceinline__ void planes_of(const f32x4& x, bf16x4& hi, bf16x4& lo
 // scale * log2 e (the projection GEMM's epilogue did it)
 // PVT (split-bf16 mode only): MFMAs per P.V product.  3 = V_hi.P_hi + V_lo.P_hi + V_hi.P_lo; 2 drops the last term, i.e. the
 // probabilities enter the second product single-rounded (V stays exact) -- an experiment switch (flash_pv_terms).
-template <int TERMS, bool TR, int IO, int PVT = 3, int FB_D = 64>
+// DMA (round 4; half rows, single rounding, head dim 64): K / V tiles arrive by LDS-direct loads (buffer_load ... lds, no VGPR
+// round trip, no ds_write) into a ring of THREE tile buffers, two tiles ahead of the one being computed, with counted
+// s_waitcnt vmcnt and a raw s_barrier per tile.  Measured before: with the staging loads switched off the kernel ran 28 %
+// faster, with the LDS stores off as well 43 % (profiles/r04_probes/flash_bf16_staging_ablation.txt) -- one tile of look-ahead
+// through registers does not cover an L2 / HBM round trip inside a 0.45 us iteration.  The K image is then 64 rows x 128 B with
+// the 16-byte chunks XOR-swizzled by (row >> 1) & 7 on the global side and on the fragment reads (an LDS-direct load writes
+// lane-linear, so the 144-byte row pitch of the register-staged image cannot be produced); the V image is unchanged (four
+// [64 keys][16 d] sub-tiles: a wave instruction fills 32 keys x 32 B of one of them).
+template <int TERMS, bool TR, int IO, int PVT = 3, int FB_D = 64, bool DMA = false>
 __global__ __launch_bounds__(256, 2) void flash_attn_bf16_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
     float* __restrict__ O, int ldq, int ldkv, int ldo, const int4* __restrict__ tiles, int n_tiles,
@@ -96,8 +104,10 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bf16_kernel(
     constexpr int FB_KPLANE = FB_KV * FB_KPITCH;
     constexpr int FB_VPLANE = NSUB * FB_VSUB;
     constexpr int FB_OPITCH = FB_D + 4;            // floats per query row of the output transpose
-    constexpr int BUF = PL * (FB_KPLANE + FB_VPLANE);
-    constexpr int SMEM = 2 * BUF > 4 * 32 * FB_OPITCH * 4 ? 2 * BUF : 4 * 32 * FB_OPITCH * 4;
+    static_assert(!DMA || (TERMS == 1 && IO == 2 && TR && FB_D == 64), "LDS-direct K/V staging: half rows, single rounding, head dim 64");
+    constexpr int BUF = DMA ? FB_KV * 128 + FB_VPLANE : PL * (FB_KPLANE + FB_VPLANE);
+    constexpr int NBUF = DMA ? 3 : 2;
+    constexpr int SMEM = NBUF * BUF > 4 * 32 * FB_OPITCH * 4 ? NBUF * BUF : 4 * 32 * FB_OPITCH * 4;
     __shared__ __attribute__((aligned(16))) char smem[SMEM];
 
     const int tile_id = xcd_remap(blockIdx.x, n_tiles);
@@ -184,17 +194,51 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bf16_kernel(
     // tile is handled by masking, below)
     const int kt0 = kr.x >> 1, kt1 = (kr.y + 1) >> 1;
     const int key_lo = kr.x * 32, key_hi = kr.y * 32 < n_tok ? kr.y * 32 : n_tok;       // keys [key_lo, key_hi) belong to this block
-    if (kt0 < kt1) {
-        load_tile(kt0 * FB_KV);
-        store_tile(smem + (kt0 & 1) * BUF);
+    // ---- LDS-direct staging (DMA): one tile = 4 loads per wave -- K rows 16 w .. 16 w + 15 (two instructions of 8 rows x 128 B),
+    //      V sub-tile w (two instructions of 32 keys x 32 B).  The buffer descriptors span THIS scene's rows only, so keys past
+    //      the scene's last token read as zeros (their scores are masked below) ----
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(K + (size_t)row_base * ldkv), 0, DMA ? (int)(unsigned)((size_t)n_tok * ldkv * 4) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(V + (size_t)row_base * ldkv), 0, DMA ? (int)(unsigned)((size_t)n_tok * ldkv * 4) : 0, 0x00020000);
+    const unsigned ld4 = (unsigned)ldkv * 4u;
+    const int dk_row = wave_u * 16 + (lane >> 3);                                     // K row of the first instruction (+8: the second)
+    const unsigned vK0 = (unsigned)dk_row * ld4 + (unsigned)col0 * 2u + (unsigned)(((lane & 7) ^ ((dk_row >> 1) & 7)) << 4);
+    const unsigned vK1 = (unsigned)(dk_row + 8) * ld4 + (unsigned)col0 * 2u + (unsigned)(((lane & 7) ^ (((dk_row + 8) >> 1) & 7)) << 4);
+    const unsigned vV0 = (unsigned)(lane >> 1) * ld4 + (unsigned)col0 * 2u + (unsigned)wave_u * 32u + (unsigned)(lane & 1) * 16u;   // keys 0..31 of sub-tile w
+    auto dma_tile = [&](int kv0, char* buf) {
+        const unsigned s0 = (unsigned)kv0 * ld4;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rK, buf + wave_u * 2048, 16, vK0, s0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rK, buf + wave_u * 2048 + 1024, 16, vK1, s0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rV, buf + FB_KV * 128 + wave_u * FB_VSUB, 16, vV0, s0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rV, buf + FB_KV * 128 + wave_u * FB_VSUB + 1024, 16, vV0, s0 + 32u * ld4, 0, 0);
+    };
+    if (DMA) {
+        if (kt0 < kt1) dma_tile(kt0 * FB_KV, smem);
+        if (kt0 + 1 < kt1) {
+            dma_tile((kt0 + 1) * FB_KV, smem + BUF);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_barrier" ::: "memory");
+    } else {
+        if (kt0 < kt1) {
+            load_tile(kt0 * FB_KV);
+            store_tile(smem + (kt0 & 1) * BUF);
+        }
+        __syncthreads();
     }
-    __syncthreads();
 
+    int ring = 0;                                          // (DMA) buffer of tile kt
     for (int kt = kt0; kt < kt1; ++kt) {
-        const char* sK = smem + (kt & 1) * BUF;
-        const char* sV = sK + PL * FB_KPLANE;
+        const char* sK = smem + (DMA ? ring : (kt & 1)) * BUF;
+        const char* sV = sK + (DMA ? FB_KV * 128 : PL * FB_KPLANE);
         const bool more = kt + 1 < kt1;
-        if (more) load_tile((kt + 1) * FB_KV);
+        const bool more2 = kt + 2 < kt1;
+        if (DMA) {
+            // tile kt + 2 goes into the buffer tile kt - 1 was read from: every wave passed the barrier that ended iteration kt - 1
+            if (more2 && !(sp.ablate & 1)) dma_tile((kt + 2) * FB_KV, smem + (ring == 0 ? 2 : ring - 1) * BUF);
+        } else if (more && !(sp.ablate & 1)) load_tile((kt + 1) * FB_KV);
 
         if (wave_active) {
             // ---- S^T[key][query] = sum_d K[key][d] * Q[query][d], two blocks of 32 keys ----
@@ -204,10 +248,12 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bf16_kernel(
             {
                 // the two 32-key blocks alternate, so consecutive MFMAs never wait for each other's accumulator
                 const char* kp = sK + li * FB_KPITCH + 16 * hi;
+                const char* kd = sK + li * 128;                       // (DMA) row li; rows li and li + 32 share the swizzle
+                const int kswz = (li >> 1) & 7;
 #pragma unroll
                 for (int ks = 0; ks < NKS; ++ks) {
-                    const bf16x8 kh0 = *reinterpret_cast<const bf16x8*>(kp + 32 * ks);
-                    const bf16x8 kh1 = *reinterpret_cast<const bf16x8*>(kp + 32 * FB_KPITCH + 32 * ks);
+                    const bf16x8 kh0 = *reinterpret_cast<const bf16x8*>(DMA ? kd + (((hi + 2 * ks) ^ kswz) << 4) : kp + 32 * ks);
+                    const bf16x8 kh1 = *reinterpret_cast<const bf16x8*>(DMA ? kd + 32 * 128 + (((hi + 2 * ks) ^ kswz) << 4) : kp + 32 * FB_KPITCH + 32 * ks);
                     if (PL == 2) {
                         const bf16x8 kl0 = *reinterpret_cast<const bf16x8*>(kp + FB_KPLANE + 32 * ks);
                         const bf16x8 kl1 = *reinterpret_cast<const bf16x8*>(kp + FB_KPLANE + 32 * FB_KPITCH + 32 * ks);
@@ -306,8 +352,16 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bf16_kernel(
                 for (int db = 0; db < NO; ++db) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db][0], ph, o[db], 0, 0, 0);
             }
         }   // wave_active
-        if (more) store_tile(smem + ((kt + 1) & 1) * BUF);
-        __syncthreads();
+        if (DMA) {
+            // tile kt + 1 has landed once at most this iteration's four loads (tile kt + 2) are outstanding
+            if (more2 && !(sp.ablate & 1)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            ring = ring == 2 ? 0 : ring + 1;
+        } else {
+            if (more && !(sp.ablate & 2)) store_tile(smem + ((kt + 1) & 1) * BUF);
+            __syncthreads();
+        }
     }
 
     // ---- normalise (or, in split mode, keep un-normalised and record m, l), transpose through LDS
@@ -374,6 +428,7 @@ int launch_flash_attn_bf16(const float* Q, int ldq, const float* K, const float*
         if (!sp.krange || !sp.o_part || !sp.m_part || !sp.l_part || sp.heads * FB_D > ldo)
             return fail(-1, "flash_attn: incomplete split-key workspace");
     }
+    if (split) sp.ablate = split->ablate;
 #define VLSAT_FA(T, R, S) hipLaunchKernelGGL((flash_attn_bf16_kernel<T, R, S>), dim3(n_tiles), dim3(256), 0, s, Q, K, V, O, ldq, ldkv, ldo, tiles, n_tiles, scale_log2e, sp)
 #define VLSAT_FAD(T, S, P, D) hipLaunchKernelGGL((flash_attn_bf16_kernel<T, true, S, P, D>), dim3(n_tiles), dim3(256), 0, s, Q, K, V, O, ldq, ldkv, ldo, tiles, n_tiles, scale_log2e, sp)
     if (FB_D != 64) {          // 16 / 4 heads: the formats the forward uses (the transpose-read path; split-bf16 only at 32)
@@ -388,7 +443,12 @@ int launch_flash_attn_bf16(const float* Q, int ldq, const float* K, const float*
     } else
     if (io_split == 2) {
         if (!use_tr || terms != 1) return fail(-1, "flash_attn_bf16: half-row tensors need terms = 1 and the transpose-read path");
-        VLSAT_FA(1, true, 2);
+        // LDS-direct K/V ring (scene-relative 32-bit byte offsets: a scene of < 2^32 / (4 ldkv) rows, which the GEMM launchers' own
+        // 32-bit guards already imply)
+        if (use_tr != 2)            // (use_tr = 2: the register-staged kernel of round 3, for A/B -- vlsat_debug_option "flash_dma" 0)
+            hipLaunchKernelGGL((flash_attn_bf16_kernel<1, true, 2, 3, 64, true>), dim3(n_tiles), dim3(256), 0, s, Q, K, V, O, ldq, ldkv, ldo, tiles, n_tiles, scale_log2e, sp);
+        else
+            VLSAT_FA(1, true, 2);
     } else if (io_split) {
         if (!use_tr) return fail(-1, "flash_attn_bf16: the split-pair format is built for the transpose-read path only");
         if (terms == 3 && pv_terms == 2)

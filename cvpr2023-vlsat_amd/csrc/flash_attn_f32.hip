@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_f32_kernel(
         const float* sK = smem + (kt & 1) * BUF;
         const float* sV = sK + FA_KV * FA_PITCH;
         const bool more = kt + 1 < kt1;
-        if (more) load_tile((kt + 1) * FA_KV);
+        if (more && !(sp.ablate & 1)) load_tile((kt + 1) * FA_KV);
 
         if (wave_active) {
         // ---- S^T[key][query] = sum_d K[key][d] * Q[query][d] ----
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_f32_kernel(
             for (int b = 0; b < NO; ++b) o[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[32 * b], s[r], o[b], 0, 0, 0);
         }
         }   // wave_active
-        if (more) store_tile(smem + ((kt + 1) & 1) * BUF);
+        if (more && !(sp.ablate & 2)) store_tile(smem + ((kt + 1) & 1) * BUF);
         __syncthreads();
     }
 
@@ -245,6 +245,7 @@ int launch_flash_attn(const float* Q, int ldq, const float* K, const float* V, i
         if (!sp.krange || !sp.o_part || !sp.m_part || !sp.l_part || sp.heads * FA_D > ldo)
             return fail(-1, "flash_attn: incomplete split-key workspace");
     }
+    if (split) sp.ablate = split->ablate;
     if (FA_D == 32)
         hipLaunchKernelGGL(flash_attn_f32_kernel<32>, dim3(n_tiles), dim3(256), 0, s, Q, K, V, O, ldq, ldkv, ldo, tiles, n_tiles, scale_log2e, sp);
     else if (FA_D == 64)

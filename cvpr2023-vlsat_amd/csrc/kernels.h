@@ -81,6 +81,7 @@ struct FlashSplit {
     float* o_part = nullptr; float* m_part = nullptr; float* l_part = nullptr;
     size_t part_stride = 0;      // floats between parts of o_part (= rows * ldo)
     int rows = 0, heads = 0;
+    int ablate = 0;              // timing experiments (garbage results): bit 0 no K/V loads after the first tile, bit 1 no LDS stores of them either
 };
 int launch_flash_attn(const float* Q, int ldq, const float* K, const float* V, int ldkv, float* O, int ldo,
                       const int4* tiles, int n_tiles, float scale_log2e, hipStream_t s, const FlashSplit* split = nullptr,
