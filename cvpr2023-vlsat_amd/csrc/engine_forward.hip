@@ -476,7 +476,7 @@ static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const fl
                                          1.f / std::sqrt((float)(D / h->H)), s, h->node_attn_split));
                 else if (fa16)
                     RUN(launch_flash_attn_bf16(p->Qe, D, p->KVe, p->KVe + (SA == 2 ? D / 2 : D), 2 * D, p->Oe, D, p->d_tiles, p->n_tiles,
-                                               sc2e, h->prec_edge == 3 ? 3 : 1, h->flash_tr ? (h->flash_dma ? 1 : 2) : 0, SA, s, &sp, h->flash_pv_terms, dh));    // (half rows: V starts at byte 2 D)
+                                               sc2e, h->prec_edge == 3 ? 3 : 1, h->flash_tr ? (h->flash_dma >= 3 ? h->flash_dma : h->flash_dma ? 1 : 2) : 0, SA, s, &sp, h->flash_pv_terms, dh));    // (half rows: V starts at byte 2 D)
                 else
                     RUN(launch_flash_attn(p->Qe, D, p->KVe, p->KVe + D, 2 * D, p->Oe, D, p->d_tiles, p->n_tiles, sc2e, s, &sp, dh));   // (head dims 32 / 128: NUM_HEADS 16 / 4)
             }

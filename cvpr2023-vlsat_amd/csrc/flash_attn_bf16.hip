@@ -86,14 +86,14 @@ __device__ __forceinline__ void planes_of(const f32x4& x, bf16x4& hi, bf16x4& lo
 // PVT (split-bf16 mode only): MFMAs per P.V product.  3 = V_hi.P_hi + V_lo.P_hi + V_hi.P_lo; 2 drops the last term, i.e. the
 // probabilities enter the second product single-rounded (V stays exact) -- an experiment switch (flash_pv_terms).
 // DMA (round 4; half rows, single rounding, head dim 64): K / V tiles arrive by LDS-direct loads (buffer_load ... lds, no VGPR
-// round trip, no ds_write) into a ring of THREE tile buffers, two tiles ahead of the one being computed, with counted
-// s_waitcnt vmcnt and a raw s_barrier per tile.  Measured before: with the staging loads switched off the kernel ran 28 %
+// round trip, no ds_write) into a ring of RING tile buffers (2 as shipped: one tile ahead, four blocks per CU), RING - 1 tiles
+// ahead of the one being computed, with counted s_waitcnt vmcnt and a raw s_barrier per tile.  Measured before: with the staging loads switched off the kernel ran 28 %
 // faster, with the LDS stores off as well 43 % (profiles/r04_probes/flash_bf16_staging_ablation.txt) -- one tile of look-ahead
 // through registers does not cover an L2 / HBM round trip inside a 0.45 us iteration.  The K image is then 64 rows x 128 B with
 // the 16-byte chunks XOR-swizzled by (row >> 1) & 7 on the global side and on the fragment reads (an LDS-direct load writes
 // lane-linear, so the 144-byte row pitch of the register-staged image cannot be produced); the V image is unchanged (four
 // [64 keys][16 d] sub-tiles: a wave instruction fills 32 keys x 32 B of one of them).
-template <int TERMS, bool TR, int IO, int PVT = 3, int FB_D = 64, bool DMA = false>
+template <int TERMS, bool TR, int IO, int PVT = 3, int FB_D = 64, int RING = 0>
 __global__ __launch_bounds__(256, 2) void flash_attn_bf16_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
     float* __restrict__ O, int ldq, int ldkv, int ldo, const int4* __restrict__ tiles, int n_tiles,
@@ -104,9 +104,10 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bf16_kernel(
     constexpr int FB_KPLANE = FB_KV * FB_KPITCH;
     constexpr int FB_VPLANE = NSUB * FB_VSUB;
     constexpr int FB_OPITCH = FB_D + 4;            // floats per query row of the output transpose
+    constexpr bool DMA = RING != 0;           // RING: tile buffers of the LDS-direct K/V ring (0: register-staged double buffer)
     static_assert(!DMA || (TERMS == 1 && IO == 2 && TR && FB_D == 64), "LDS-direct K/V staging: half rows, single rounding, head dim 64");
     constexpr int BUF = DMA ? FB_KV * 128 + FB_VPLANE : PL * (FB_KPLANE + FB_VPLANE);
-    constexpr int NBUF = DMA ? 3 : 2;
+    constexpr int NBUF = DMA ? RING : 2, LA = NBUF - 1;           // (DMA) tiles of look-ahead
     constexpr int SMEM = NBUF * BUF > 4 * 32 * FB_OPITCH * 4 ? NBUF * BUF : 4 * 32 * FB_OPITCH * 4;
     __shared__ __attribute__((aligned(16))) char smem[SMEM];
 
@@ -148,6 +149,8 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bf16_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[b][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
+    // (tried in round 4 and dropped: the row sums of P through the matrix pipe -- one more MFMA per 16 keys with an all-ones A
+    //  operand instead of 32 fp32 adds per lane and tile: 735 vs 790 TFLOP/s on the same box, profiles/r04_probes/flash_bf16_dma_ab.txt)
 
     // ---- staging: K rows (tid>>4) + 16 i, four d per thread; V: wave-instruction = 4 keys x all 64 d, so that a
     //      16-lane write group fills 4 consecutive 32-byte rows of ONE sub-tile (conflict-free ds_write_b64) ----
@@ -212,14 +215,19 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bf16_kernel(
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rV, buf + FB_KV * 128 + wave_u * FB_VSUB, 16, vV0, s0, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rV, buf + FB_KV * 128 + wave_u * FB_VSUB + 1024, 16, vV0, s0 + 32u * ld4, 0, 0);
     };
+    // counted wait: everything but the newest `n` tiles (4 loads each) has landed
+    auto wait_tiles = [&](int n) {
+        if (n <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (n == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (n == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    };
     if (DMA) {
-        if (kt0 < kt1) dma_tile(kt0 * FB_KV, smem);
-        if (kt0 + 1 < kt1) {
-            dma_tile((kt0 + 1) * FB_KV, smem + BUF);
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        int issued = 0;
+#pragma unroll
+        for (int j = 0; j < LA; ++j)
+            if (kt0 + j < kt1) { dma_tile((kt0 + j) * FB_KV, smem + j * BUF); ++issued; }
+        wait_tiles(issued - 1);
         asm volatile("s_barrier" ::: "memory");
     } else {
         if (kt0 < kt1) {
@@ -234,10 +242,9 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bf16_kernel(
         const char* sK = smem + (DMA ? ring : (kt & 1)) * BUF;
         const char* sV = sK + (DMA ? FB_KV * 128 : PL * FB_KPLANE);
         const bool more = kt + 1 < kt1;
-        const bool more2 = kt + 2 < kt1;
         if (DMA) {
-            // tile kt + 2 goes into the buffer tile kt - 1 was read from: every wave passed the barrier that ended iteration kt - 1
-            if (more2 && !(sp.ablate & 1)) dma_tile((kt + 2) * FB_KV, smem + (ring == 0 ? 2 : ring - 1) * BUF);
+            // tile kt + LA goes into the buffer tile kt - 1 was read from: every wave passed the barrier that ended iteration kt - 1
+            if (kt + LA < kt1 && !(sp.ablate & 1)) dma_tile((kt + LA) * FB_KV, smem + (ring == 0 ? NBUF - 1 : ring - 1) * BUF);
         } else if (more && !(sp.ablate & 1)) load_tile((kt + 1) * FB_KV);
 
         if (wave_active) {
@@ -353,11 +360,10 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bf16_kernel(
             }
         }   // wave_active
         if (DMA) {
-            // tile kt + 1 has landed once at most this iteration's four loads (tile kt + 2) are outstanding
-            if (more2 && !(sp.ablate & 1)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // tile kt + 1 has landed once only the tiles issued after it (kt + 2 .. kt + LA, as far as they exist) are outstanding
+            wait_tiles((sp.ablate & 1) ? 0 : min(LA - 1, kt1 - kt - 2));
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            ring = ring == 2 ? 0 : ring + 1;
+            ring = ring == NBUF - 1 ? 0 : ring + 1;
         } else {
             if (more && !(sp.ablate & 2)) store_tile(smem + ((kt + 1) & 1) * BUF);
             __syncthreads();
@@ -443,10 +449,16 @@ int launch_flash_attn_bf16(const float* Q, int ldq, const float* K, const float*
     } else
     if (io_split == 2) {
         if (!use_tr || terms != 1) return fail(-1, "flash_attn_bf16: half-row tensors need terms = 1 and the transpose-read path");
-        // LDS-direct K/V ring (scene-relative 32-bit byte offsets: a scene of < 2^32 / (4 ldkv) rows, which the GEMM launchers' own
-        // 32-bit guards already imply)
-        if (use_tr != 2)            // (use_tr = 2: the register-staged kernel of round 3, for A/B -- vlsat_debug_option "flash_dma" 0)
-            hipLaunchKernelGGL((flash_attn_bf16_kernel<1, true, 2, 3, 64, true>), dim3(n_tiles), dim3(256), 0, s, Q, K, V, O, ldq, ldkv, ldo, tiles, n_tiles, scale_log2e, sp);
+        // LDS-direct K/V staging (scene-relative 32-bit byte offsets: a scene of < 2^32 / (4 ldkv) rows, which the GEMM launchers'
+        // own 32-bit guards already imply).  Measured on one box, interleaved (profiles/r04_probes/flash_bf16_dma_ab.txt): register-
+        // staged 596 TFLOP/s; ring of 3 buffers (3 blocks per CU) 745-773; ring of 4 (2 blocks per CU) 650-659; ring of 2 = one
+        // tile ahead with FOUR blocks per CU (34 KB of LDS, 120 VGPRs) 813-817: occupancy beats look-ahead depth.
+        if (use_tr == 3)            // (experiments: vlsat_debug_option "flash_dma" 3 | 4 = rings of three / four buffers)
+            hipLaunchKernelGGL((flash_attn_bf16_kernel<1, true, 2, 3, 64, 3>), dim3(n_tiles), dim3(256), 0, s, Q, K, V, O, ldq, ldkv, ldo, tiles, n_tiles, scale_log2e, sp);
+        else if (use_tr == 4)
+            hipLaunchKernelGGL((flash_attn_bf16_kernel<1, true, 2, 3, 64, 4>), dim3(n_tiles), dim3(256), 0, s, Q, K, V, O, ldq, ldkv, ldo, tiles, n_tiles, scale_log2e, sp);
+        else if (use_tr != 2)       // (use_tr = 2: the register-staged kernel of round 3, for A/B -- "flash_dma" 0)
+            hipLaunchKernelGGL((flash_attn_bf16_kernel<1, true, 2, 3, 64, 2>), dim3(n_tiles), dim3(256), 0, s, Q, K, V, O, ldq, ldkv, ldo, tiles, n_tiles, scale_log2e, sp);
         else
             VLSAT_FA(1, true, 2);
     } else if (io_split) {

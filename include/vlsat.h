@@ -363,6 +363,10 @@ int vlsat_debug_gemm_clock_probe(int64_t* buf);
  * twice the error on weights that make the attention peaked -- left at 3);
  * "gemm_splitk" 0|1: small GEMM launches on the split-K kernel; "node_attn_split" n: node attention with sixteen lanes per
  * query for plans with fewer than n one-query-per-lane waves;
+ * "flash_dma" 0|1|3|4: half-row bf16 edge attention at head dim 64, K / V tiles by LDS-direct loads (1, default: two tile buffers,
+ * one tile ahead, four blocks per CU; 3 / 4: rings of three / four buffers; 0: the register-staged kernel of round 3);
+ * "flash_ablate" bits: timing experiments on the edge attention, GARBAGE results (1: no K/V loads after the first tile, 2: no LDS
+ * stores of them);
  * "flash_bf16" / "pointnet_bf16" / "gate_bf16" 0|1: in the bf16 modes, edge attention / object encoder / edge gate on
  * the bf16 matrix cores (0: the fp32 kernels); "flash_tr" 0|1: its V operand by
  * ds_read_b64_tr_b16 (0: ds_read_u16 gather). */
