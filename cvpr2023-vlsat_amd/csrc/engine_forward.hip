@@ -162,6 +162,7 @@ int gcn_block(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const GcnW& w, float
         kp.c_split = (gate16 || gate16h) ? S : 0;      // (the fp32 gate kernels read plain fp32)
         RUN(gemm(h, s, kp));
     }
+    bool fused_agg = false;
     GemmArgs e2 = G(sc.Hbig, 2 * D, w.we2, 2 * D, e, D, E, D, w.be2);       // e <- nn_edge output (pre-activation)
     e2.a_split = S; e2.c_split = S;
     RUN(gemm(h, s, e2));
@@ -171,6 +172,14 @@ int gcn_block(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const GcnW& w, float
         g.src = p->d_src; g.dst = p->d_dst; g.w0k = w.w0k; g.w3 = w.w3; g.b3 = w.b3; g.gated = sc.G;
         g.prob = p->prob; g.n_edges = E; g.use_edge = h->d.use_gcn_edge; g.grid_cap = h->gate_grid; g.row_map = h->gate_row_map;
         const double dk = D / h->H, dox = A / h->H;
+        // bf16 gate at 8 x (64, 32), max aggregation, no debug tap: the aggregation happens inside the gate kernel (no [E, 256]
+        // tensor of gated messages, no aggregate launch); the start values go in first
+        fused_agg = gate16 && !gate16h && !(h->gate_heads_mfma == 2) && h->gate_fuse_agg && h->d.gcn_aggr == 0 && !g.prob && h->debug_stop < 0 && h->gate_row_map && E > 0;
+        if (fused_agg) {
+            Scope scope(h, s, PC_AGGREGATE, 0);
+            RUN(launch_agg_init(p->d_rowptr, N, A, x + D, LDX, s));
+            g.agg = x + D; g.ld_agg = LDX;
+        }
         Scope scope(h, s, PC_GATE, (double)E * h->H * (2.0 * dk * 2 * dk + 2.0 * 2 * dk * dox));
         if (gate16h) {
             RUN(launch_edge_gate_bf16_heads(g, h->H, D / h->H, A / h->H, h->prec_edge == 3 ? 3 : 1, S, s));
@@ -182,7 +191,7 @@ int gcn_block(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const GcnW& w, float
         else if (gate16) RUN(launch_edge_gate_bf16(g, h->prec_edge == 3 ? 3 : 1, S, s));
         else RUN(launch_edge_gate(g, s));
     }
-    {
+    if (!fused_agg) {
         Scope scope(h, s, PC_AGGREGATE, 0);
         RUN(launch_aggregate(sc.G, A, p->d_rowptr, p->d_order, N, h->d.gcn_aggr, x, LDX, D, s));
     }

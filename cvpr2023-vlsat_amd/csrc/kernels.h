@@ -149,9 +149,17 @@ struct GateArgs {
     int n_edges;
     int use_edge = 1;        // MODEL.USE_GCN_EDGE: 0 -> the gate MLP sees the query alone (kproj / w0k unused)
     int grid_cap = 0;        // debug: persistent grid size (0 = 3 blocks per CU; vlsat_debug_option "gate_grid")
+    // Fused max aggregation (Aggre_Index with GCN_AGGR = max, reference network_util.py:64-73): when `agg` is set the gated rows
+    // are not stored; every wave reduces its 32 rows by source node through LDS and folds the partial maxima into
+    // agg[src, h*32 + m] (row pitch ld_agg) with integer-ordered atomic max -- exact and order-independent.  `agg` must have been
+    // initialised by launch_agg_init (-inf for nodes with out-edges, 0 for the others: torch_scatter's empty segment).
+    float* agg = nullptr;
+    int ld_agg = 0;
     int row_map = 1;         // rows of a wave: 1 = 32 edges of one head, 0 = 4 edges x 8 heads (vlsat_debug_option "gate_row_map")
 };
 int launch_edge_gate(const GateArgs& a, hipStream_t s);
+// agg[n, 0:n_ch] = rowptr[n+1] > rowptr[n] ? -inf : 0   (start values of the fused max aggregation)
+int launch_agg_init(const int32_t* rowptr, int n_nodes, int n_ch, float* agg, int ld_agg, hipStream_t s);
 // any head geometry (dk query / edge channels per head, dox output channels per head): plain VALU
 int launch_edge_gate_generic(const GateArgs& a, int n_heads, int dk, int dox, hipStream_t s);
 // the head geometries of MODEL.NUM_HEADS in {4, 8, 16} x DIM_ATTEN in {128, 256, 512} on the fp32 matrix cores

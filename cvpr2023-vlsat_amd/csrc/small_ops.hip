@@ -204,6 +204,23 @@ __global__ __launch_bounds__(256) void aggregate_kernel(const float* __restrict_
         out[(size_t)n * ldo + col0 + c] = acc;
     }
 }
+// start values of the aggregation fused into the gate kernel (edge_gate_bf16.hip): -inf where a maximum will arrive, 0 for
+// nodes without out-edges (torch_scatter's empty segment)
+__global__ __launch_bounds__(256) void agg_init_kernel(const int32_t* __restrict__ rowptr, int n_nodes, int n_ch, float* __restrict__ agg, int ld) {
+    const int i = blockIdx.x * 256 + threadIdx.x, n = i / (n_ch / 4), c4 = (i % (n_ch / 4)) * 4;
+    if (n >= n_nodes) return;
+    const float v = rowptr[n + 1] > rowptr[n] ? -INFINITY : 0.f;
+    *reinterpret_cast<f32x4*>(agg + (size_t)n * ld + c4) = f32x4{v, v, v, v};
+}
+int launch_agg_init(const int32_t* rowptr, int n_nodes, int n_ch, float* agg, int ld_agg, hipStream_t s) {
+    if (n_nodes <= 0) return 0;
+    if ((n_ch & 3) || (ld_agg & 3)) return fail(-1, "agg_init: channel count and pitch must be multiples of 4");
+    const long n4 = (long)n_nodes * (n_ch / 4);
+    hipLaunchKernelGGL(agg_init_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, rowptr, n_nodes, n_ch, agg, ld_agg);
+    VLSAT_LAUNCH_CHECK("agg_init");
+    return 0;
+}
+
 int launch_aggregate(const float* gated, int n_ch, const int32_t* rowptr, const int32_t* order, int n_nodes,
                      int aggr, float* out, int ldo, int col0, hipStream_t s) {
     if (n_nodes <= 0) return 0;
