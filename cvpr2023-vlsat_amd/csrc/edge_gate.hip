@@ -20,6 +20,7 @@
 // One wave = 32 rows = 4 edges per step (192 MFMAs); a block of 4 waves walks 16-edge groups.
 #include <cstdlib>
 #include "gemm_core.h"
+#include "gate_agg.h"
 #include "kernels.h"
 
 namespace vlsat {
@@ -30,6 +31,9 @@ constexpr int GT_PITCH3 = 132;   // W3 rows: 128 + 4 pad
 __global__ __launch_bounds__(256, 2) void edge_gate_kernel(GateArgs p) {
     __shared__ __attribute__((aligned(16))) float sW0[128 * GT_PITCH];
     __shared__ __attribute__((aligned(16))) float sW3[32 * GT_PITCH3];
+    // wave buffers of the fused aggregation (gate_agg.h); with them a CU holds two blocks instead of three, which this MFMA-bound
+    // kernel does not feel (measured: 96 vs 89 TFLOP/s charged time with the LDS merely reserved)
+    __shared__ __attribute__((aligned(16))) char sAgg[4 * AG_WAVE_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, hi = lane >> 5;
 
@@ -113,7 +117,10 @@ __global__ __launch_bounds__(256, 2) void edge_gate_kernel(GateArgs p) {
         }
         sum += __shfl_xor(sum, 32);
         const float inv = 1.f / sum;
-        if (valid) {
+        if (p.agg) {                           // fused max aggregation: the gated rows are never stored (gate_agg.h)
+            gate_aggregate_max(sAgg + wave * AG_WAVE_BYTES, lg, inv, p.node + (size_t)dn * p.ld_node + p.v_off + h * 32 + 4 * hi, valid ? sn : -1,
+                               li, hi, lane, h, p.agg, p.ld_agg);
+        } else if (valid) {
             // lane's channels: m = 8*r4 + 4*hi + c  (crow32), c = 0..3 -> one float4 per r4
             const float* vrow = p.node + (size_t)dn * p.ld_node + p.v_off + h * 32 + 4 * hi;
             float* grow = p.gated + (size_t)e * 256 + h * 32 + 4 * hi;
@@ -192,6 +199,7 @@ int launch_edge_gate_generic(const GateArgs& a, int n_heads, int dk, int dox, hi
 
 int launch_edge_gate(const GateArgs& a, hipStream_t s) {
     if (a.n_edges <= 0) return 0;
+    if (a.agg && (!a.row_map || a.prob || (a.ld_agg & 3))) return fail(-1, "edge_gate: the fused aggregation needs the 32-edges-per-wave row map and no prob tap");
     if ((a.ld_node & 3) || (a.gq_off & 3) || (a.v_off & 3)) return fail(-1, "edge_gate: ld_node/gq_off/v_off must be multiples of 4");
     const int n_groups = a.row_map ? 2 * ((a.n_edges + 31) / 32) : (a.n_edges + 15) / 16;
     // persistent: 3 blocks per CU are resident (51.7 KB LDS each); every block stages the weights once

@@ -13,32 +13,22 @@
 // The bf16 planes of W0k / W3 are made by the block itself from the fp32 weights (they are tiny).
 // One wave = 32 rows = 4 edges per step (72 MFMAs in split-bf16, against 192 64-cycle fp32 ones).
 #include "gemm_core.h"
+#include "gate_agg.h"
 #include "kernels.h"
 
 namespace vlsat {
 
 namespace {
 
-// max into a float cell from concurrent waves: for the integer order of IEEE bit patterns a non-negative value wins by signed
-// max, a negative one by unsigned min (the cell starts at -inf or at another run's result); exact and order-independent
-__device__ __forceinline__ void atomic_max_f32(float* p, float x) {
-    const int b = __float_as_int(x);
-    if (b >= 0) atomicMax(reinterpret_cast<int*>(p), b);
-    else atomicMin(reinterpret_cast<unsigned*>(p), (unsigned)b);
-}
-
 constexpr int GB_P0 = 144;      // W0k plane row pitch (64 bf16 + 16 B)
 constexpr int GB_P3 = 264;      // W3 plane row pitch (128 bf16 + 8 B: the 32 rows of a ds_read_b64 land on 32 different bank pairs)
 
 // KS: format of kproj -- 0 fp32, 1 split-pair words, 2 half rows (bf16; TERMS = 1)
 template <int TERMS, int KS>
-__global__ __launch_bounds__(256, 2) void edge_gate_bf16_kernel(GateArgs p) {
+__global__ __launch_bounds__(256, TERMS == 1 ? 4 : 2) void edge_gate_bf16_kernel(GateArgs p) {
     constexpr int PL = TERMS == 1 ? 1 : 2;
     constexpr int W0B = 128 * GB_P0, W3B = 32 * GB_P3;
-    // fused aggregation: per wave a [32 rows][16 channels] fp32 transposition buffer (row pitch 20 floats: the eight rows of a
-    // ds_write_b128 lane group land on eight different 4-bank groups) and the 32 rows' source nodes
-    constexpr int AG_PITCH = 20, AG_WAVE = 32 * AG_PITCH * 4 + 32 * 4;
-    __shared__ __attribute__((aligned(16))) char smem[PL * (W0B + W3B) + 4 * AG_WAVE];
+    __shared__ __attribute__((aligned(16))) char smem[PL * (W0B + W3B) + 4 * AG_WAVE_BYTES];     // + the fused aggregation's wave buffers (gate_agg.h)
     char* sW0 = smem;                    // [PL][128][144]
     char* sW3 = smem + PL * W0B;         // [PL][32][272]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -171,46 +161,9 @@ __global__ __launch_bounds__(256, 2) void edge_gate_bf16_kernel(GateArgs p) {
         }
         sum += __shfl_xor(sum, 32);
         const float inv = 1.f / sum;
-        if (p.agg) {
-            // ---- gated = prob * value, then max over the rows of each source node (Aggre_Index, GCN_AGGR = max) without ever
-            //      storing the gated rows: two passes of 16 channels through the wave's LDS buffer; lane (channel lc, row group q)
-            //      walks rows 8 q .. 8 q + 7 (edge lists are source-major: one or two runs), and every finished run goes to
-            //      agg[src, h*32 + channel] with an integer-ordered atomic max (exact, order-independent) ----
-            float* tb = reinterpret_cast<float*>(smem + PL * (W0B + W3B) + wave * AG_WAVE);
-            int* sb = reinterpret_cast<int*>(tb + 32 * AG_PITCH);
-            const float* vrow = p.node + (size_t)dn * p.ld_node + p.v_off + h * 32 + 4 * hi;
-            if (hi == 0) sb[li] = valid ? sn : -1;
-            const int lc = lane & 15, q = lane >> 4;
-#pragma unroll
-            for (int pass = 0; pass < 2; ++pass) {
-#pragma unroll
-                for (int rr = 0; rr < 2; ++rr) {
-                    const int r4 = 2 * pass + rr;
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(vrow + 8 * r4);
-                    f32x4 o;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) o[c] = lg[r4 * 4 + c] * inv * v[c];
-                    *reinterpret_cast<f32x4*>(tb + li * AG_PITCH + 8 * rr + 4 * hi) = o;
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // (wave-private buffer: program order + this wait)
-                int cur = -1;
-                float acc = 0.f;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int row = 8 * q + j;
-                    const int sj = sb[row];
-                    const float x = tb[row * AG_PITCH + lc];
-                    if (sj != cur) {
-                        if (cur >= 0) atomic_max_f32(p.agg + (size_t)cur * p.ld_agg + h * 32 + 16 * pass + lc, acc);
-                        cur = sj;
-                        acc = x;
-                    } else {
-                        acc = fmaxf(acc, x);
-                    }
-                }
-                if (cur >= 0) atomic_max_f32(p.agg + (size_t)cur * p.ld_agg + h * 32 + 16 * pass + lc, acc);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // (the reads are done before the next pass overwrites)
-            }
+        if (p.agg) {                       // fused max aggregation: the gated rows are never stored (gate_agg.h)
+            gate_aggregate_max(smem + PL * (W0B + W3B) + wave * AG_WAVE_BYTES, lg, inv, p.node + (size_t)dn * p.ld_node + p.v_off + h * 32 + 4 * hi,
+                               valid ? sn : -1, li, hi, lane, h, p.agg, p.ld_agg);
         } else if (valid) {
             const float* vrow = p.node + (size_t)dn * p.ld_node + p.v_off + h * 32 + 4 * hi;
             float* grow = p.gated + (size_t)e * 256 + h * 32 + 4 * hi;
@@ -238,7 +191,9 @@ int launch_edge_gate_bf16(const GateArgs& a, int terms, int kproj_split, hipStre
     if (terms != 1 && terms != 3) return fail(-1, "edge_gate_bf16: terms must be 1 or 3");
     if (a.agg && (!a.row_map || a.prob || (a.ld_agg & 3))) return fail(-1, "edge_gate_bf16: the fused aggregation needs the 32-edges-per-wave row map and no prob tap");
     const int n_groups = a.row_map ? 2 * ((a.n_edges + 31) / 32) : (a.n_edges + 15) / 16;
-    const int cap = a.grid_cap > 0 ? a.grid_cap : 768;            // persistent grid (weights staged once per block)
+    // persistent grid (weights staged once per block): three blocks per CU; the single-rounding kernel holds four (128 VGPRs,
+    // 37 KB of LDS) and 1024 measured 0.7 % faster per step than 768 or 1280 with the aggregation fused in
+    const int cap = a.grid_cap > 0 ? a.grid_cap : terms == 1 ? 1024 : 768;
     const int grid = n_groups < cap ? n_groups : cap;
 #define VLSAT_GB(T, K) hipLaunchKernelGGL((edge_gate_bf16_kernel<T, K>), dim3(grid), dim3(256), 0, s, a)
     if (kproj_split == 2 && terms != 1) return fail(-1, "edge_gate_bf16: half-row kproj needs terms = 1");

@@ -96,7 +96,7 @@ struct vlsat_ctx {
     float* sk_ws[2] = {nullptr, nullptr};    // its workspace + counters: [0] launch stream, [1] the side stream of two-stream plans
     unsigned* sk_cnt[2] = {nullptr, nullptr};
     int flash_dma = 1;                       // half-row bf16 edge attention: K / V by LDS-direct loads, one tile ahead (0: register-staged, round 3; 3 | 4: rings of three / four tile buffers)
-    int gate_fuse_agg = 1;                   // bf16 gate at the default head geometry, GCN_AGGR = max: aggregation fused into the gate (vlsat_debug_option "gate_fuse_agg")
+    int gate_fuse_agg = 1;                   // gate at the default head geometry, GCN_AGGR = max: aggregation fused into the gate kernel: 0 never, 1 the bf16 modes, 2 fp32 as well ("gate_fuse_agg")
     int flash_ablate = 0;                    // timing experiments on the bf16 edge attention (FlashSplit::ablate; results are garbage)
     int flash_pv_terms = 3;                  // split-bf16 edge attention: MFMAs per P.V product (3, or 2 = probabilities single-rounded)
     int ln_resid = 1;                        // split-pair mode: post-attention residual added in the LayerNorm kernel

@@ -75,7 +75,7 @@ int vlsat_debug_option(vlsat_handle h, const char* name, int32_t value) {
     else if (k == "half_fmt") h->half_fmt = value != 0;
     else if (k == "ln_resid") h->ln_resid = value != 0;
     else if (k == "flash_dma") h->flash_dma = (value == 3 || value == 4) ? value : value != 0;
-    else if (k == "gate_fuse_agg") h->gate_fuse_agg = value != 0;
+    else if (k == "gate_fuse_agg") h->gate_fuse_agg = value < 0 ? 0 : value > 2 ? 2 : value;
     else if (k == "flash_ablate") h->flash_ablate = value;
     else if (k == "flash_pv_terms") h->flash_pv_terms = value == 2 ? 2 : 3;
     else if (k == "flash_bf16") h->flash_bf16 = value != 0;

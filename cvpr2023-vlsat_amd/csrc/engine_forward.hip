@@ -172,9 +172,12 @@ int gcn_block(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const GcnW& w, float
         g.src = p->d_src; g.dst = p->d_dst; g.w0k = w.w0k; g.w3 = w.w3; g.b3 = w.b3; g.gated = sc.G;
         g.prob = p->prob; g.n_edges = E; g.use_edge = h->d.use_gcn_edge; g.grid_cap = h->gate_grid; g.row_map = h->gate_row_map;
         const double dk = D / h->H, dox = A / h->H;
-        // bf16 gate at 8 x (64, 32), max aggregation, no debug tap: the aggregation happens inside the gate kernel (no [E, 256]
+        // the gate at 8 x (64, 32) in any precision, max aggregation, no debug tap: the aggregation happens inside the gate kernel (no [E, 256]
         // tensor of gated messages, no aggregate launch); the start values go in first
-        fused_agg = gate16 && !gate16h && !(h->gate_heads_mfma == 2) && h->gate_fuse_agg && h->d.gcn_aggr == 0 && !g.prob && h->debug_stop < 0 && h->gate_row_map && E > 0;
+        const bool shipped_kernel = !gate16h && default_heads(h) && !(h->gate_heads_mfma == 2 && !gate16);     // edge_gate.hip / edge_gate_bf16.hip
+        // (fp32: measured neutral -- 2196-2201 vs 2195 scenes/s -- and it moves waiting time into the GEMM class of the two-stream
+        //  profile, so the exact-fp32 mode keeps the separate aggregate launch unless "gate_fuse_agg" is 2)
+        fused_agg = shipped_kernel && (h->gate_fuse_agg == 2 || (h->gate_fuse_agg == 1 && gate16)) && h->d.gcn_aggr == 0 && !g.prob && h->debug_stop < 0 && h->gate_row_map && E > 0;
         if (fused_agg) {
             Scope scope(h, s, PC_AGGREGATE, 0);
             RUN(launch_agg_init(p->d_rowptr, N, A, x + D, LDX, s));

@@ -1,0 +1,64 @@
+// Max aggregation fused into the edge-gate kernels (Aggre_Index with MODEL.GCN_AGGR = max, reference network_util.py:64-73, applied
+// to the gated messages of network_MMG.py:104): shared by edge_gate.hip and edge_gate_bf16.hip, whose waves own 32 consecutive
+// edges of one head with lane (li = edge row, hi) holding the channels 8 r4 + 4 hi + c of the 32.
+#pragma once
+#include "common.h"
+
+namespace vlsat {
+
+// max into a float cell from concurrent waves: in the integer order of IEEE bit patterns a non-negative value wins by signed max,
+// a negative one by unsigned min (the cell starts at -inf or holds another run's result); exact and order-independent
+__device__ __forceinline__ void atomic_max_f32(float* p, float x) {
+    const int b = __float_as_int(x);
+    if (b >= 0) atomicMax(reinterpret_cast<int*>(p), b);
+    else atomicMin(reinterpret_cast<unsigned*>(p), (unsigned)b);
+}
+
+// per wave: a [32 rows][16 channels] fp32 transposition buffer (row pitch 20 floats: the eight rows of a ds_write_b128 lane group
+// land on eight different 4-bank groups) and the 32 rows' source nodes
+constexpr int AG_PITCH = 20, AG_WAVE_BYTES = 32 * AG_PITCH * 4 + 32 * 4;
+
+// gated = prob * value for this lane's 16 channels (lg[r] * inv are the probabilities, vrow the value row of the edge's target),
+// then the maximum over the rows of each source node WITHOUT storing the gated rows: two passes of 16 channels through the wave's
+// LDS buffer `wbuf`; lane (channel lc, row group q) walks rows 8 q .. 8 q + 7 (edge lists are source-major: one or two runs per
+// group, but any order is handled) and every finished run goes to agg[src, h*32 + channel] with atomic_max_f32.  sn < 0 marks a
+// row past the edge list.
+__device__ __forceinline__ void gate_aggregate_max(char* wbuf, const f32x16& lg, float inv, const float* vrow, int sn, int li, int hi,
+                                                   int lane, int h, float* agg, int ld_agg) {
+    float* tb = reinterpret_cast<float*>(wbuf);
+    int* sb = reinterpret_cast<int*>(tb + 32 * AG_PITCH);
+    if (hi == 0) sb[li] = sn;
+    const int lc = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int r4 = 2 * pass + rr;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(vrow + 8 * r4);
+            f32x4 o;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[c] = lg[r4 * 4 + c] * inv * v[c];
+            *reinterpret_cast<f32x4*>(tb + li * AG_PITCH + 8 * rr + 4 * hi) = o;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // (wave-private buffer: program order + this wait)
+        int cur = -1;
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = 8 * q + j;
+            const int sj = sb[row];
+            const float x = tb[row * AG_PITCH + lc];
+            if (sj != cur) {
+                if (cur >= 0) atomic_max_f32(agg + (size_t)cur * ld_agg + h * 32 + 16 * pass + lc, acc);
+                cur = sj;
+                acc = x;
+            } else {
+                acc = fmaxf(acc, x);
+            }
+        }
+        if (cur >= 0) atomic_max_f32(agg + (size_t)cur * ld_agg + h * 32 + 16 * pass + lc, acc);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // (the reads are done before the next pass overwrites)
+    }
+}
+
+}  // namespace vlsat

@@ -363,6 +363,8 @@ int vlsat_debug_gemm_clock_probe(int64_t* buf);
  * twice the error on weights that make the attention peaked -- left at 3);
  * "gemm_splitk" 0|1: small GEMM launches on the split-K kernel; "node_attn_split" n: node attention with sixteen lanes per
  * query for plans with fewer than n one-query-per-lane waves;
+ * "gate_fuse_agg" 0|1|2: MODEL.GCN_AGGR = max at 8 heads x 256: the aggregation by source node happens inside the gate kernel (no [E, 256]
+ * tensor of gated messages, no aggregate launch; bit-identical results) -- 1 (default) in the bf16 modes, 2 in exact fp32 too, 0 never;
  * "flash_dma" 0|1|3|4: half-row bf16 edge attention at head dim 64, K / V tiles by LDS-direct loads (1, default: two tile buffers,
  * one tile ahead, four blocks per CU; 3 / 4: rings of three / four buffers; 0: the register-staged kernel of round 3);
  * "flash_ablate" bits: timing experiments on the edge attention, GARBAGE results (1: no K/V loads after the first tile, 2: no LDS

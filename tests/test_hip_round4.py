@@ -38,3 +38,33 @@ def test_auto_precision_picks_the_fastest_mode_inside_the_tolerance(scale, want)
     err = max(float((g[:k] - x.float()).abs().max()) for g, x, k in zip(got, ref, (n, n, e, e)))
     assert err < 1e-2, (r, err)
     m.close()
+
+
+@pytest.mark.parametrize("mode,fuse", [("bf16x3", 1), ("bf16_mixed", 1), ("fp32", 2)])
+def test_fused_gate_aggregation_is_bit_identical(mode, fuse):
+    """Aggre_Index(max) inside the gate kernel (integer-ordered atomic max over the rows of a source node, csrc/gate_agg.h)
+    against the separate CSR aggregate kernel: the same fp32 values, so the same maxima bit for bit -- on an UNSORTED edge list
+    with duplicate edges, self loops and nodes without any out-edge (empty segment -> 0), two scenes of different size."""
+    cfg = VLSATConfig(N_LAYERS=2)
+    w = synth.make_weights(cfg)
+    g = torch.Generator().manual_seed(7)
+    scenes = [synth.make_scene(13, 64, 5000), synth.make_scene(31, 64, 5001)]
+    b = synth.collate(scenes)
+    parts, off = [], 0
+    for n in (13, 31):                       # random pairs inside each scene; the last two nodes of a scene never are a source
+        e = 5 * n + 3
+        src = torch.randint(0, n - 2, (e,), generator=g) + off
+        dst = torch.randint(0, n, (e,), generator=g) + off
+        parts.append(torch.stack([src, dst]))
+        off += n
+    ei = torch.cat(parts, 1)
+    d = {k: torch.from_numpy(v).to(DEV) for k, v in b.items() if k != "edge_indices"}
+    m = _model(cfg, w).set_gemm_precision(mode)
+    outs = {}
+    for f in (0, fuse):
+        m.debug_option("gate_fuse_agg", f)
+        outs[f] = [o.clone() for o in m(d["obj_points"], d["obj_2d_feats"], ei.to(DEV), d["descriptor"], d["batch_ids"])]
+    torch.cuda.synchronize()
+    for a, c in zip(outs[0], outs[fuse]):
+        assert torch.isfinite(a).all() and torch.equal(a, c)
+    m.close()
