@@ -224,8 +224,8 @@ static GemmArgs tail_of(const GemmArgs& a, int row0) {
 }
 
 template <int BM, int BN>
-static int run_tiled(const GemmArgs& a, hipStream_t s) {
-    const int G = slots();
+static int run_tiled(const GemmArgs& a, hipStream_t s, int slot_mult2 = 2) {
+    const int G = slots() / 2 * slot_mult2;            // resident block slots the grid may use (default: two per CU)
     const int nbm = (a.M + BM - 1) / BM, nbn = (a.N + BN - 1) / BN;
     const long T = (long)nbm * nbn;
     if (T <= G) {                                   // one round: grid = tiles (rounded up to 8)
@@ -319,6 +319,9 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
         case 2: return run_tiled<128, 64>(a, s);
         case 3: return run_tiled<64, 128>(a, s);
         case 4: return run_tiled<64, 64>(a, s);
+        case 5: return run_tiled<64, 64>(a, s, 4);        // (experiment: four 64 x 64 blocks per CU)
+        case 6: return run_tiled<64, 128>(a, s, 3);       // (experiment: three 64 x 128 blocks per CU)
+        case 7: return run_tiled<64, 64>(a, s, 3);
         default: break;
     }
     // split-bf16 node-row launches with 1024..2048 output columns (self-attention QKV, cross-attention KV at the bench batch):
@@ -331,6 +334,10 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
     if (a.N > 64 && blocks(128, 128) >= G) return run_tiled<128, 128>(a, s);
     if (a.N <= 64 && blocks(128, 64) >= G) return run_tiled<128, 64>(a, s);
     if (a.N > 64 && blocks(64, 128) >= G) return run_tiled<64, 128>(a, s);
+    // exact fp32 on 64 x 64 tiles over more than one round of two blocks per CU (node rows of a batch: QKV 960 tiles, KV 640,
+    // the node-side projection 2080): the kernel holds 80 VGPRs and 32 KB of LDS, so four blocks fit a CU and these latency-bound
+    // launches take the wider grid -- KV 42.6 -> 31.0 us, QKV 46.5 -> 39.9, wnode 90.3 -> 78.9 (tools/gemm_tile_sweep.py, round 4)
+    if (a.prec == 0 && blocks(64, 64) > G) return run_tiled<64, 64>(a, s, 4);
     return run_tiled<64, 64>(a, s);
 }
 

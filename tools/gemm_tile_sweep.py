@@ -16,7 +16,8 @@ from vlsat_amd import lib as L  # noqa: E402
 SHAPES = [("self qkv", 1536, 512, False), ("cross kv", 1024, 512, False), ("q / out-proj(+resid)", 512, 512, True),
           ("wnode", 3328, 512, False), ("prop.0", 768, 768, False), ("prop.2", 512, 768, False), ("mlp_3d", 504, 768, False),
           ("adapter fc1", 256, 512, False), ("obj head", 160, 512, False)]
-TILES = [("auto", 0, False), ("auto+splitk", 0, True), ("128x128", 1, False), ("128x64", 2, False), ("64x128", 3, False), ("64x64", 4, False)]
+TILES = [("auto", 0, False), ("auto+splitk", 0, True), ("128x128", 1, False), ("128x64", 2, False), ("64x128", 3, False), ("64x64", 4, False),
+         ("64x64 x4/CU", 5, False), ("64x128 x3/CU", 6, False), ("64x64 x3/CU", 7, False)]
 
 
 def main():
