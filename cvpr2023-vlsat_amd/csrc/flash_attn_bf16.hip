@@ -37,6 +37,11 @@ constexpr int FB_VSUB = FB_KV * 32 + 128;                     // 2176: one [64 k
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
+template <int N> __device__ __forceinline__ void fb_wait_vm() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 __device__ __forceinline__ void split4(const f32x4& x, bf16x4& hi, bf16x4& lo) {
     hi = __builtin_convertvector(x, bf16x4);
     lo = __builtin_convertvector(x - __builtin_convertvector(hi, f32x4), bf16x4);
@@ -105,8 +110,13 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bf16_kernel(
     constexpr int FB_VPLANE = NSUB * FB_VSUB;
     constexpr int FB_OPITCH = FB_D + 4;            // floats per query row of the output transpose
     constexpr bool DMA = RING != 0;           // RING: tile buffers of the LDS-direct K/V ring (0: register-staged double buffer)
-    static_assert(!DMA || (TERMS == 1 && IO == 2 && TR && FB_D == 64), "LDS-direct K/V staging: half rows, single rounding, head dim 64");
-    constexpr int BUF = DMA ? FB_KV * 128 + FB_VPLANE : PL * (FB_KPLANE + FB_VPLANE);
+    static_assert(!DMA || (TERMS == 1 && IO == 2 && TR), "LDS-direct K/V staging: half rows, single rounding");
+    // (DMA) K image: 64 rows of ROWB = 2 FB_D bytes, unpadded (an LDS-direct load writes lane-linear), 16-byte chunks XOR-swizzled with
+    // KSWZ(row) on the global side and on the fragment reads: 64-byte rows (row >> 2) & 3, 128-byte rows (row >> 1) & 7, 256-byte rows row & 15
+    constexpr int ROWB = 2 * FB_D, CPR = ROWB / 16, RPI = 1024 / ROWB;          // bytes per K row, chunks per row, rows per load instruction
+    constexpr int KI = FB_KV / RPI / 4, VI = 2 * NSUB / 4, LPT = KI + VI;      // load instructions per wave and tile: K, V, both
+    constexpr int KBYTES = FB_KV * ROWB;
+    constexpr int BUF = DMA ? KBYTES + FB_VPLANE : PL * (FB_KPLANE + FB_VPLANE);
     constexpr int NBUF = DMA ? RING : 2, LA = NBUF - 1;           // (DMA) tiles of look-ahead
     constexpr int SMEM = NBUF * BUF > 4 * 32 * FB_OPITCH * 4 ? NBUF * BUF : 4 * 32 * FB_OPITCH * 4;
     __shared__ __attribute__((aligned(16))) char smem[SMEM];
@@ -197,30 +207,37 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bf16_kernel(
     // tile is handled by masking, below)
     const int kt0 = kr.x >> 1, kt1 = (kr.y + 1) >> 1;
     const int key_lo = kr.x * 32, key_hi = kr.y * 32 < n_tok ? kr.y * 32 : n_tok;       // keys [key_lo, key_hi) belong to this block
-    // ---- LDS-direct staging (DMA): one tile = 4 loads per wave -- K rows 16 w .. 16 w + 15 (two instructions of 8 rows x 128 B),
-    //      V sub-tile w (two instructions of 32 keys x 32 B).  The buffer descriptors span THIS scene's rows only, so keys past
-    //      the scene's last token read as zeros (their scores are masked below) ----
+    // ---- LDS-direct staging (DMA): one tile = LPT loads per wave -- K rows in instructions of RPI rows (a wave takes KI consecutive
+    //      ones), V in instructions of 32 keys x 32 B of one [64 keys][16 d] sub-tile (a wave takes VI consecutive halves).  The buffer
+    //      descriptors span THIS scene's rows only, so keys past the scene's last token read as zeros (their scores are masked below) ----
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(K + (size_t)row_base * ldkv), 0, DMA ? (int)(unsigned)((size_t)n_tok * ldkv * 4) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(V + (size_t)row_base * ldkv), 0, DMA ? (int)(unsigned)((size_t)n_tok * ldkv * 4) : 0, 0x00020000);
     const unsigned ld4 = (unsigned)ldkv * 4u;
-    const int dk_row = wave_u * 16 + (lane >> 3);                                     // K row of the first instruction (+8: the second)
-    const unsigned vK0 = (unsigned)dk_row * ld4 + (unsigned)col0 * 2u + (unsigned)(((lane & 7) ^ ((dk_row >> 1) & 7)) << 4);
-    const unsigned vK1 = (unsigned)(dk_row + 8) * ld4 + (unsigned)col0 * 2u + (unsigned)(((lane & 7) ^ (((dk_row + 8) >> 1) & 7)) << 4);
-    const unsigned vV0 = (unsigned)(lane >> 1) * ld4 + (unsigned)col0 * 2u + (unsigned)wave_u * 32u + (unsigned)(lane & 1) * 16u;   // keys 0..31 of sub-tile w
+    auto kswz_of = [](int row) { return FB_D == 32 ? (row >> 2) & 3 : FB_D == 64 ? (row >> 1) & 7 : row & 15; };
+    unsigned vK[4];                                   // (KI <= 4 used; an array bound that depends on the template arguments makes hipcc drop every host stub of this template without a diagnostic)
+#pragma unroll
+    for (int j = 0; j < KI; ++j) {
+        const int row = (wave_u * KI + j) * RPI + lane / CPR;
+        vK[j] = (unsigned)row * ld4 + (unsigned)col0 * 2u + (unsigned)(((lane % CPR) ^ kswz_of(row)) << 4);
+    }
+    const unsigned vV0 = (unsigned)(lane >> 1) * ld4 + (unsigned)col0 * 2u + (unsigned)(lane & 1) * 16u;       // key lane / 2 of a 32-key half, 16-byte half lane & 1
     auto dma_tile = [&](int kv0, char* buf) {
         const unsigned s0 = (unsigned)kv0 * ld4;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rK, buf + wave_u * 2048, 16, vK0, s0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rK, buf + wave_u * 2048 + 1024, 16, vK1, s0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rV, buf + FB_KV * 128 + wave_u * FB_VSUB, 16, vV0, s0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rV, buf + FB_KV * 128 + wave_u * FB_VSUB + 1024, 16, vV0, s0 + 32u * ld4, 0, 0);
+#pragma unroll
+        for (int j = 0; j < KI; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rK, buf + (wave_u * KI + j) * 1024, 16, vK[j], s0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < VI; ++j) {
+            const int idx = wave_u * VI + j, sub = idx >> 1, kh = idx & 1;                 // sub-tile, 32-key half of it
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rV, buf + KBYTES + sub * FB_VSUB + kh * 1024, 16, vV0, s0 + (unsigned)kh * 32u * ld4 + (unsigned)sub * 32u, 0, 0);
+        }
     };
-    // counted wait: everything but the newest `n` tiles (4 loads each) has landed
+    // counted wait: everything but the newest `n` tiles (LPT loads each) has landed
     auto wait_tiles = [&](int n) {
-        if (n <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (n == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else if (n == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        if (n <= 0) fb_wait_vm<0>();
+        else if (n == 1) fb_wait_vm<LPT>();
+        else if (n == 2) fb_wait_vm<2 * LPT>();
+        else fb_wait_vm<3 * LPT>();
     };
     if (DMA) {
         int issued = 0;
@@ -240,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bf16_kernel(
     int ring = 0;                                          // (DMA) buffer of tile kt
     for (int kt = kt0; kt < kt1; ++kt) {
         const char* sK = smem + (DMA ? ring : (kt & 1)) * BUF;
-        const char* sV = sK + (DMA ? FB_KV * 128 : PL * FB_KPLANE);
+        const char* sV = sK + (DMA ? KBYTES : PL * FB_KPLANE);
         const bool more = kt + 1 < kt1;
         if (DMA) {
             // tile kt + LA goes into the buffer tile kt - 1 was read from: every wave passed the barrier that ended iteration kt - 1
@@ -255,12 +272,12 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bf16_kernel(
             {
                 // the two 32-key blocks alternate, so consecutive MFMAs never wait for each other's accumulator
                 const char* kp = sK + li * FB_KPITCH + 16 * hi;
-                const char* kd = sK + li * 128;                       // (DMA) row li; rows li and li + 32 share the swizzle
-                const int kswz = (li >> 1) & 7;
+                const char* kd = sK + li * ROWB;                      // (DMA) row li; rows li and li + 32 share the swizzle
+                const int kswz = kswz_of(li);
 #pragma unroll
                 for (int ks = 0; ks < NKS; ++ks) {
                     const bf16x8 kh0 = *reinterpret_cast<const bf16x8*>(DMA ? kd + (((hi + 2 * ks) ^ kswz) << 4) : kp + 32 * ks);
-                    const bf16x8 kh1 = *reinterpret_cast<const bf16x8*>(DMA ? kd + 32 * 128 + (((hi + 2 * ks) ^ kswz) << 4) : kp + 32 * FB_KPITCH + 32 * ks);
+                    const bf16x8 kh1 = *reinterpret_cast<const bf16x8*>(DMA ? kd + 32 * ROWB + (((hi + 2 * ks) ^ kswz) << 4) : kp + 32 * FB_KPITCH + 32 * ks);
                     if (PL == 2) {
                         const bf16x8 kl0 = *reinterpret_cast<const bf16x8*>(kp + FB_KPLANE + 32 * ks);
                         const bf16x8 kl1 = *reinterpret_cast<const bf16x8*>(kp + FB_KPLANE + 32 * FB_KPITCH + 32 * ks);
@@ -438,7 +455,10 @@ int launch_flash_attn_bf16(const float* Q, int ldq, const float* K, const float*
 #define VLSAT_FA(T, R, S) hipLaunchKernelGGL((flash_attn_bf16_kernel<T, R, S>), dim3(n_tiles), dim3(256), 0, s, Q, K, V, O, ldq, ldkv, ldo, tiles, n_tiles, scale_log2e, sp)
 #define VLSAT_FAD(T, S, P, D) hipLaunchKernelGGL((flash_attn_bf16_kernel<T, true, S, P, D>), dim3(n_tiles), dim3(256), 0, s, Q, K, V, O, ldq, ldkv, ldo, tiles, n_tiles, scale_log2e, sp)
     if (FB_D != 64) {          // 16 / 4 heads: the formats the forward uses (the transpose-read path; split-bf16 only at 32)
-        if (FB_D == 32) {
+        if (io_split == 2 && use_tr != 2) {          // half rows: LDS-direct K/V staging, one tile ahead
+            if (FB_D == 32) hipLaunchKernelGGL((flash_attn_bf16_kernel<1, true, 2, 3, 32, 2>), dim3(n_tiles), dim3(256), 0, s, Q, K, V, O, ldq, ldkv, ldo, tiles, n_tiles, scale_log2e, sp);
+            else hipLaunchKernelGGL((flash_attn_bf16_kernel<1, true, 2, 3, 128, 2>), dim3(n_tiles), dim3(256), 0, s, Q, K, V, O, ldq, ldkv, ldo, tiles, n_tiles, scale_log2e, sp);
+        } else if (FB_D == 32) {
             if (io_split == 2) VLSAT_FAD(1, 2, 3, 32);
             else if (terms == 3 && pv_terms == 2) VLSAT_FAD(3, 1, 2, 32);
             else if (terms == 3) VLSAT_FAD(3, 1, 3, 32);
