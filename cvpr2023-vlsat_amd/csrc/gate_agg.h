@@ -16,7 +16,10 @@ __device__ __forceinline__ void atomic_max_f32(float* p, float x) {
 
 // per wave: a [32 rows][16 channels] fp32 transposition buffer (row pitch 20 floats: the eight rows of a ds_write_b128 lane group
 // land on eight different 4-bank groups) and the 32 rows' source nodes
-constexpr int AG_PITCH = 20, AG_WAVE_BYTES = 32 * AG_PITCH * 4 + 32 * 4;
+// (each group of eight rows is shifted by 16 more floats, so the two row groups that share an LDS cycle of the column reads below sit
+//  on disjoint halves of the 32 banks)
+constexpr int AG_PITCH = 20, AG_FLOATS = 32 * AG_PITCH + 3 * 16, AG_WAVE_BYTES = AG_FLOATS * 4 + 32 * 4;
+__device__ __forceinline__ int ag_row(int row) { return row * AG_PITCH + (row >> 3) * 16; }
 
 // gated = prob * value for this lane's 16 channels (lg[r] * inv are the probabilities, vrow the value row of the edge's target),
 // then the maximum over the rows of each source node WITHOUT storing the gated rows: two passes of 16 channels through the wave's
@@ -26,9 +29,13 @@ constexpr int AG_PITCH = 20, AG_WAVE_BYTES = 32 * AG_PITCH * 4 + 32 * 4;
 __device__ __forceinline__ void gate_aggregate_max(char* wbuf, const f32x16& lg, float inv, const float* vrow, int sn, int li, int hi,
                                                    int lane, int h, float* agg, int ld_agg) {
     float* tb = reinterpret_cast<float*>(wbuf);
-    int* sb = reinterpret_cast<int*>(tb + 32 * AG_PITCH);
+    int* sb = reinterpret_cast<int*>(tb + AG_FLOATS);
     if (hi == 0) sb[li] = sn;
     const int lc = lane & 15, q = lane >> 4;
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const i32x4 s03 = *reinterpret_cast<const i32x4*>(sb + 8 * q), s47 = *reinterpret_cast<const i32x4*>(sb + 8 * q + 4);   // sources of this lane's rows
+    const int srow[8] = {s03[0], s03[1], s03[2], s03[3], s47[0], s47[1], s47[2], s47[3]};
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
@@ -38,7 +45,7 @@ __device__ __forceinline__ void gate_aggregate_max(char* wbuf, const f32x16& lg,
             f32x4 o;
 #pragma unroll
             for (int c = 0; c < 4; ++c) o[c] = lg[r4 * 4 + c] * inv * v[c];
-            *reinterpret_cast<f32x4*>(tb + li * AG_PITCH + 8 * rr + 4 * hi) = o;
+            *reinterpret_cast<f32x4*>(tb + ag_row(li) + 8 * rr + 4 * hi) = o;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // (wave-private buffer: program order + this wait)
         int cur = -1;
@@ -46,8 +53,8 @@ __device__ __forceinline__ void gate_aggregate_max(char* wbuf, const f32x16& lg,
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int row = 8 * q + j;
-            const int sj = sb[row];
-            const float x = tb[row * AG_PITCH + lc];
+            const int sj = srow[j];
+            const float x = tb[ag_row(row) + lc];
             if (sj != cur) {
                 if (cur >= 0) atomic_max_f32(agg + (size_t)cur * ld_agg + h * 32 + 16 * pass + lc, acc);
                 cur = sj;
