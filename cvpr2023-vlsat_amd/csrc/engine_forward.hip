@@ -396,8 +396,7 @@ static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const fl
         RUN(launch_rowmax(out, h->C_pt, N, p->P, h->C_pt, p->F, 768, s));
     }
     if (tr && tr->mimic3d)                 // obj_feature[..., :512] (reference SGFN_MMG/model.py:291-292)
-        VLSAT_HIP_CHECK(hipMemcpy2DAsync(tr->mimic3d, 512 * sizeof(float), p->F, 768 * sizeof(float), 512 * sizeof(float), N,
-                                         hipMemcpyDeviceToDevice, s));
+        RUN(launch_copy_rows(tr->mimic3d, 512, p->F, 768, 512, (size_t)N, s));
     STAGE(1);
     // a-3 mlp_3d (+BN folded) + spatial tail -> X3[:, 0:512]
     RUN(gemm(h, s, G(p->F, 768, h->mlp_w, 768, p->X3, LDX, N, D - 8, h->mlp_b, ACT_RELU)));
@@ -427,7 +426,7 @@ static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const fl
             float* out = nullptr;
             RUN(stn_encoder(h, p, s, br ? h->stn_re2 : h->stn_re3, p->H1 + 64 * br, 128, (size_t)E, 1, br ? h->re2_w2 : h->re3_w2,
                             br ? h->re2_b2 : h->re3_b2, br ? h->re2_w3 : h->re3_w3, br ? h->re2_b3 : h->re3_b3, D, &out));
-            VLSAT_HIP_CHECK(hipMemcpyAsync(br ? p->E2 : p->E3, out, (size_t)E * D * sizeof(float), hipMemcpyDeviceToDevice, s));
+            RUN(launch_copy_rows(br ? p->E2 : p->E3, (size_t)D, out, (size_t)D, D, (size_t)E, s));
         }
     }
     STAGE(3);
@@ -438,8 +437,7 @@ static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const fl
         a.resid = f2d; a.ldr = D; a.resid_scale = 0.5f;
         RUN(gemm(h, t, a));
         if (tr && tr->mimic2d)             // the adapter's output before the MMG touches it (:312)
-            VLSAT_HIP_CHECK(hipMemcpy2DAsync(tr->mimic2d, 512 * sizeof(float), p->X2, LDX * sizeof(float), 512 * sizeof(float), N,
-                                             hipMemcpyDeviceToDevice, t));
+            RUN(launch_copy_rows(tr->mimic2d, 512, p->X2, (size_t)LDX, 512, (size_t)N, t));
     }
     STAGE(4);
     {   // a-7 distance bias

@@ -160,6 +160,10 @@ struct GateArgs {
 int launch_edge_gate(const GateArgs& a, hipStream_t s);
 // agg[n, 0:n_ch] = rowptr[n+1] > rowptr[n] ? -inf : 0   (start values of the fused max aggregation)
 int launch_agg_init(const int32_t* rowptr, int n_nodes, int n_ch, float* agg, int ld_agg, hipStream_t s);
+// p[0:n] = 0 with a kernel of the library (n % 4 == 0, p 16-byte aligned): the forward path does not use hipMemsetAsync
+int launch_zero_f32(float* p, size_t n, hipStream_t s);
+// dst[r, 0:cols] = src[r, 0:cols], r < rows (pitches in floats; 16-byte accesses when sizes and pointers allow)
+int launch_copy_rows(float* dst, size_t dst_ld, const float* src, size_t src_ld, int cols, size_t rows, hipStream_t s);
 // any head geometry (dk query / edge channels per head, dox output channels per head): plain VALU
 int launch_edge_gate_generic(const GateArgs& a, int n_heads, int dk, int dox, hipStream_t s);
 // the head geometries of MODEL.NUM_HEADS in {4, 8, 16} x DIM_ATTEN in {128, 256, 512} on the fp32 matrix cores

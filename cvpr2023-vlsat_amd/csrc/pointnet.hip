@@ -155,7 +155,7 @@ int launch_pointnet(const float* pts, int n_obj, int n_points, int cin, const fl
     int nsplit = (512 + n_obj - 1) / n_obj;
     if (nsplit > n_chunks) nsplit = n_chunks;
     if (nsplit < 1) nsplit = 1;
-    if (nsplit > 1) VLSAT_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)n_obj * n_out * sizeof(float), s));
+    if (nsplit > 1 && launch_zero_f32(out, (size_t)n_obj * n_out, s)) return -1;
 #define VLSAT_PN_CASE(CIN) \
     case CIN: hipLaunchKernelGGL(pointnet_kernel<CIN>, dim3(n_obj * nsplit), dim3(256), 0, s, pts, n_points, w1, b1, w2, \
                                  b2, w3, b3, n_out, out, nsplit); break;

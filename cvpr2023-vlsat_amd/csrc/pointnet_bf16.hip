@@ -236,7 +236,7 @@ int launch_pointnet_bf16(const float* pts, int n_obj, int n_points, int cin, con
     int nsplit = (256 + n_obj - 1) / n_obj;
     if (nsplit > n_chunks) nsplit = n_chunks;
     if (nsplit < 1) nsplit = 1;
-    if (nsplit > 1) VLSAT_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)n_obj * n_out * sizeof(float), s));
+    if (nsplit > 1 && launch_zero_f32(out, (size_t)n_obj * n_out, s)) return -1;
 #define VLSAT_PB(CIN, T) hipLaunchKernelGGL((pointnet_bf16_kernel<CIN, T>), dim3(n_obj * nsplit), dim3(512), 0, s, pts, n_points, w1, b1, \
                                             w2h, w2l, b2, w3h, w3l, b3, n_out, out, nsplit)
 #define VLSAT_PB_CASE(CIN) case CIN: if (terms == 3) VLSAT_PB(CIN, 3); else VLSAT_PB(CIN, 1); break;

@@ -221,6 +221,46 @@ int launch_agg_init(const int32_t* rowptr, int n_nodes, int n_ch, float* agg, in
     return 0;
 }
 
+// p[0:n] = 0 (n a multiple of 4, p 16-byte aligned).  The library's own fill: hipMemsetAsync, driven from several host threads
+// on several streams at once, was caught leaving foreign 8-byte patterns in the destination about once per 20 000 calls
+// (tools/replica_race_probe.py, profiles/r04_probes/replica_race.txt); nothing on the forward path uses it any more.
+__global__ __launch_bounds__(256) void zero_f32_kernel(float* __restrict__ p, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256)
+        reinterpret_cast<f32x4*>(p)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+int launch_zero_f32(float* p, size_t n, hipStream_t s) {
+    if (n == 0) return 0;
+    if ((n & 3) || (reinterpret_cast<uintptr_t>(p) & 15)) return fail(-1, "zero_f32: length must be a multiple of 4 floats and the pointer 16-byte aligned");
+    const size_t n4 = n / 4;
+    hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)std::min<size_t>((n4 + 255) / 256, 2048)), dim3(256), 0, s, p, n4);
+    VLSAT_LAUNCH_CHECK("zero_f32");
+    return 0;
+}
+
+// dst[r, 0:cols] = src[r, 0:cols] for r < rows (pitches in floats): the device-to-device copies of the forward path, for the
+// same reason as zero_f32 (no runtime blit on a path that several host threads drive at once).  V = 4: 16-byte accesses
+// (columns and pitches multiples of 4 floats, 16-byte aligned pointers), V = 1 otherwise.
+template <int V>
+__global__ __launch_bounds__(256) void copy_rows_kernel(float* __restrict__ dst, size_t dst_ld, const float* __restrict__ src, size_t src_ld,
+                                                        int cv, size_t nv) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (size_t)gridDim.x * 256) {
+        const size_t r = i / cv, c = (i % cv) * V;
+        if constexpr (V == 4) *reinterpret_cast<f32x4*>(dst + r * dst_ld + c) = *reinterpret_cast<const f32x4*>(src + r * src_ld + c);
+        else dst[r * dst_ld + c] = src[r * src_ld + c];
+    }
+}
+int launch_copy_rows(float* dst, size_t dst_ld, const float* src, size_t src_ld, int cols, size_t rows, hipStream_t s) {
+    if (rows == 0 || cols <= 0) return 0;
+    const bool v4 = !((cols & 3) || (dst_ld & 3) || (src_ld & 3) || ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15));
+    const int cv = v4 ? cols / 4 : cols;
+    const size_t nv = rows * (size_t)cv;
+    const dim3 grid((unsigned)std::min<size_t>((nv + 255) / 256, 4096));
+    if (v4) hipLaunchKernelGGL(copy_rows_kernel<4>, grid, dim3(256), 0, s, dst, dst_ld, src, src_ld, cv, nv);
+    else hipLaunchKernelGGL(copy_rows_kernel<1>, grid, dim3(256), 0, s, dst, dst_ld, src, src_ld, cv, nv);
+    VLSAT_LAUNCH_CHECK("copy_rows");
+    return 0;
+}
+
 int launch_aggregate(const float* gated, int n_ch, const int32_t* rowptr, const int32_t* order, int n_nodes,
                      int aggr, float* out, int ldo, int col0, hipStream_t s) {
     if (n_nodes <= 0) return 0;

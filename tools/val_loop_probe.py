@@ -74,7 +74,7 @@ def main():
     print(f"  one scene per call, reference-compatible loop (host rank lists)   {a.scenes / t:8.1f} scenes/s   {t / a.scenes * 1e3:6.3f} ms/scene")
     for k in [int(x) for x in a.workers.split(",")]:
         t, got = timed(lambda: EV.validation(model, one_per_call, device=dev, workers=k))
-        assert got == ref, "summaries differ"
+        assert got == ref, "summaries differ: " + ", ".join(f"{q} {ref[q]!r} vs {got[q]!r}" for q in ref if got[q] != ref[q])
         print(f"  one scene per call, counts on the device, {k} in flight              {a.scenes / t:8.1f} scenes/s   {t / a.scenes * 1e3:6.3f} ms/scene")
     t, got = timed(lambda: EV.validation(model, [big], device=dev, workers=1))
     worst = max(abs(got[k] - ref[k]) for k in ref)      # (batched and one-scene forwards differ in the last bits: a near-tie may move a rank)
