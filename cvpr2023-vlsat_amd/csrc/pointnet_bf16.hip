@@ -8,9 +8,10 @@
 //   conv1 (CIN->64)   VALU; the result goes to LDS as bf16 planes H1[128][64] (row pitch 144 B)
 //   conv2 (64->128)   A = H1 planes, B = W2 planes [128][64] staged once per point chunk; relu(.+b2) -> H2 planes
 //                     [128][128] (pitch 272 B), written over H1
-//   conv3 (128->768)  W3 plane slices [128 cols][32 k] (pitch 80 B) double-buffered through registers; epilogue relu +
-//                     running column max in registers
-// All LDS pitches are 16 B off a multiple of 128 B / 64 B: conflict-free ds_read_b128 fragment reads.
+//   conv3 (128->768)  W3 plane slices [128 cols][32 k] (unpadded 64-byte rows, 16-byte pieces XOR-swizzled with bits 2..3 of
+//                     the row: conflict-free for the staging stores AND the fragment reads) double-buffered through
+//                     registers; epilogue relu + running column max in registers
+// The H / W2 pitches are 16 B off a multiple of 128 B: conflict-free ds_read_b128 fragment reads.
 // The bf16 planes of W2 / W3 are the ones vlsat_set_gemm_precision makes for every GEMM weight.
 #include "gemm_core.h"
 #include "kernels.h"
@@ -21,7 +22,7 @@ namespace {
 
 constexpr int PB_M = 128;                 // points per chunk
 constexpr int PB_P1 = 144, PB_P2 = 272;   // row pitch (bytes) of the H1 / H2 planes
-constexpr int PB_PW2 = 144, PB_PW3 = 80;  // row pitch of the W2 planes [128][64] / W3 slices [128][32]
+constexpr int PB_PW2 = 144, PB_PW3 = 64;  // row pitch of the W2 planes [128][64] / W3 slices [128][32] (unpadded, pieces XOR-swizzled)
 constexpr int PB_H = PB_M * PB_P2;        // bytes of one H plane region (H2 is the larger)
 constexpr int PB_W = 128 * PB_PW2;        // bytes of one W2 plane
 constexpr int PB_W3 = 128 * PB_PW3;       // bytes of one W3 slice plane
@@ -80,8 +81,8 @@ __global__ __launch_bounds__(512, 2) void pointnet_bf16_kernel(
         for (int pl = 0; pl < PL; ++pl)
             rw[pl] = *reinterpret_cast<const uint4*>(wsrc[pl] + (size_t)n * 128 + (j & 3) * 32 + piece * 8);
     };
-    auto w3_store = [&](int stage) {
-        const int row = tid >> 2, piece = tid & 3;
+    auto w3_store = [&](int stage) {            // unpadded 64-byte rows, piece ^ ((row >> 2) & 3): 16 lanes = 4 rows x 4 pieces = 16 bank groups
+        const int row = tid >> 2, piece = (tid & 3) ^ ((tid >> 4) & 3);
 #pragma unroll
         for (int pl = 0; pl < PL; ++pl)
             *reinterpret_cast<uint4*>(sW + (stage * PL + pl) * (128 * PB_PW3) + row * PB_PW3 + piece * 16) = rw[pl];
@@ -90,7 +91,10 @@ __global__ __launch_bounds__(512, 2) void pointnet_bf16_kernel(
     for (int ch = part; ch < n_chunks; ch += nsplit) {
         // ---- conv1: thread -> point pp, channels cg .. cg+15 ----
         {
-            const int pp = tid >> 2, cg = (tid & 3) * 16;
+            // 16 consecutive lanes (one pass of a ds_write_b128) = 16 points at the same channel group: with the 144-byte pitch
+            // their bank groups 9 pp (mod 16) are a permutation (tid >> 2, tid & 3 wrapped onto the first point's banks from the
+            // third point on), and the point reads are coalesced
+            const int pp = wave * 16 + (lane & 15), cg = (lane >> 4) * 16;
             int p = ch * PB_M + pp;
             p = p < P ? p : P - 1;
             float xin[CIN];
@@ -169,17 +173,19 @@ __global__ __launch_bounds__(512, 2) void pointnet_bf16_kernel(
             const bool more = j + 1 < n_slices;
             if (more) w3_load(j + 1);
             const char* ap = sH + (wm * 32 + li) * PB_P2 + 64 * k4 + 16 * hi;
-            const char* bp = sW + ((j & 1) * PL) * (128 * PB_PW3) + (wn * 64 + li) * PB_PW3 + 16 * hi;
+            const char* bp = sW + ((j & 1) * PL) * (128 * PB_PW3) + (wn * 64 + li) * PB_PW3;
+            const int sw = (li >> 2) & 3;                             // piece swizzle of this lane's rows (w3_store)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap + 32 * ks);
                 bf16x8 al = ah;
                 if (PL == 2) al = *reinterpret_cast<const bf16x8*>(ap + PB_H + 32 * ks);
+                const int po = ((2 * ks + hi) ^ sw) * 16;
 #pragma unroll
                 for (int tn = 0; tn < 2; ++tn) {
-                    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(bp + tn * 32 * PB_PW3 + 32 * ks);
+                    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(bp + tn * 32 * PB_PW3 + po);
                     if (PL == 2) {
-                        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(bp + 128 * PB_PW3 + tn * 32 * PB_PW3 + 32 * ks);
+                        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(bp + 128 * PB_PW3 + tn * 32 * PB_PW3 + po);
                         acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[tn], 0, 0, 0);
                         acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[tn], 0, 0, 0);
                     }
