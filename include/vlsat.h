@@ -30,6 +30,11 @@
  *     host thread at a time, and its forwards are ordered on ONE stream at a time (small scratch buffers -- the split-K
  *     workspace of small GEMM launches -- belong to the handle: moving to another stream needs an event / sync between
  *     the last forward on the old stream and the first on the new one; separate handles are independent).
+ *   - several handles may be driven from several host threads at the same time (one thread and one stream per handle:
+ *     evaluate.validation(workers=K)).  The forward path launches only kernels of this library -- no hipMemsetAsync, no
+ *     runtime device-to-device copy: a hipMemsetAsync issued from several threads at once was caught writing a foreign
+ *     pattern about once per 20 000 calls.  A host that drives handles from threads should keep
+ *     runtime fills (and library reductions that use them internally) out of those threads as well.
  */
 #ifndef VLSAT_H
 #define VLSAT_H
