@@ -264,7 +264,11 @@ def main():
     ap.add_argument("--gemm-precision", default="fp32", choices=["fp32", "bf16x3", "bf16_mixed", "bf16"],
                     help="fp32 = BASELINE configs[1] (default, the headline); bf16x3 / bf16_mixed = configs[2] "
                          "(split-bf16 MFMA: <=1e-3; mixed single/split bf16: <=1e-2)")
+    ap.add_argument("--lib", default="", help="another build of libvlsat_hip.so to load instead of the in-tree one (same-box A/B of a kernel change)")
     args = ap.parse_args()
+    if args.lib:
+        from vlsat_amd import lib as _L
+        _L.LIB_PATH = os.path.abspath(args.lib)
 
     rank, local, world = vdist.init()
     if world != args.gpus:
