@@ -114,15 +114,41 @@ def _n_scenes(b) -> int:
     return int(b["batch_ids"].max().item()) + 1 if b["batch_ids"].numel() else 0
 
 
+def merge_batches(bs) -> dict:
+    """Consecutive batches (the reference loader's item names) collated into ONE on the device: node offsets applied to
+    ``edge_indices``, scene offsets to ``batch_ids``, ``fc_sizes`` hints concatenated when every batch carries one (what
+    collate_fn_mmg does for a bigger batch_size, reference DataLoader.py:160-172).  Counts are additive over scenes, so a loop
+    may hand the library several of its one-scene batches at a time."""
+    if len(bs) == 1:
+        return bs[0]
+    ei, bid, n_off, s_off = [], [], 0, 0
+    for b in bs:
+        n = b["obj_points"].shape[0]
+        ids = b.get("batch_ids")
+        ids = torch.zeros(n, 1, dtype=torch.int64, device=b["obj_points"].device) if ids is None else ids.view(-1, 1)
+        ei.append(b["edge_indices"] + n_off)
+        bid.append(ids + s_off)
+        n_off += n
+        s_off += _n_scenes(b)
+    out = {k: torch.cat([b[k] for b in bs]) for k in ("obj_points", "obj_2d_feats", "descriptor", "gt_class", "gt_rel_cls")}
+    out["edge_indices"], out["batch_ids"], out["n_scenes"] = torch.cat(ei), torch.cat(bid), s_off
+    if all("fc_sizes" in b for b in bs):
+        out["fc_sizes"] = [int(x) for b in bs for x in b["fc_sizes"]]
+    return out
+
+
 @torch.no_grad()
-def _validation_pipelined(model, batches: Iterable[dict], device, workers: int) -> np.ndarray:
+def _validation_pipelined(model, batches: Iterable[dict], device, workers: int, merge: int = 1) -> np.ndarray:
     """The counts vector of this rank's batches with NO host round trip per batch and ``workers`` batches in flight:
     every worker thread owns a replica of the model (its own library handle: a handle is driven by one host thread and one
     stream at a time) and a stream; forward, ranking and counting of a batch are enqueued back to back
     (``metrics.process_val_counts``) and the counts accumulate on the device with integer atomics.  One scene per batch --
     validation()'s own pattern (batch_size = 1, reference src/model/model.py:185,201-211) -- leaves most of the 256 CUs idle
     when scenes run one after the other (a 40-object forward is ~115 dependent kernels of 5-20 us); several in flight fill
-    them.  The host side scales too: the library call that enqueues a forward releases the GIL (ctypes)."""
+    them.  The host side scales too: the library call that enqueues a forward releases the GIL (ctypes).
+    ``merge`` > 1: every worker takes that many consecutive batches at a time and collates them on the device into one call
+    (``merge_batches``): the forward then runs at its batched rate.  Counts are additive, so the summary is the same up to
+    near-ties (a batched forward differs from a one-scene forward in the last bits: a rank may move by one)."""
     import threading
     from . import metrics as M
     dev = torch.device(device)
@@ -137,9 +163,10 @@ def _validation_pipelined(model, batches: Iterable[dict], device, workers: int) 
             with torch.cuda.stream(stream):
                 while not errors:
                     with lock:
-                        b = next(it, None)
-                    if b is None:
+                        group = [b for b in (next(it, None) for _ in range(max(1, merge))) if b is not None]
+                    if not group:
                         break
+                    b = merge_batches(group)
                     M.process_val_counts(models[k], counts[k], b["obj_points"], b["obj_2d_feats"], b["gt_class"], b["descriptor"],
                                          b["gt_rel_cls"], b["edge_indices"], b.get("batch_ids"), _n_scenes(b), b.get("fc_sizes"))
             stream.synchronize()
@@ -162,19 +189,20 @@ def _validation_pipelined(model, batches: Iterable[dict], device, workers: int) 
 
 
 @torch.no_grad()
-def validation(model, batches: Iterable[dict], device=None, workers: int = 0) -> Dict[str, float]:
+def validation(model, batches: Iterable[dict], device=None, workers: int = 0, merge: int = 1) -> Dict[str, float]:
     """``batches`` yields this rank's dicts with the reference loader's item names
     (obj_points [N,3,P], obj_2d_feats, gt_class, gt_rel_cls, edge_indices [E,2], descriptor, batch_ids; optionally
     ``fc_sizes``: objects per scene when edge_indices is the canonical fully-connected list, which spares the graph plan a
     read-back of the edge list).  One collective at the very end.
     workers = 0: the reference-compatible path -- ``process_val`` per batch (numpy rank lists on the host, like
     ``Mmgnet.process_val``) and host-side accumulation.  workers >= 1: counts accumulated on the device, no host round trip
-    per batch, ``workers`` batches in flight on as many streams and model replicas (for one-scene-per-call loops)."""
+    per batch, ``workers`` batches in flight on as many streams and model replicas (for one-scene-per-call loops);
+    ``merge`` = B > 1 additionally collates B consecutive batches into one call (``merge_batches``)."""
     from . import metrics as M
     if workers > 0:
         if device is None:
             raise ValueError("validation(workers > 0) needs the device")
-        vec = _validation_pipelined(model, batches, device, int(workers))
+        vec = _validation_pipelined(model, batches, device, int(workers), int(merge))
         t = vdist.allreduce_metrics(torch.from_numpy(vec).to(device))
         return summarize(t.cpu().numpy())
     vec = np.zeros(len(fields()), dtype=np.float64)

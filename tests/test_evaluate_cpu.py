@@ -87,3 +87,33 @@ def test_two_rank_allreduce_equals_single_process(tmp_path):
     for c in "abc":
         EV.accumulate(vec, *_case(z, c), n_scenes=1)
     assert np.array_equal(got, vec)
+
+
+def test_merge_batches_is_the_loaders_collation():
+    """evaluate.merge_batches of one-scene items == synth.collate of the same scenes (node offsets on the edges, scene ids,
+    concatenated fc_sizes hints), with and without batch_ids / hints."""
+    import torch
+    from vlsat_amd import synth
+    scenes = [synth.make_scene(n, 16, 50 + n) for n in (3, 5, 4)]
+    want = synth.collate(scenes)
+    items = []
+    for i, sc in enumerate(scenes):
+        b = synth.collate([sc])
+        n, e = b["obj_points"].shape[0], b["edge_indices"].shape[1]
+        it = {k: torch.from_numpy(v) for k, v in b.items() if k != "edge_indices"}
+        it.update(edge_indices=torch.from_numpy(b["edge_indices"]).t().contiguous(), gt_class=torch.full((n,), i),
+                  gt_rel_cls=torch.full((e, 26), i), fc_sizes=[n])
+        items.append(it)
+    m = EV.merge_batches(items)
+    assert m["fc_sizes"] == [3, 5, 4] and m["n_scenes"] == 3
+    assert np.array_equal(m["edge_indices"].t().numpy(), want["edge_indices"])
+    assert np.array_equal(m["batch_ids"].numpy().reshape(-1), want["batch_ids"].reshape(-1))
+    for k in ("obj_points", "obj_2d_feats", "descriptor"):
+        assert np.array_equal(m[k].numpy(), want[k])
+    assert m["gt_class"].tolist() == [0] * 3 + [1] * 5 + [2] * 4 and m["gt_rel_cls"].shape == (want["edge_indices"].shape[1], 26)
+    for it in items:                      # no hints, no batch_ids: scene ids are made up, the scene count comes from n_scenes
+        it.pop("fc_sizes"), it.pop("batch_ids")
+        it["n_scenes"] = 1
+    m2 = EV.merge_batches(items)
+    assert "fc_sizes" not in m2 and m2["n_scenes"] == 3 and m2["batch_ids"].view(-1).tolist() == [0] * 3 + [1] * 5 + [2] * 4
+    assert EV.merge_batches(items[:1]) is items[0]

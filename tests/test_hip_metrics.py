@@ -302,3 +302,27 @@ def test_pipelined_validation_equals_the_reference_compatible_loop(workers):
     for b in batches:                                                 # without the fully-connected hint: the edge list is hashed
         b.pop("fc_sizes")
     assert EV.validation(model, batches, device=DEV, workers=workers) == want
+
+
+def test_merged_validation_matches_the_one_scene_loop():
+    """evaluate.validation(workers=2, merge=4): four consecutive one-scene items collated on the device per call.  Counts are
+    additive; the batched forward differs from the one-scene forward in the last bits, so a near-tie may move a rank by one:
+    the totals (scenes, objects, predicates, triplets, per-class sample counts) are exact, the hit counts within a few units."""
+    _need_gpu()
+    from vlsat_amd import evaluate as EV
+    from vlsat_amd.model import VLSATModel
+    cfg, w, batches = _label_batches(13, 1, 29)
+    model = VLSATModel(cfg, DEV).load_state(w).eval()
+    want = EV._validation_pipelined(model, batches, DEV, 1)
+    F = EV.fields()
+    totals = [i for i, f in enumerate(F) if f == "scenes" or "_n_" in f]
+
+    def check(got):
+        assert np.array_equal(got[totals], want[totals]) and got[F.index("scenes")] == 13
+        assert np.abs(got - want).sum() <= 8, [(F[i], want[i], got[i]) for i in np.nonzero(got != want)[0]]
+    check(EV._validation_pipelined(model, batches, DEV, 2, merge=4))
+    s1 = EV.validation(model, batches, device=DEV, workers=2, merge=4)
+    assert s1["scenes"] == 13
+    for b in batches:
+        b.pop("fc_sizes")
+    check(EV._validation_pipelined(model, batches, DEV, 1, merge=5))

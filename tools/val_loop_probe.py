@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--objects", default="9,80", help="range of objects per scene (3RScan: 9..80), or one number")
     ap.add_argument("--gemm-precision", default="fp32", choices=["fp32", "bf16x3", "bf16_mixed"])
     ap.add_argument("--workers", default="1,2,4,6,8")
+    ap.add_argument("--merge", default="4,8,16", help="also: K workers each collating B consecutive one-scene batches into one call (evaluate.merge_batches)")
     ap.add_argument("--no-hint", action="store_true", help="do not pass fc_sizes: the plan cache hashes the (device) edge list, one read-back per new graph")
     a = ap.parse_args()
     dev = "cuda:0"
@@ -76,6 +77,12 @@ def main():
         t, got = timed(lambda: EV.validation(model, one_per_call, device=dev, workers=k))
         assert got == ref, "summaries differ: " + ", ".join(f"{q} {ref[q]!r} vs {got[q]!r}" for q in ref if got[q] != ref[q])
         print(f"  one scene per call, counts on the device, {k} in flight              {a.scenes / t:8.1f} scenes/s   {t / a.scenes * 1e3:6.3f} ms/scene")
+    for bsz in [int(x) for x in a.merge.split(",") if x]:
+        for k in (1, 2):
+            t, got = timed(lambda: EV.validation(model, one_per_call, device=dev, workers=k, merge=bsz))
+            worst = max(abs(got[q] - ref[q]) for q in ref)
+            print(f"  one scene per item, {bsz} items collated per call, {k} in flight          {a.scenes / t:8.1f} scenes/s   {t / a.scenes * 1e3:6.3f} ms/scene"
+                  f"   largest difference of a summary percentage: {worst:.4f}")
     t, got = timed(lambda: EV.validation(model, [big], device=dev, workers=1))
     worst = max(abs(got[k] - ref[k]) for k in ref)      # (batched and one-scene forwards differ in the last bits: a near-tie may move a rank)
     print(f"  all {a.scenes} scenes in ONE call (batched)                               {a.scenes / t:8.1f} scenes/s   {t / a.scenes * 1e3:6.3f} ms/scene"
