@@ -160,7 +160,7 @@ struct GateArgs {
 int launch_edge_gate(const GateArgs& a, hipStream_t s);
 // agg[n, 0:n_ch] = rowptr[n+1] > rowptr[n] ? -inf : 0   (start values of the fused max aggregation)
 int launch_agg_init(const int32_t* rowptr, int n_nodes, int n_ch, float* agg, int ld_agg, hipStream_t s);
-// p[0:n] = 0 with a kernel of the library (n % 4 == 0, p 16-byte aligned): the forward path does not use hipMemsetAsync
+// p[0:n] = 0 with a kernel of the library (16-byte stores when n and p allow): the forward path does not use hipMemsetAsync
 int launch_zero_f32(float* p, size_t n, hipStream_t s);
 // dst[r, 0:cols] = src[r, 0:cols], r < rows (pitches in floats; 16-byte accesses when sizes and pointers allow)
 int launch_copy_rows(float* dst, size_t dst_ld, const float* src, size_t src_ld, int cols, size_t rows, hipStream_t s);

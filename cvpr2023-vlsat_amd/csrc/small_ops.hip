@@ -221,18 +221,24 @@ int launch_agg_init(const int32_t* rowptr, int n_nodes, int n_ch, float* agg, in
     return 0;
 }
 
-// p[0:n] = 0 (n a multiple of 4, p 16-byte aligned).  The library's own fill: hipMemsetAsync, driven from several host threads
-// on several streams at once, was caught leaving foreign 8-byte patterns in the destination about once per 20 000 calls
-// (tools/replica_race_probe.py, profiles/r04_probes/replica_race.txt); nothing on the forward path uses it any more.
-__global__ __launch_bounds__(256) void zero_f32_kernel(float* __restrict__ p, size_t n4) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256)
-        reinterpret_cast<f32x4*>(p)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+// p[0:n] = 0.  The library's own fill: hipMemsetAsync, driven from several host threads on several streams at once, was caught
+// leaving foreign 8-byte patterns in the destination about once per 20 000 calls (tools/replica_race_probe.py,
+// profiles/r04_probes/replica_race.txt); nothing on the forward path uses it any more.  V = 4: 16-byte stores (n a multiple
+// of 4, p 16-byte aligned), V = 1 otherwise.
+template <int V>
+__global__ __launch_bounds__(256) void zero_f32_kernel(float* __restrict__ p, size_t nv) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (size_t)gridDim.x * 256) {
+        if constexpr (V == 4) reinterpret_cast<f32x4*>(p)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        else p[i] = 0.f;
+    }
 }
 int launch_zero_f32(float* p, size_t n, hipStream_t s) {
     if (n == 0) return 0;
-    if ((n & 3) || (reinterpret_cast<uintptr_t>(p) & 15)) return fail(-1, "zero_f32: length must be a multiple of 4 floats and the pointer 16-byte aligned");
-    const size_t n4 = n / 4;
-    hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)std::min<size_t>((n4 + 255) / 256, 2048)), dim3(256), 0, s, p, n4);
+    const bool v4 = !((n & 3) || (reinterpret_cast<uintptr_t>(p) & 15));
+    const size_t nv = v4 ? n / 4 : n;
+    const dim3 grid((unsigned)std::min<size_t>((nv + 255) / 256, 2048));
+    if (v4) hipLaunchKernelGGL(zero_f32_kernel<4>, grid, dim3(256), 0, s, p, nv);
+    else hipLaunchKernelGGL(zero_f32_kernel<1>, grid, dim3(256), 0, s, p, nv);
     VLSAT_LAUNCH_CHECK("zero_f32");
     return 0;
 }

@@ -199,6 +199,27 @@ def test_pointnet_vs_oracle(lib, n, p):
     assert err < 2e-5, f"pointnet n={n} p={p}: {err:.3e}"
 
 
+def test_pointnet_output_needs_only_4_byte_alignment(lib):
+    """vlsat_k_pointnet with an output pointer that is 4- but not 16-byte aligned, few objects (the points of an object are
+    split over several blocks that merge with atomicMax: the start value comes from the library's own fill kernel, which takes
+    the scalar path here) -- same result as the aligned call, and nothing written outside the [n, 768] block."""
+    w = synth.make_weights(VLSATConfig())
+    b = synth.make_batch(1, 5, 512, seed0=321)
+    pts = torch.from_numpy(b["obj_points"]).to(DEV)
+    want = _pointnet(lib, pts, w)
+    l = lib.load()
+    buf = torch.full((5 * 768 + 8,), float("nan"), device=DEV)
+    out = buf[1:1 + 5 * 768]
+    d = {k: torch.from_numpy(np.ascontiguousarray(w["obj_encoder." + k])).to(DEV) for k in
+         ("conv1.weight", "conv1.bias", "conv2.weight", "conv2.bias", "conv3.weight", "conv3.bias")}
+    lib.check(l.vlsat_k_pointnet(pts.data_ptr(), 5, 512, d["conv1.weight"].data_ptr(), d["conv1.bias"].data_ptr(),
+                                 d["conv2.weight"].data_ptr(), d["conv2.bias"].data_ptr(), d["conv3.weight"].data_ptr(),
+                                 d["conv3.bias"].data_ptr(), 768, out.data_ptr(), lib.stream_ptr()))
+    _sync()
+    assert out.data_ptr() % 16 == 4 and torch.equal(out.cpu().view(5, 768), want)
+    assert bool(torch.isnan(buf[0])) and bool(torch.isnan(buf[1 + 5 * 768:]).all())
+
+
 def test_pointnet_golden(lib, golden_dir):
     import os
     w = synth.make_weights(VLSATConfig(N_LAYERS=3))
