@@ -50,7 +50,12 @@ struct vlsat_ctx {
                              // KP2, G2, T768b, H2b: +7.3 KB per edge, 0.73 GB at the bench batch); plans whose workspace would pass
                              // DUAL_WS_BUDGET with it fall back to one stream (engine_plan.hip).  The per-class profiling keeps the
                              // two streams unless "prof_dual" is 0.
-    hipStream_t side = nullptr;
+    hipStream_t side = nullptr;          // lane 1: the 2D edge chain (two-stream schedule of round 4: every 2D twin stage)
+    hipStream_t side2 = nullptr;         // lane 2: the 2D node chain of the dependency-exact schedule (adapter, node cross-attention, wnode, 2D object head)
+    int sched = -1;          // two-stream plans: 1 = dependency-exact three-lane schedule (round 5), 0 = the fork / join schedule of round 4,
+                             // -1 = by mode: exact in the bf16 modes (+1.1 ... +1.7 %), fork / join in exact fp32, whose kernels are all
+                             // matrix-pipe-bound and lose 0.8 % to the extra concurrency (profiles/r05_probes/ab_sched.txt)
+                             // (vlsat_debug_option "sched"; results are bit-identical, the launches are the same)
     hipStream_t copy = nullptr;          // plan index uploads (non-blocking stream)
     std::vector<hipEvent_t> sync_ev;     // fork/join events (timing disabled), created on first use
     int fa_split = 1;        // allow the split-key edge attention for small plans (vlsat_debug_option "flash_split")
@@ -77,8 +82,8 @@ struct vlsat_ctx {
     bool prof = false;
     struct Rec { int cls; hipEvent_t a, b; double flops; long kernels; };
     std::vector<Rec> recs;
-    Rec open[2] = {};        // per stream (0 launch stream, 1 side stream): interval of the kernel class being launched (see Scope)
-    bool open_ok[2] = {false, false};
+    Rec open[3] = {};        // per lane (0 launch stream, 1 / 2 the side streams): interval of the kernel class being launched (see Scope)
+    bool open_ok[3] = {false, false, false};
     hipEvent_t prof_base = nullptr;       // time origin of the current batch of records (intervals of the two streams are
     bool prof_base_set = false;           // put on one timeline and a class's time is the length of their UNION)
     int prof_dual = 1;                    // keep the two-stream execution while profiling (vlsat_debug_option "prof_dual")
@@ -93,8 +98,8 @@ struct vlsat_ctx {
     int node_attn_split = 1024;              // node attention: sixteen lanes per query when the plan has fewer waves than this
     long config_epoch = 0;                   // bumped by every call that changes what a forward launches (graphs are re-captured)
     int gemm_splitk = 1;                     // small GEMM launches take the split-K kernel (gemm_splitk.hip)
-    float* sk_ws[2] = {nullptr, nullptr};    // its workspace + counters: [0] launch stream, [1] the side stream of two-stream plans
-    unsigned* sk_cnt[2] = {nullptr, nullptr};
+    float* sk_ws[3] = {nullptr, nullptr, nullptr};    // its workspace + counters, one set per lane: [0] launch stream, [1] / [2] the side streams
+    unsigned* sk_cnt[3] = {nullptr, nullptr, nullptr};
     int flash_dma = 1;                       // half-row bf16 edge attention: K / V by LDS-direct loads, one tile ahead (0: register-staged, round 3; 3 | 4: rings of three / four tile buffers)
     int gate_fuse_agg = 1;                   // gate at the default head geometry, GCN_AGGR = max: aggregation fused into the gate kernel: 0 never, 1 the bf16 modes, 2 fp32 as well ("gate_fuse_agg")
     int flash_ablate = 0;                    // timing experiments on the bf16 edge attention (FlashSplit::ablate; results are garbage)
@@ -164,6 +169,12 @@ struct vlsat_plan_s {
     const void* graph_ptrs[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     long graph_epoch = -1;                  // handle configuration (weights / precision / options) it was captured under
     float *NP2 = nullptr, *Hbig2 = nullptr, *KP2 = nullptr, *G2 = nullptr, *T768b = nullptr, *rs2 = nullptr, *H2b = nullptr;
+    // node cross-attention: its query / output rows (the self-attention's QKVn / On may be in use on another lane) and the
+    // key | value projection of X3 [kvx_slots][N, 2 D], computed on the 3D lane right after the self-attention (so that gcn_3ds may
+    // overwrite X3 without waiting for the 2D side); two-stream plans keep one slot per layer
+    float *Q2n = nullptr, *On2 = nullptr, *KVx = nullptr;
+    int kvx_slots = 1;
+    float* KVe2 = nullptr;                  // second K|V buffer of the edge cross-attention (two-stream plans: the 3D lane runs a layer ahead)
 };
 
 namespace vlsat {

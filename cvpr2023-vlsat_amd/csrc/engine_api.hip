@@ -38,6 +38,8 @@ int vlsat_set_edge_attention_scope(vlsat_handle h, int32_t scope) {
 // debug / experiment switches of one handle (they replace the VLSAT_* environment variables of round 1; defaults are
 // the measured-best settings and none changes results beyond fp32 summation order):
 //   "dual_stream" 0|1|2 2D twin stages on a second stream: 1 small plans only, 2 every plan (plans created afterwards)
+//   "sched"       -1|0|1  two-stream plans: dependency-exact three-lane schedule (1), the fork / join schedule of round 4 (0), or by
+//                       mode (-1, default: exact in the bf16 modes, fork / join in exact fp32)
 //   "flash_split" 0|1   split-key edge attention for plans that cannot fill the chip (plans created afterwards)
 //   "gemm_dma"    0|1   LDS-direct staging of fp32 GEMM operands (0: VGPR-staged)
 //   "gemm_p8"     0|1   single-rounding bf16 modes: large half-row launches on the 256 x 256 8-phase kernel (0: ring kernel)
@@ -60,6 +62,7 @@ int vlsat_debug_option(vlsat_handle h, const char* name, int32_t value) {
     const std::string k(name);
     ++h->config_epoch;
     if (k == "dual_stream") h->dual_stream = value < 0 ? 0 : value;
+    else if (k == "sched") h->sched = value < 0 ? -1 : value != 0;
     else if (k == "flash_split") h->fa_split = value != 0;
     else if (k == "gemm_dma") h->gemm_no_dma = value == 0;
     else if (k == "gemm_p8") h->gemm_no_p8 = value == 0;

@@ -46,7 +46,7 @@ hipEvent_t next_event(vlsat_ctx* h) {
 // (a run of consecutive launches of one class is one interval), plus one where the stream's work ends (join / end of the
 // forward).  With the 2D twin stages on the side stream the intervals of the two streams overlap; vlsat_profile_read puts
 // them on one timeline (a base event per batch of records) and charges a class the length of the UNION of its intervals.
-static inline int prof_lane(const vlsat_ctx* h, hipStream_t s) { return (h->side && s == h->side) ? 1 : 0; }
+static inline int prof_lane(const vlsat_ctx* h, hipStream_t s) { return (h->side && s == h->side) ? 1 : (h->side2 && s == h->side2) ? 2 : 0; }
 struct Scope {
     vlsat_ctx* h;
     hipStream_t s;
@@ -103,7 +103,7 @@ int gemm(vlsat_ctx* h, hipStream_t s, const GemmArgs& a0) {
     a.no_p8 = h->gemm_no_p8;
     a.launches = &h->gemm_launches;
     if (h->gemm_splitk) {
-        const int w = (h->side && s == h->side) ? 1 : 0;
+        const int w = prof_lane(h, s);             // (a split-K workspace per lane: launches of different lanes overlap)
         a.sk_ws = h->sk_ws[w]; a.sk_ws_floats = SPLITK_WS_FLOATS;
         a.sk_counters = h->sk_cnt[w]; a.sk_n_counters = SPLITK_COUNTERS;
     }
@@ -118,20 +118,27 @@ GemmArgs G(const float* A, int lda, const float* W, int K, float* C, int ldc, in
     return g;
 }
 
-int attn_block(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const AttnW& w, float* xq, const float* xkv, bool self) {
+// One MultiHeadAttention block on node rows (reference transformer/attention.py:105-126), in place on xq.
+// self: q = k = v = xq, one fused [3D, D] projection into qbuf = QKVn [N, 3D].  Cross (q = X2, k = v = X3): the key | value
+// projection `kv` [N, 2D] was made by kv_project() on the lane that owns X3; only the query is projected here, into qbuf [N, D].
+int attn_block(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const AttnW& w, float* xq, bool self, float* qbuf, const float* kv,
+               float* obuf) {
     const int N = (int)p->N, D = h->D, LDX = ldx_of(h);
+    const float *K, *V;
+    int ldq, ldkv;
     if (self) {
-        RUN(gemm(h, s, G(xq, LDX, w.wqkv, D, p->QKVn, 3 * D, N, 3 * D, w.bqkv)));
+        RUN(gemm(h, s, G(xq, LDX, w.wqkv, D, qbuf, 3 * D, N, 3 * D, w.bqkv)));
+        ldq = ldkv = 3 * D; K = qbuf + D; V = qbuf + 2 * D;
     } else {
-        RUN(gemm(h, s, G(xq, LDX, w.wq, D, p->QKVn, 3 * D, N, D, w.bq)));
-        RUN(gemm(h, s, G(xkv, LDX, w.wkv, D, p->QKVn + D, 3 * D, N, 2 * D, w.bkv)));
+        RUN(gemm(h, s, G(xq, LDX, w.wq, D, qbuf, D, N, D, w.bq)));
+        ldq = D; ldkv = 2 * D; K = kv; V = kv + D;
     }
     {
         Scope sc(h, s, PC_NODE_ATTN, 0);
-        RUN(launch_node_attn(p->QKVn, 3 * D, p->QKVn + D, 3 * D, p->QKVn + 2 * D, 3 * D, p->On, D, p->bias,
+        RUN(launch_node_attn(qbuf, ldq, K, ldkv, V, ldkv, obuf, D, p->bias,
                              p->d_scene_ptr, p->d_bias_ptr, p->S, p->max_n, h->H, D / h->H, 1.0f, s, h->node_attn_split));
     }
-    GemmArgs o = G(p->On, D, w.wo, D, xq, LDX, N, D, w.bo);
+    GemmArgs o = G(obuf, D, w.wo, D, xq, LDX, N, D, w.bo);
     o.resid = xq; o.ldr = LDX;
     RUN(gemm(h, s, o));
     {
@@ -140,11 +147,23 @@ int attn_block(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const AttnW& w, flo
     }
     return 0;
 }
+// key | value projection of a node cross-attention: kv [N, 2D] = xkv . Wkv^T + b
+int kv_project(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const AttnW& w, const float* xkv, float* kv) {
+    const int N = (int)p->N, D = h->D;
+    return gemm(h, s, G(xkv, ldx_of(h), w.wkv, D, kv, 2 * D, N, 2 * D, w.bkv));
+}
 
+// node side of a GraphEdgeAttenNetwork block: NP [N, 6D + A] = [P_i | P_j | Gq | value]
+int gcn_node_project(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const GcnW& w, const float* x, const Scratch& sc) {
+    const int N = (int)p->N, D = h->D, NPC = npc_of(h);
+    return gemm(h, s, G(x, ldx_of(h), w.wnode, D, sc.NP, NPC, N, NPC, w.bnode));
+}
+
+// node_done: sc.NP has already been filled by gcn_node_project (on another lane; the caller has ordered this lane behind it)
 int gcn_block(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const GcnW& w, float* x, float* e, int e_relu_pending,
-              int out_relu, const Scratch& sc) {
+              int out_relu, const Scratch& sc, bool node_done = false) {
     const int N = (int)p->N, E = (int)p->E, D = h->D, A = h->A, LDX = ldx_of(h), NPC = npc_of(h);
-    RUN(gemm(h, s, G(x, LDX, w.wnode, D, sc.NP, NPC, N, NPC, w.bnode)));
+    if (!node_done) RUN(gcn_node_project(h, p, s, w, x, sc));
     const int S = split_fmt(h);
     const bool gate16 = h->prec_edge && h->gate_bf16 && default_heads(h);
     const bool gate16h = h->prec_edge && h->gate_bf16 && (!default_heads(h) || h->gate_heads_mfma == 2) && h->gate_heads_mfma && h->gate_heads_bf16 &&
@@ -298,15 +317,15 @@ static int forward_impl(vlsat_handle h, vlsat_plan p, const float* pts, const fl
     if (rc != 0 && !capture && h && p && p->h == h && p->used) {
         hipStream_t s = static_cast<hipStream_t>(stream);
         const std::string msg = last_error_cstr();                    // (the calls below must not replace the real error)
-        if (h->side && p->dual) {
+        for (hipStream_t side : {h->side, h->side2}) {
             hipEvent_t e = nullptr;
-            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess) {
-                hipEventRecord(e, h->side);
+            if (side && p->dual && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess) {
+                hipEventRecord(e, side);
                 hipStreamWaitEvent(s, e, 0);
                 hipEventDestroy(e);                                   // (destruction is deferred until the event completes)
             }
         }
-        h->open_ok[0] = h->open_ok[1] = false;                        // profiling intervals left open are dropped
+        h->open_ok[0] = h->open_ok[1] = h->open_ok[2] = false;        // profiling intervals left open are dropped
         hipEventRecord(p->last_use, s);
         set_error(msg);
     }
@@ -338,15 +357,27 @@ static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const fl
     if (!capture) profile_close(h, s);     // an interval left open by a failed forward must not span foreign work
 #define STAGE(id) do { if (stop == (id)) { profile_close(h, s); hipEventRecord(p->last_use, s); return 0; } } while (0)
 
-    // Two-stream mode (small plans only; not while profiling or stopping at a debug stage): `t` carries the 2D twin
-    // of a stage while `s` carries the 3D one.  fork(): t waits for everything enqueued on s so far; join(): s waits
-    // for t.  Every forward ends joined, so the caller only ever sees its own stream.
+    // Lanes.  A two-stream plan (p->dual: it owns a second scratch set) runs the forward on up to three streams that always end
+    // joined into the caller's, so the caller only ever sees its own stream:
+    //   s  the caller's stream: the 3D chain -- object encoder, self-attention, gcn_3ds, the key | value projections both
+    //      cross-attentions read from 3D tensors, the 3D heads.  It never reads a 2D tensor (reference network_MMG.py:217-234,
+    //      SURVEY 3.3), so it never waits for the other lanes except for a buffer to become free;
+    //   t  the 2D edge chain: rel_encoder_2d, gcn_2ds (edge side + prop), edge cross-attention (query projection, attention,
+    //      out-projection, LayerNorm), the 2D relation head;
+    //   u  the 2D node chain: adapter, node cross-attention, the node-side projection of gcn_2ds, the 2D object head.
+    // "sched" = 1 (default): dependency-exact -- every cross-lane edge of the data flow is ONE event (after() / wait()), so the
+    // latency-bound node-row launches and GEMM tails of one lane execute under the non-persistent attention / gate kernels of
+    // another.  "sched" = 0: the fork / join schedule of round 4 (u = t; the lanes meet twice per layer).  The launches, their
+    // operands and therefore the results are the same in both; not while stopping at a debug stage or for the training outputs.
     const bool dual = p->dual && do2d && (!h->prof || capture || h->prof_dual) && stop < 0 && !tr;
-    hipStream_t t = s;
+    const bool exact = dual && (h->sched < 0 ? h->prec_edge != 0 : h->sched != 0);
+    hipStream_t t = s, u = s;
     size_t ev_i = 0;
     if (dual) {
         if (!h->side) VLSAT_HIP_CHECK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+        if (!h->side2) VLSAT_HIP_CHECK(hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking));
         t = h->side;
+        u = exact ? h->side2 : h->side;
     }
     auto next_ev = [&](hipEvent_t* e) -> int {
         if (ev_i == h->sync_ev.size()) {
@@ -357,21 +388,32 @@ static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const fl
         *e = h->sync_ev[ev_i++];
         return 0;
     };
-    auto order = [&](hipStream_t first, hipStream_t then) -> int {       // `then` continues after `first`'s work so far
+    // after(x, &e): e stands for everything enqueued on lane x so far; wait(y, e): lane y continues behind it.  While the
+    // per-class profile is on, a lane's open interval ends where it starts to wait (the wait is nobody's kernel time).
+    auto after = [&](hipStream_t x, hipEvent_t* e) -> int {
+        *e = nullptr;
         if (!dual) return 0;
-        hipEvent_t e;
-        RUN(next_ev(&e));
-        VLSAT_HIP_CHECK(hipEventRecord(e, first));
-        VLSAT_HIP_CHECK(hipStreamWaitEvent(then, e, 0));
+        RUN(next_ev(e));
+        VLSAT_HIP_CHECK(hipEventRecord(*e, x));
         return 0;
     };
-    auto fork = [&]() { return order(s, t); };
-    auto join = [&]() {
-        if (dual && !capture) profile_close(h, t);          // the side stream's open interval ends with its work
-        return order(t, s);
+    auto wait = [&](hipStream_t y, hipEvent_t e) -> int {
+        if (!dual || !e) return 0;
+        if (!capture) profile_close(h, y);
+        VLSAT_HIP_CHECK(hipStreamWaitEvent(y, e, 0));
+        return 0;
     };
+    auto order = [&](hipStream_t first, hipStream_t then) -> int {       // `then` continues after `first`'s work so far
+        if (!dual || first == then) return 0;
+        hipEvent_t e;
+        RUN(after(first, &e));
+        return wait(then, e);
+    };
+    auto fork = [&]() { return exact ? 0 : order(s, t); };               // (round-4 schedule only)
+    auto join = [&]() { return exact ? 0 : order(t, s); };
     const Scratch sc3 = scratch_of(p, 0), sc2 = scratch_of(p, dual ? 1 : 0);
     const int S = split_fmt(h);            // edge tensors in the split-pair format (bf16 modes)
+    if (exact) RUN(order(s, u));           // u starts where the forward starts (behind whatever the caller enqueued before it)
 
     const bool ft = h->d.feature_transform != 0;
     if (!ft) {   // a-2 object encoder
@@ -410,7 +452,9 @@ static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const fl
         Scope sc(h, s, PC_MISC, 0);
         RUN(launch_edge_embed(desc, p->d_src, p->d_dst, E, h->re_w1cat, h->re_b1cat, p->H1, s));
     }
-    RUN(fork());                                                            // t: 2D relation encoder + adapter
+    hipEvent_t h1_ready = nullptr;
+    RUN(after(s, &h1_ready));
+    RUN(wait(t, h1_ready));                                                 // t: 2D relation encoder (old schedule: + adapter)
     if (!ft) {
         for (int br = 0; br < (do2d ? 2 : 1); ++br) {          // conv2 / conv3 of rel_encoder_3d (on s) and rel_encoder_2d (on t)
             const Scratch& sc = br ? sc2 : sc3;
@@ -428,16 +472,19 @@ static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const fl
                             br ? h->re2_b2 : h->re3_b2, br ? h->re2_w3 : h->re3_w3, br ? h->re2_b3 : h->re3_b3, D, &out));
             RUN(launch_copy_rows(br ? p->E2 : p->E3, (size_t)D, out, (size_t)D, D, (size_t)E, s));
         }
+        if (dual) { hipEvent_t e; RUN(after(s, &e)); RUN(wait(t, e)); }    // (E2 was written on s)
     }
     STAGE(3);
-    // a-6 adapter -> X2[:, 0:512]
+    // a-6 adapter -> X2[:, 0:512]   (lane u: it depends on the inputs only -- u was forked where the forward began)
+    hipEvent_t x2_ready = nullptr;        // X2[:, 0:512] is complete (adapter, then prop of gcn_2ds[l]) -> the node cross-attention may run
     if (do2d) {
-        RUN(gemm(h, t, G(f2d, D, h->ad_w1, D, p->T256, 256, N, 256, h->ad_b1, ACT_RELU)));
+        RUN(gemm(h, u, G(f2d, D, h->ad_w1, D, p->T256, 256, N, 256, h->ad_b1, ACT_RELU)));
         GemmArgs a = G(p->T256, 256, h->ad_w2h, 256, p->X2, LDX, N, D, h->ad_b2h);
         a.resid = f2d; a.ldr = D; a.resid_scale = 0.5f;
-        RUN(gemm(h, t, a));
+        RUN(gemm(h, u, a));
         if (tr && tr->mimic2d)             // the adapter's output before the MMG touches it (:312)
-            RUN(launch_copy_rows(tr->mimic2d, 512, p->X2, (size_t)LDX, 512, (size_t)N, t));
+            RUN(launch_copy_rows(tr->mimic2d, 512, p->X2, (size_t)LDX, 512, (size_t)N, u));
+        if (exact) RUN(after(u, &x2_ready));
     }
     STAGE(4);
     {   // a-7 distance bias
@@ -446,18 +493,40 @@ static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const fl
     }
     STAGE(5);
     int e3_pending_relu = 0;
+    hipEvent_t flash_done[2] = {nullptr, nullptr};            // the edge attention that read KVe slot i has completed
     for (int l = 0; l < L; ++l) {
         const int inter = (l < L - 1 || L == 1) ? 1 : 0;     // reference network_MMG.py:236
         const int base = 10 + 10 * l;
-        RUN(attn_block(h, p, s, h->self_attn[l], p->X3, p->X3, true));                  // :217
+        RUN(attn_block(h, p, s, h->self_attn[l], p->X3, true, p->QKVn, nullptr, p->On));   // :217
         STAGE(base + 0);
-        RUN(join());                                          // X2 / E2 of the previous stage are complete
-        if (do2d) RUN(attn_block(h, p, s, h->cross_attn[l], p->X2, p->X3, false));      // :218
+        // :218 node cross-attention, q = X2, k = v = X3 (after the self-attention, before gcn_3ds): the key | value projection
+        // runs on the lane that owns X3, so gcn_3ds below does not have to wait for the 2D side to have read X3
+        float* kvx = p->KVx + (size_t)(p->kvx_slots > 1 ? l : 0) * (size_t)N * 2 * D;
+        hipEvent_t kvx_ready = nullptr, np2_ready = nullptr;
+        if (do2d) {
+            RUN(kv_project(h, p, s, h->cross_attn[l], p->X3, kvx));
+            if (exact) {
+                RUN(after(s, &kvx_ready));                    // (also behind the distance bias)
+                RUN(wait(u, kvx_ready));
+                RUN(wait(u, x2_ready));
+            } else {
+                RUN(join());                                  // X2 / E2 of the previous stage are complete
+            }
+            RUN(attn_block(h, p, exact ? u : s, h->cross_attn[l], p->X2, false, p->Q2n, kvx, p->On2));
+            if (exact) {                                      // node side of gcn_2ds[l] on the same lane, then the edge lane may go on
+                RUN(gcn_node_project(h, p, u, h->gcn2[l], p->X2, sc2));
+                RUN(after(u, &np2_ready));
+            }
+        }
         STAGE(base + 1);
         RUN(fork());                                          // t: gcn_2ds + query projection; s: gcn_3ds + key/value projection
         RUN(gcn_block(h, p, s, h->gcn3[l], p->X3, p->E3, e3_pending_relu, inter, sc3)); // :224
         STAGE(base + 2);
-        if (do2d) RUN(gcn_block(h, p, t, h->gcn2[l], p->X2, p->E2, 0, inter, sc2));     // :225
+        if (do2d) {
+            RUN(wait(t, np2_ready));
+            RUN(gcn_block(h, p, t, h->gcn2[l], p->X2, p->E2, 0, inter, sc2, exact));      // :225
+            if (exact) RUN(after(t, &x2_ready));
+        }
         STAGE(base + 3);
         if (do2d) {   // :231 edge cross-attention: q = 2D edges, k = v = 3D edges (pre-activation)
             const AttnW& w = h->cross_rel[l];
@@ -466,30 +535,43 @@ static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const fl
             // format of Q / K|V / O: that of the chain when the bf16 attention kernel is built for this head dim and mode, else fp32
             const bool fa16 = h->prec_edge && h->flash_bf16 && (dh == 64 || (h->flash_heads_bf16 && S && flash_attn_bf16_supports(dh, h->prec_edge == 3 ? 3 : 1, h->flash_tr, S)));
             const int SA = fa16 ? S : 0;
+            // K | V of layer l go to slot l % 2 on the dependency-exact schedule (the 3D lane may be a layer ahead of the attention
+            // that reads them: it waits for the reader of the slot's previous content only)
+            const int slot = exact ? (l & 1) : 0;
+            float* kve = slot ? p->KVe2 : p->KVe;
+            hipStream_t fs = exact ? t : s;                   // lane of the attention itself
             GemmArgs gq = G(p->E2, D, w.wq, D, p->Qe, D, E, D, w.bq);
             gq.a_split = S; gq.c_split = SA;
             if (SA) gq.c_scale = sc2e;                                 // the split-format attention takes Q pre-scaled
             RUN(gemm(h, t, gq));
-            GemmArgs gkv = G(p->E3, D, w.wkv, D, p->KVe, 2 * D, E, 2 * D, w.bkv);
+            RUN(wait(s, flash_done[slot]));
+            GemmArgs gkv = G(p->E3, D, w.wkv, D, kve, 2 * D, E, 2 * D, w.bkv);
             gkv.a_split = S; gkv.c_split = SA;
             RUN(gemm(h, s, gkv));
-            RUN(join());
+            if (exact) {
+                hipEvent_t kve_ready;
+                RUN(after(s, &kve_ready));
+                RUN(wait(t, kve_ready));
+            } else {
+                RUN(join());
+            }
             {
-                Scope sc(h, s, PC_FLASH, p->flash_flops);
+                Scope sc(h, fs, PC_FLASH, p->flash_flops);
                 FlashSplit sp;
                 sp.ablate = h->flash_ablate;
                 sp.parts = p->fa_parts; sp.krange = p->d_krange; sp.o_part = p->fa_opart; sp.m_part = p->fa_m;
                 sp.l_part = p->fa_l; sp.part_stride = (size_t)E * D; sp.rows = E; sp.heads = h->H;
                 if (dh != 32 && dh != 64 && dh != 128)   // any other head dim: VALU attention over the scenes' edge ranges (no bias)
-                    RUN(launch_node_attn(p->Qe, D, p->KVe, 2 * D, p->KVe + D, 2 * D, p->Oe, D, nullptr, p->d_edge_ptr32, nullptr,
+                    RUN(launch_node_attn(p->Qe, D, kve, 2 * D, kve + D, 2 * D, p->Oe, D, nullptr, p->d_edge_ptr32, nullptr,
                                          h->edge_scope == 1 ? 1 : p->S, h->edge_scope == 1 ? E : p->max_e, h->H, D / h->H,
-                                         1.f / std::sqrt((float)(D / h->H)), s, h->node_attn_split));
+                                         1.f / std::sqrt((float)(D / h->H)), fs, h->node_attn_split));
                 else if (fa16)
-                    RUN(launch_flash_attn_bf16(p->Qe, D, p->KVe, p->KVe + (SA == 2 ? D / 2 : D), 2 * D, p->Oe, D, p->d_tiles, p->n_tiles,
-                                               sc2e, h->prec_edge == 3 ? 3 : 1, h->flash_tr ? (h->flash_dma >= 3 ? h->flash_dma : h->flash_dma ? 1 : 2) : 0, SA, s, &sp, h->flash_pv_terms, dh));    // (half rows: V starts at byte 2 D)
+                    RUN(launch_flash_attn_bf16(p->Qe, D, kve, kve + (SA == 2 ? D / 2 : D), 2 * D, p->Oe, D, p->d_tiles, p->n_tiles,
+                                               sc2e, h->prec_edge == 3 ? 3 : 1, h->flash_tr ? (h->flash_dma >= 3 ? h->flash_dma : h->flash_dma ? 1 : 2) : 0, SA, fs, &sp, h->flash_pv_terms, dh));    // (half rows: V starts at byte 2 D)
                 else
-                    RUN(launch_flash_attn(p->Qe, D, p->KVe, p->KVe + D, 2 * D, p->Oe, D, p->d_tiles, p->n_tiles, sc2e, s, &sp, dh));   // (head dims 32 / 128: NUM_HEADS 16 / 4)
+                    RUN(launch_flash_attn(p->Qe, D, kve, kve + D, 2 * D, p->Oe, D, p->d_tiles, p->n_tiles, sc2e, fs, &sp, dh));   // (head dims 32 / 128: NUM_HEADS 16 / 4)
             }
+            if (exact) RUN(after(t, &flash_done[slot]));
             // out-projection + residual, then LayerNorm (+ inter-layer ReLU).  Split format: the GEMM reads O and the
             // residual as hi/lo pairs and writes plain fp32 into the (now dead) Q buffer; the LayerNorm packs E2 again.
             // Split-pair mode: the residual is added by the LayerNorm kernel instead (as an accumulator init it made the
@@ -500,9 +582,9 @@ static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const fl
             GemmArgs o = G(p->Oe, D, w.wo, D, pre_ln, D, E, D, w.bo);
             if (!ln_resid) { o.resid = p->E2; o.ldr = D; o.r_split = S; }
             o.a_split = SA;
-            RUN(gemm(h, s, o));
-            Scope sc(h, s, PC_LAYERNORM, 0);
-            RUN(launch_layernorm_to(pre_ln, D, p->E2, D, E, D, w.lng, w.lnb, inter, S, s, ln_resid ? p->E2 : nullptr, D, S));
+            RUN(gemm(h, fs, o));
+            Scope sc(h, fs, PC_LAYERNORM, 0);
+            RUN(launch_layernorm_to(pre_ln, D, p->E2, D, E, D, w.lng, w.lnb, inter, S, fs, ln_resid ? p->E2 : nullptr, D, S));
         }
         e3_pending_relu = inter;
         STAGE(base + 4);
@@ -529,8 +611,15 @@ static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const fl
         if (do2d) RUN(rel_head(h, p, t, h->rel2, p->E2, 0, rel2d, sc2));
     }
     RUN(obj_head(h, p, s, p->X3, h->obj3_w, h->obj3_b, obj3d, sc3));
-    if (do2d) RUN(obj_head(h, p, t, p->X2, h->obj2_w, h->obj2_b, obj2d, sc2));
-    RUN(join());
+    if (do2d) {
+        RUN(wait(u, x2_ready));
+        RUN(obj_head(h, p, u, p->X2, h->obj2_w, h->obj2_b, obj2d, sc2));
+    }
+    if (dual) {                                               // every lane ends joined into the caller's stream
+        if (!capture) { profile_close(h, t); profile_close(h, u); }
+        RUN(order(t, s));
+        if (u != t) RUN(order(u, s));
+    }
     if (capture) return 0;
     profile_close(h, s);
     VLSAT_HIP_CHECK(hipEventRecord(p->last_use, s));
@@ -580,7 +669,8 @@ int vlsat_forward_graph(vlsat_handle h, vlsat_plan p, const float* pts, const fl
     if (!same) {
         retire_graph(h, p);                // (its last launch may still be running)
         if (p->dual && !h->side) VLSAT_HIP_CHECK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
-        h->sync_ev.reserve(64);            // (events of the fork / join points are created on demand: fine during capture)
+        if (p->dual && !h->side2) VLSAT_HIP_CHECK(hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking));
+        h->sync_ev.reserve(128);            // (events of the fork / join points are created on demand: fine during capture)
         VLSAT_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
         const int rc = forward_impl(h, p, pts, f2d, desc, obj3d, obj2d, rel3d, rel2d, nullptr, stream, true);
         hipGraph_t g = nullptr;

@@ -256,18 +256,22 @@ int vlsat_plan_create(vlsat_handle h, const int64_t* bid, const int64_t* edges, 
     want(&p->H1, Es * 128); want(&p->H2, Es * 128); want(&p->E3, Es * 512); want(&p->E2, Es * 512);
     want(&p->Hbig, Es * 1024); want(&p->KP, Es * 512); want(&p->G, Es * A);
     want(&p->Qe, Es * 512); want(&p->KVe, Es * 1024); want(&p->Oe, Es * 512);
+    want(&p->Q2n, Ns * 512); want(&p->On2, Ns * 512);
     // launch-bound plans (every edge GEMM fits one round of the grid): second scratch set for the 2D twin stages
     p->dual = h->dual_stream && E > 0 && (h->dual_stream > 1 || E <= 8192);      // (dual_stream = 2: every plan)
     if (p->dual) {                         // ... unless the second scratch set would take the plan past the budget
         size_t base = 0;
         for (auto& it : items) base += it.bytes;
-        const size_t extra = (Ns * (size_t)(NPC + LDX + 1) + Es * (size_t)(1024 + 512 + A + 128)) * sizeof(float);
+        const size_t extra = (Ns * (size_t)(NPC + LDX + 1 + 1024 * (size_t)h->d.n_layers) + Es * (size_t)(1024 + 512 + A + 128 + 1024)) * sizeof(float);
         if (base + extra > DUAL_WS_BUDGET) p->dual = false;
     }
     if (p->dual) {
         want(&p->NP2, Ns * NPC); want(&p->Hbig2, Es * 1024); want(&p->KP2, Es * 512); want(&p->G2, Es * A);
         want(&p->T768b, Ns * LDX); want(&p->rs2, Ns); want(&p->H2b, Es * 128);
+        want(&p->KVe2, Es * 1024);
+        p->kvx_slots = std::max(1, (int)h->d.n_layers);
     }
+    want(&p->KVx, Ns * 1024 * (size_t)p->kvx_slots);
     if (h->d.feature_transform) {
         // point rows R = N*P (objects) or E (relation encoders, P = 1), one phase at a time:
         //   rows [R,64] h1, [R,64], [R,128], [R,1024] STN convs (the last two double as conv2/conv3 of the main chain),

@@ -273,8 +273,9 @@ void vlsat_destroy(vlsat_handle h) {
     if (h->prof_base) hipEventDestroy(h->prof_base);
     for (hipEvent_t e : h->sync_ev) hipEventDestroy(e);
     if (h->side) hipStreamDestroy(h->side);
+    if (h->side2) hipStreamDestroy(h->side2);
     if (h->copy) hipStreamDestroy(h->copy);
-    for (int i = 0; i < 2; ++i) { hipFree(h->sk_ws[i]); hipFree(h->sk_cnt[i]); }
+    for (int i = 0; i < 3; ++i) { hipFree(h->sk_ws[i]); hipFree(h->sk_cnt[i]); }
     delete h;
 }
 
@@ -430,7 +431,7 @@ int vlsat_finalize_weights(vlsat_handle h) {
     h->finalized = true;
     ++h->config_epoch;
     if (h->prec) RUN(split_all_weights(h));
-    for (int i = 0; i < 2 && !h->sk_ws[i]; ++i) {     // split-K workspaces of the small GEMM launches (gemm_splitk.hip), once per handle
+    for (int i = 0; i < 3 && !h->sk_ws[i]; ++i) {     // split-K workspaces of the small GEMM launches (gemm_splitk.hip), once per handle
         VLSAT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->sk_ws[i]), SPLITK_WS_FLOATS * sizeof(float)));
         VLSAT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->sk_cnt[i]), SPLITK_COUNTERS * sizeof(unsigned)));
         VLSAT_HIP_CHECK(hipMemset(h->sk_cnt[i], 0, SPLITK_COUNTERS * sizeof(unsigned)));

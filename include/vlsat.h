@@ -356,7 +356,9 @@ int vlsat_debug_gemm_clock_probe(int64_t* buf);
 /* Experiment switches of one handle; defaults are the measured-best settings and none changes results beyond
  * fp32 summation order.  "dual_stream" 0|1|2: 2D twin stages on a second stream (1: launch-bound plans only, 2 = default: every plan;
  * a two-stream plan owns a second scratch set, +7.3 KB per edge = 0.73 GB at the 64-scene bench batch, and falls back to one stream
- * when its workspace would pass 48 GiB with it); "gemm_p8" 0|1: large edge-row GEMM launches on the 256 x 256 8-phase kernel in
+ * when its workspace would pass 48 GiB with it); "sched" -1|0|1: schedule of a two-stream plan -- 1 = dependency-exact, three lanes
+ * (3D chain / 2D edge chain / 2D node chain) coupled by one event per data-flow edge, 0 = the fork / join schedule (lanes meet twice
+ * per layer), -1 (default) = exact in the bf16 modes, fork / join in exact fp32; bit-identical results; "gemm_p8" 0|1: large edge-row GEMM launches on the 256 x 256 8-phase kernel in
  * every precision mode (1, default; 0: the older 128 x 128 / ring kernels -- in the half-row mode the edge-attention residual then
  * goes back from the LayerNorm kernel into the out-projection); "flash_split" 0|1:
  * split-key edge attention for plans that cannot fill the chip (both: plans created afterwards); "gemm_dma" 0|1:

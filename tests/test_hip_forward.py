@@ -200,26 +200,34 @@ def test_random_graphs_vs_oracle(seed):
     _check(run_hip(cfg, b), run_oracle(cfg, b), TIGHT, f"random graph batch #{seed} ({len(scenes)} scenes, E={len(perm)})")
 
 
-def test_two_stream_mode_is_bit_identical():
-    """Small plans run the 2D twin stages on a second stream (engine.hip: fork/join around the relation encoder,
-    adapter, gcn_2ds, query projection and the 2D heads).  Same kernels on the same data, so the outputs must be
-    bit-identical to the single-stream schedule -- any difference is a race.  30 scenes x 3 repeats."""
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16_mixed"])
+def test_two_stream_mode_is_bit_identical(precision):
+    """Two-stream plans run the forward on up to three lanes (engine_forward.hip): the dependency-exact schedule of round 5
+    ("sched" = 1: 3D chain / 2D edge chain / 2D node chain, coupled by one event per data-flow edge, the 3D chain up to a layer
+    ahead) and the fork / join schedule of round 4 ("sched" = 0).  Same kernels on the same data, so the outputs of both must be
+    bit-identical to the single-stream schedule -- any difference is a race or a missing dependency.  30 scenes of 2-59 objects
+    plus a 6-scene batch, every forward 3 times BACK TO BACK without a host wait (so that the next forward's 3D lane meets the
+    previous one's tail), in every precision mode."""
     from vlsat_amd.model import VLSATModel
     cfg = VLSATConfig(N_LAYERS=3)
     w = synth.make_weights(cfg)
-    dual = VLSATModel(cfg, DEV).load_state(w).eval()
-    single = VLSATModel(cfg, DEV).load_state(w).eval().debug_option("dual_stream", 0)
+    single = VLSATModel(cfg, DEV).load_state(w).eval().set_gemm_precision(precision).debug_option("dual_stream", 0)
+    exact = VLSATModel(cfg, DEV).load_state(w).eval().set_gemm_precision(precision).debug_option("sched", 1)
+    forkjoin = VLSATModel(cfg, DEV).load_state(w).eval().set_gemm_precision(precision).debug_option("sched", 0)
     g = np.random.default_rng(7)
-    for i in range(30):
-        b = _dev(synth.collate([synth.make_scene(int(g.integers(2, 60)), int(g.integers(8, 200)), 12000 + i)]))
-        ref = [o.clone() for o in single(b["obj_points"], b["obj_2d_feats"], b["edge_indices"], b["descriptor"], b["batch_ids"])]
-        for rep in range(3):
-            got = dual(b["obj_points"], b["obj_2d_feats"], b["edge_indices"], b["descriptor"], b["batch_ids"])
+    batches = [_dev(synth.collate([synth.make_scene(int(g.integers(2, 60)), int(g.integers(8, 200)), 12000 + i)])) for i in range(30)]
+    batches.append(_dev(synth.collate([synth.make_scene(int(n), 64, 12100 + j) for j, n in enumerate((40, 3, 17, 1, 58, 25))])))
+    for i, b in enumerate(batches):
+        args = (b["obj_points"], b["obj_2d_feats"], b["edge_indices"], b["descriptor"], b["batch_ids"])
+        ref = [o.clone() for o in single(*args)]
+        for name, m in (("exact", exact), ("fork/join", forkjoin)):
+            outs = [[o.clone() for o in m(*args)] for rep in range(3)]
             torch.cuda.synchronize()
-            for n, a, c in zip(NAMES, got, ref):
-                assert torch.equal(a, c), f"scene {i} rep {rep} {n}: max diff {float((a - c).abs().max()):.3e}"
-    dual.close()
-    single.close()
+            for rep, got in enumerate(outs):
+                for n, a, c in zip(NAMES, got, ref):
+                    assert torch.equal(a, c), f"{name} batch {i} rep {rep} {n}: max diff {float((a - c).abs().max()):.3e}"
+    for m in (single, exact, forkjoin):
+        m.close()
 
 
 def test_feature_transform_ragged_vs_oracle():
