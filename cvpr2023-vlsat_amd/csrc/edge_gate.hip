@@ -28,12 +28,13 @@ namespace vlsat {
 constexpr int GT_PITCH = 68;     // W0k rows: 64 + 4 pad
 constexpr int GT_PITCH3 = 132;   // W3 rows: 128 + 4 pad
 
+// FUSED: the max aggregation runs inside the kernel (GateArgs::agg; gate_agg.h) and its wave buffers exist -- 63 KB of LDS per block,
+// two blocks per CU.  Exact fp32 keeps the separate aggregate launch by default, and that variant holds 51.7 KB: three per CU.
+template <bool FUSED>
 __global__ __launch_bounds__(256, 2) void edge_gate_kernel(GateArgs p) {
     __shared__ __attribute__((aligned(16))) float sW0[128 * GT_PITCH];
     __shared__ __attribute__((aligned(16))) float sW3[32 * GT_PITCH3];
-    // wave buffers of the fused aggregation (gate_agg.h); with them a CU holds two blocks instead of three, which this MFMA-bound
-    // kernel does not feel (measured: 96 vs 89 TFLOP/s charged time with the LDS merely reserved)
-    __shared__ __attribute__((aligned(16))) char sAgg[4 * AG_WAVE_BYTES];
+    __shared__ __attribute__((aligned(16))) char sAgg[FUSED ? 4 * AG_WAVE_BYTES : 16];      // wave buffers of the fused aggregation
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, hi = lane >> 5;
 
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void edge_gate_kernel(GateArgs p) {
         }
         sum += __shfl_xor(sum, 32);
         const float inv = 1.f / sum;
-        if (p.agg) {                           // fused max aggregation: the gated rows are never stored (gate_agg.h)
+        if (FUSED && p.agg) {                  // fused max aggregation: the gated rows are never stored (gate_agg.h)
             gate_aggregate_max(sAgg + wave * AG_WAVE_BYTES, lg, inv, p.node + (size_t)dn * p.ld_node + p.v_off + h * 32 + 4 * hi, valid ? sn : -1,
                                li, hi, lane, h, p.agg, p.ld_agg);
         } else if (valid) {
@@ -202,11 +203,12 @@ int launch_edge_gate(const GateArgs& a, hipStream_t s) {
     if (a.agg && (!a.row_map || a.prob || (a.ld_agg & 3))) return fail(-1, "edge_gate: the fused aggregation needs the 32-edges-per-wave row map and no prob tap");
     if ((a.ld_node & 3) || (a.gq_off & 3) || (a.v_off & 3)) return fail(-1, "edge_gate: ld_node/gq_off/v_off must be multiples of 4");
     const int n_groups = a.row_map ? 2 * ((a.n_edges + 31) / 32) : (a.n_edges + 15) / 16;
-    // persistent: 3 blocks per CU are resident (51.7 KB LDS each); every block stages the weights once
-    // and walks ~n_groups/768 groups, so there is no partial last wave of blocks
-    const int cap = a.grid_cap > 0 ? a.grid_cap : 768;
+    // persistent: every block stages the weights once and walks ~n_groups / grid groups; the grid is what is resident at once -- 3
+    // blocks per CU (51.7 KB of LDS each), 2 with the aggregation's wave buffers (63 KB) -- so there is no partial last wave of blocks
+    const int cap = a.grid_cap > 0 ? a.grid_cap : (a.agg ? 512 : 768);
     const int grid = n_groups < cap ? n_groups : cap;
-    hipLaunchKernelGGL(edge_gate_kernel, dim3(grid), dim3(256), 0, s, a);
+    if (a.agg) hipLaunchKernelGGL(edge_gate_kernel<true>, dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(edge_gate_kernel<false>, dim3(grid), dim3(256), 0, s, a);
     VLSAT_LAUNCH_CHECK("edge_gate");
     return 0;
 }

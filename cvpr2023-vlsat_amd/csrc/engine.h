@@ -96,7 +96,7 @@ struct vlsat_ctx {
     int gemm_no_dma = 0, gate_grid = 0, gate_row_map = 1, gate_heads_mfma = 1, flash_heads_bf16 = 1, gate_heads_bf16 = 1;      // vlsat_debug_option
     int gemm_no_p8 = 0;                      // vlsat_debug_option "gemm_p8": 0 keeps half-row launches off the 8-phase kernel
     int node_attn_split = 1024;              // node attention: sixteen lanes per query when the plan has fewer waves than this
-    long config_epoch = 0;                   // bumped by every call that changes what a forward launches (graphs are re-captured)
+    long config_epoch = 0;                   // bumped by every call that changes what a forward launches 
     int gemm_splitk = 1;                     // small GEMM launches take the split-K kernel (gemm_splitk.hip)
     float* sk_ws[3] = {nullptr, nullptr, nullptr};    // its workspace + counters, one set per lane: [0] launch stream, [1] / [2] the side streams
     unsigned* sk_cnt[3] = {nullptr, nullptr, nullptr};
@@ -119,11 +119,6 @@ struct vlsat_ctx {
     // scene; hipMalloc/hipFree per scene would dominate small scenes), pinned upload buffers, spare events
     std::vector<vlsat::Arena> arena_pool;
     std::vector<vlsat::Arena> arena_trash;          // too many pooled: freed once their last forward has completed
-    // graph executables of destroyed / re-captured plans: destroyed once their last launch has completed (hipGraphExecDestroy
-    // on an executable that is still running frees the streams its branches run on: the next hipGraphLaunch of ANY graph then
-    // crashed inside hip::Graph::UpdateStreams, one run in four of tools/latency_probe.py -- found in round 3)
-    struct DeadGraph { hipGraphExec_t g; hipEvent_t done; };
-    std::vector<DeadGraph> graph_trash;
     std::vector<vlsat::Staging> staging;
     std::vector<hipEvent_t> spare_ev;
 };
@@ -162,12 +157,6 @@ struct vlsat_plan_s {
     float* stn_ws = nullptr;                        // MODEL.feature_transform scratch (carved per phase in stn_encoder)
     size_t stn_ws_floats = 0;
     bool dual = false;
-    // hipGraph replay (vlsat_forward_graph): the captured forward of this plan for ONE set of tensor addresses
-    hipGraphExec_t graph_exec = nullptr;
-    hipEvent_t graph_done = nullptr;        // recorded behind every launch of graph_exec; the next launch -- on whatever stream --
-    bool graph_launched = false;            // waits for it first, so the event always covers EVERY launch still in flight
-    const void* graph_ptrs[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    long graph_epoch = -1;                  // handle configuration (weights / precision / options) it was captured under
     float *NP2 = nullptr, *Hbig2 = nullptr, *KP2 = nullptr, *G2 = nullptr, *T768b = nullptr, *rs2 = nullptr, *H2b = nullptr;
     // node cross-attention: its query / output rows (the self-attention's QKVn / On may be in use on another lane) and the
     // key | value projection of X3 [kvx_slots][N, 2 D], computed on the 3D lane right after the self-attention (so that gcn_3ds may
@@ -205,6 +194,5 @@ int split_all_weights(vlsat_ctx* h);
 hipEvent_t take_event(vlsat_ctx* h);
 void give_event(vlsat_ctx* h, hipEvent_t e);
 void release_plan_resources(vlsat_ctx* h);       // frees pools (vlsat_destroy)
-void retire_graph(vlsat_ctx* h, vlsat_plan_s* p); // p's graph executable (if any) -> graph_trash; sweeps what has completed
 
 }  // namespace vlsat

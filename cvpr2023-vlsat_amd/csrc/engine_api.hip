@@ -214,8 +214,10 @@ int vlsat_k_flash_attn_bf16(const float* Q, const float* K, const float* V, floa
     hipStream_t st = static_cast<hipStream_t>(stream);
     VLSAT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d), tiles.size() * sizeof(int4)));
     VLSAT_HIP_CHECK(hipMemcpy(d, tiles.data(), tiles.size() * sizeof(int4), hipMemcpyHostToDevice));
+    FlashSplit sp;                              // (no split keys; rows = the tensors' rows: lets the half-row variant take its LDS-direct staging)
+    sp.rows = (int)tok_ptr[n_scenes];
     int r = launch_flash_attn_bf16(Q, ld, K, V, ld, O, ld, d, (int)tiles.size(), scale * 1.4426950408889634f, terms, use_tr != 0,
-                                   use_tr == 2 ? 1 : use_tr == 3 ? 2 : 0, st);
+                                   use_tr == 2 ? 1 : use_tr == 3 ? 2 : 0, st, &sp);
     hipStreamSynchronize(st);     // test entry point only: the tile table is freed right away
     hipFree(d);
     return r;

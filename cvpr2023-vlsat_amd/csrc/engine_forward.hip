@@ -301,20 +301,16 @@ extern "C" {
 // -------------------------------------------------------------------------------------------
 struct TrainOut { float *mimic3d, *mimic2d, *edge_dis; };
 
-// capture: the call is being recorded into a hipGraph (vlsat_forward_graph): nothing that touches events owned by the plan
-// or queries the device may happen in here then -- the caller has done the upload wait and records last_use itself.
 static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const float* f2d, const float* desc,
-                        float* obj3d, float* obj2d, float* rel3d, float* rel2d, const TrainOut* tr, void* stream,
-                        bool capture);
+                        float* obj3d, float* obj2d, float* rel3d, float* rel2d, const TrainOut* tr, void* stream);
 
 // A forward that fails half way has already enqueued kernels on the plan's arena (possibly on the side stream too): every
 // exit path joins the side stream into the caller's and records the plan's last-use event, so that vlsat_plan_destroy never
 // recycles the arena behind a stale or never-recorded event (the contract of vlsat.h).
 static int forward_impl(vlsat_handle h, vlsat_plan p, const float* pts, const float* f2d, const float* desc,
-                        float* obj3d, float* obj2d, float* rel3d, float* rel2d, const TrainOut* tr, void* stream,
-                        bool capture = false) {
-    const int rc = forward_body(h, p, pts, f2d, desc, obj3d, obj2d, rel3d, rel2d, tr, stream, capture);
-    if (rc != 0 && !capture && h && p && p->h == h && p->used) {
+                        float* obj3d, float* obj2d, float* rel3d, float* rel2d, const TrainOut* tr, void* stream) {
+    const int rc = forward_body(h, p, pts, f2d, desc, obj3d, obj2d, rel3d, rel2d, tr, stream);
+    if (rc != 0 && h && p && p->h == h && p->used) {
         hipStream_t s = static_cast<hipStream_t>(stream);
         const std::string msg = last_error_cstr();                    // (the calls below must not replace the real error)
         for (hipStream_t side : {h->side, h->side2}) {
@@ -333,8 +329,7 @@ static int forward_impl(vlsat_handle h, vlsat_plan p, const float* pts, const fl
 }
 
 static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const float* f2d, const float* desc,
-                        float* obj3d, float* obj2d, float* rel3d, float* rel2d, const TrainOut* tr, void* stream,
-                        bool capture) {
+                        float* obj3d, float* obj2d, float* rel3d, float* rel2d, const TrainOut* tr, void* stream) {
     if (!h || !p || !pts || !desc || !obj3d) return fail(VLSAT_EINVAL, "vlsat_forward: null argument");
     if (p->h != h) return fail(VLSAT_EINVAL, "plan belongs to a different handle");
     // a weight reload is open (vlsat_load_weight after a finalize freed the device weights): nothing may launch on them
@@ -349,12 +344,12 @@ static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const fl
     const int N = (int)p->N, E = (int)p->E, D = h->D, L = h->d.n_layers, LDX = ldx_of(h);
     const int stop = h->debug_stop;
     h->cur_N = N;
-    if (p->upload_pending && !capture) {   // the plan's index tables travel on the handle's copy stream
+    if (p->upload_pending) {   // the plan's index tables travel on the handle's copy stream
         VLSAT_HIP_CHECK(hipStreamWaitEvent(s, p->uploaded, 0));
         if (hipEventQuery(p->uploaded) == hipSuccess) p->upload_pending = false;
     }
     p->used = true;
-    if (!capture) profile_close(h, s);     // an interval left open by a failed forward must not span foreign work
+    profile_close(h, s);                   // an interval left open by a failed forward must not span foreign work
 #define STAGE(id) do { if (stop == (id)) { profile_close(h, s); hipEventRecord(p->last_use, s); return 0; } } while (0)
 
     // Lanes.  A two-stream plan (p->dual: it owns a second scratch set) runs the forward on up to three streams that always end
@@ -369,7 +364,7 @@ static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const fl
     // latency-bound node-row launches and GEMM tails of one lane execute under the non-persistent attention / gate kernels of
     // another.  "sched" = 0: the fork / join schedule of round 4 (u = t; the lanes meet twice per layer).  The launches, their
     // operands and therefore the results are the same in both; not while stopping at a debug stage or for the training outputs.
-    const bool dual = p->dual && do2d && (!h->prof || capture || h->prof_dual) && stop < 0 && !tr;
+    const bool dual = p->dual && do2d && (!h->prof || h->prof_dual) && stop < 0 && !tr;
     const bool exact = dual && (h->sched < 0 ? h->prec_edge != 0 : h->sched != 0);
     hipStream_t t = s, u = s;
     size_t ev_i = 0;
@@ -399,7 +394,7 @@ static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const fl
     };
     auto wait = [&](hipStream_t y, hipEvent_t e) -> int {
         if (!dual || !e) return 0;
-        if (!capture) profile_close(h, y);
+        profile_close(h, y);
         VLSAT_HIP_CHECK(hipStreamWaitEvent(y, e, 0));
         return 0;
     };
@@ -616,11 +611,11 @@ static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const fl
         RUN(obj_head(h, p, u, p->X2, h->obj2_w, h->obj2_b, obj2d, sc2));
     }
     if (dual) {                                               // every lane ends joined into the caller's stream
-        if (!capture) { profile_close(h, t); profile_close(h, u); }
+        profile_close(h, t);
+        profile_close(h, u);
         RUN(order(t, s));
         if (u != t) RUN(order(u, s));
     }
-    if (capture) return 0;
     profile_close(h, s);
     VLSAT_HIP_CHECK(hipEventRecord(p->last_use, s));
 #undef STAGE
@@ -643,59 +638,6 @@ int vlsat_forward_train(vlsat_handle h, vlsat_plan p, const float* pts, const fl
         return fail(VLSAT_EINVAL, "vlsat_forward_train: null output");
     const TrainOut tr{obj_feature_3d_mimic, obj_features_2d_mimic, gcn_edge_feature_2d_dis};
     return forward_impl(h, p, pts, f2d, desc, obj3d, obj2d, rel3d, rel2d, &tr, stream);
-}
-
-// vlsat_forward through a hipGraph: the first call for a (plan, tensor addresses, handle configuration) triple records the
-// forward's launches -- both streams of a two-stream plan included -- into a graph; later calls with the same triple
-// replay it with one hipGraphLaunch.  Any other addresses / a changed configuration re-capture.  `stream` must be a
-// capturable stream (not the NULL stream).  Profiling and debug stages fall back to vlsat_forward.
-int vlsat_forward_graph(vlsat_handle h, vlsat_plan p, const float* pts, const float* f2d, const float* desc,
-                        float* obj3d, float* obj2d, float* rel3d, float* rel2d, void* stream) {
-    if (!h || !p) return fail(VLSAT_EINVAL, "vlsat_forward_graph: null argument");
-    if (!h->finalized) {                    // (a captured graph holds the freed weight pointers: drop it as well)
-        retire_graph(h, p);
-        return fail(VLSAT_ESTATE, "vlsat_forward_graph: weights are not finalised (a reload is in progress or failed)");
-    }
-    if (h->prof || h->debug_stop >= 0) return forward_impl(h, p, pts, f2d, desc, obj3d, obj2d, rel3d, rel2d, nullptr, stream);
-    if (!stream) return fail(VLSAT_EINVAL, "vlsat_forward_graph: the NULL stream cannot be captured; pass a created stream");
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const void* ptrs[7] = {pts, f2d, desc, obj3d, obj2d, rel3d, rel2d};
-    if (p->upload_pending) {               // outside the capture: events owned by the plan
-        VLSAT_HIP_CHECK(hipStreamWaitEvent(s, p->uploaded, 0));
-        if (hipEventQuery(p->uploaded) == hipSuccess) p->upload_pending = false;
-    }
-    bool same = p->graph_exec && p->graph_epoch == h->config_epoch;
-    for (int i = 0; same && i < 7; ++i) same = p->graph_ptrs[i] == ptrs[i];
-    if (!same) {
-        retire_graph(h, p);                // (its last launch may still be running)
-        if (p->dual && !h->side) VLSAT_HIP_CHECK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
-        if (p->dual && !h->side2) VLSAT_HIP_CHECK(hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking));
-        h->sync_ev.reserve(128);            // (events of the fork / join points are created on demand: fine during capture)
-        VLSAT_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
-        const int rc = forward_impl(h, p, pts, f2d, desc, obj3d, obj2d, rel3d, rel2d, nullptr, stream, true);
-        hipGraph_t g = nullptr;
-        const hipError_t e = hipStreamEndCapture(s, &g);
-        if (rc) { if (g) hipGraphDestroy(g); return rc; }
-        if (e != hipSuccess || !g) return fail(VLSAT_EHIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
-        const hipError_t ei = hipGraphInstantiate(&p->graph_exec, g, nullptr, nullptr, 0);
-        hipGraphDestroy(g);
-        if (ei != hipSuccess) { p->graph_exec = nullptr; return fail(VLSAT_EHIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ei)); }
-        for (int i = 0; i < 7; ++i) p->graph_ptrs[i] = ptrs[i];
-        p->graph_epoch = h->config_epoch;
-        p->graph_done = take_event(h);
-        p->graph_launched = false;
-        if (!p->graph_done) { retire_graph(h, p); return fail(VLSAT_EHIP, "vlsat_forward_graph: cannot create an event"); }
-    }
-    // One event per executable: a replay on ANOTHER stream first waits (on the device) for the previous launch, so that
-    // graph_done, re-recorded below, still stands for every launch in flight when retire_graph / plan_destroy test it
-    // (the workspace is not re-entrant anyway: two overlapping replays of one plan would race on it).
-    if (p->graph_launched) VLSAT_HIP_CHECK(hipStreamWaitEvent(s, p->graph_done, 0));
-    p->graph_launched = true;
-    VLSAT_HIP_CHECK(hipGraphLaunch(p->graph_exec, s));
-    VLSAT_HIP_CHECK(hipEventRecord(p->graph_done, s));
-    p->used = true;
-    VLSAT_HIP_CHECK(hipEventRecord(p->last_use, s));
-    return 0;
 }
 
 int vlsat_profile_enable(vlsat_handle h, int32_t enable) {

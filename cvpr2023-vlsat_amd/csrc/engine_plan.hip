@@ -45,31 +45,7 @@ static void sweep_trash(vlsat_ctx* h, bool force) {
     }
 }
 
-static void sweep_graphs(vlsat_ctx* h, bool force) {
-    for (size_t i = 0; i < h->graph_trash.size();) {
-        auto& d = h->graph_trash[i];
-        if (force || !d.done || hipEventQuery(d.done) == hipSuccess) {
-            hipGraphExecDestroy(d.g);
-            give_event(h, d.done);
-            h->graph_trash.erase(h->graph_trash.begin() + i);
-        } else {
-            ++i;
-        }
-    }
-}
-
-void retire_graph(vlsat_ctx* h, vlsat_plan_s* p) {
-    if (p->graph_exec) {
-        h->graph_trash.push_back({p->graph_exec, p->graph_done});
-        p->graph_exec = nullptr;
-        p->graph_done = nullptr;
-        p->graph_launched = false;
-    }
-    sweep_graphs(h, false);
-}
-
 void release_plan_resources(vlsat_ctx* h) {
-    sweep_graphs(h, true);                 // (vlsat_destroy has waited for the device)
     sweep_trash(h, true);
     for (auto& a : h->arena_pool) { hipFree(a.p); if (a.last) hipEventDestroy(a.last); }
     h->arena_pool.clear();
@@ -357,7 +333,6 @@ int vlsat_plan_create(vlsat_handle h, const int64_t* bid, const int64_t* edges, 
 void vlsat_plan_destroy(vlsat_plan p) {
     if (!p) return;
     vlsat_ctx* h = p->h;
-    retire_graph(h, p);                    // (a launch may still be in flight: destroyed when its event has completed)
     if (p->arena) {
         // The forward that used this workspace may still be in flight: the arena keeps the event of that forward (or
         // of the upload, if the plan never ran) and whoever takes it next waits for it ON THE DEVICE.  No host wait.
@@ -384,6 +359,25 @@ int vlsat_plan_info(vlsat_plan p, int32_t* n_scenes, size_t* ws, int32_t* is_fc)
     if (n_scenes) *n_scenes = p->S;
     if (ws) *ws = p->ws_bytes;
     if (is_fc) *is_fc = p->is_fc;
+    return 0;
+}
+
+// Does a DEVICE copy of the graph equal what this plan was built from?  *mismatches (device int32, zeroed by the caller) gets the
+// number of edge columns of edges_dev [2,E] (int64) that differ from the plan's (from, to) tables plus the nodes at which
+// batch_ids_dev (int64 [N], may be NULL) starts a run where the plan has no scene boundary or vice versa.  Asynchronous on
+// `stream`.  For callers that name a graph by a key instead of handing the edge list over the host (VLSATModel's `fc_sizes`
+// hint with device tensors): one call per new key makes the key's claim checked instead of trusted -- a wrongly ordered edge
+// list would otherwise attribute every rel_cls row to the wrong edge (reference edge order: dataset_3dssg.py:264-266).
+int vlsat_plan_check_graph(vlsat_plan p, const int64_t* edges_dev, const int64_t* batch_ids_dev, int32_t* mismatches, void* stream) {
+    if (!p || !mismatches || (p->E > 0 && !edges_dev)) return fail(VLSAT_EINVAL, "vlsat_plan_check_graph: null argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (p->upload_pending) {               // the plan's tables travel on the handle's copy stream
+        VLSAT_HIP_CHECK(hipStreamWaitEvent(s, p->uploaded, 0));
+        if (hipEventQuery(p->uploaded) == hipSuccess) p->upload_pending = false;
+    }
+    RUN(launch_check_graph(edges_dev, p->E, p->d_src, p->d_dst, batch_ids_dev, p->N, p->d_scene_ptr, p->S, mismatches, s));
+    p->used = true;                        // (the arena's next owner must order behind this read)
+    VLSAT_HIP_CHECK(hipEventRecord(p->last_use, s));
     return 0;
 }
 

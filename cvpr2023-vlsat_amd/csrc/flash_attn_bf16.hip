@@ -22,6 +22,8 @@
 //   implementation the transpose-read path is tested against.
 // Split keys (plans that cannot fill the chip) and the output transpose through LDS are as in flash_attn_f32.hip.
 // Roofline: bf16 MFMA, 2.5 PF / TERMS; algorithmic work 4*T^2*64 flop per (scene, head).
+#include <type_traits>
+
 #include "gemm_core.h"
 #include "kernels.h"
 
@@ -40,6 +42,29 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 template <int N> __device__ __forceinline__ void fb_wait_vm() {
     static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// max of three without the canonicalising v_max hipcc puts in front of an fmaxf on MFMA results
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+// packed fp32 pairs: one full-rate VALU instruction for two values.  Inline asm is invisible to hipcc's hazard recogniser: on
+// gfx950 a VALU instruction that reads the result of a transcendental one (v_exp_f32) needs a wait state in between, which the
+// compiler inserts only before instructions it knows to be VALU -- hence the s_nop in front of the add that takes the exponentials
+// (found by the kernel tests: without it the row sums used stale registers).
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("s_nop 0\n\tv_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, float m) {      // {a.x - m, a.y - m}
+    f32x2 d;
+    const f32x2 mm = {m, m};
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(mm));
+    return d;
 }
 
 __device__ __forceinline__ void split4(const f32x4& x, bf16x4& hi, bf16x4& lo) {
@@ -254,14 +279,19 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bf16_kernel(
         __syncthreads();
     }
 
+    // One key tile.  SLOT: the tile's LDS buffer as a compile-time constant where the loop below can provide it (two-buffer
+    // configurations: the loop is unrolled by two, so every LDS address of the iteration is lane constant + immediate -- the
+    // run-time slot cost ~40 VALU address instructions per tile in a kernel that is VALU-bound, round 5), else -1 = `ring`.
     int ring = 0;                                          // (DMA) buffer of tile kt
-    for (int kt = kt0; kt < kt1; ++kt) {
-        const char* sK = smem + (DMA ? ring : (kt & 1)) * BUF;
+    auto tile_step = [&](int kt, auto slotc) __attribute__((always_inline)) {
+        constexpr int SLOT = decltype(slotc)::value;
+        const int buf_i = SLOT >= 0 ? SLOT : (DMA ? ring : (kt & 1));
+        const char* sK = smem + buf_i * BUF;
         const char* sV = sK + (DMA ? KBYTES : PL * FB_KPLANE);
         const bool more = kt + 1 < kt1;
         if (DMA) {
             // tile kt + LA goes into the buffer tile kt - 1 was read from: every wave passed the barrier that ended iteration kt - 1
-            if (kt + LA < kt1 && !(sp.ablate & 1)) dma_tile((kt + LA) * FB_KV, smem + (ring == 0 ? NBUF - 1 : ring - 1) * BUF);
+            if (kt + LA < kt1 && !(sp.ablate & 1)) dma_tile((kt + LA) * FB_KV, smem + (buf_i == 0 ? NBUF - 1 : buf_i - 1) * BUF);
         } else if (more && !(sp.ablate & 1)) load_tile((kt + 1) * FB_KV);
 
         if (wave_active) {
@@ -290,6 +320,12 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bf16_kernel(
                     s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh1, qh[ks], s[1], 0, 0, 0);
                 }
             }
+            // The first readers of the score registers below are inline-asm VALU instructions, which hipcc's hazard recogniser
+            // does not see: the wait states between an MFMA's register write and a VALU read of it (19 for a 16-pass MFMA; the
+            // hardware has no interlock there) are inserted by hand.  The asm names the accumulators, so it cannot move above the
+            // MFMAs, and everything that reads them is ordered behind it.  (Found by the kernel tests: without it the maxima were
+            // taken from stale registers.)
+            asm volatile("s_nop 15\n\ts_nop 3" : "+v"(s[0]), "+v"(s[1]));
             // keys outside [key_lo, key_hi): beyond the scene's tokens (last tile) or another part's (split mode)
             const int kv0 = kt * FB_KV;
             if (kv0 < key_lo || kv0 + FB_KV > key_hi) {
@@ -302,22 +338,37 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bf16_kernel(
                     }
             }
             // ---- online softmax for this lane's query ----
-            float mx = fmaxf(s[0][0], s[1][0]);
+            // The kernel is bound by VALU issue at head dim 64 (round 4 PMC: matrix pipe 35 % busy; per tile and wave 512 MFMA cycles
+            // against ~1100 of VALU), so the softmax is written for instruction count (round 5): the maximum of the 32 scores with
+            // v_max3_f32 (two new values per instruction; fmaxf costs a canonicalising v_max per MFMA result on top of the max itself:
+            // 54 -> 16 instructions), score - m and the row sum as packed fp32 pairs (v_pk_add_f32: 33 + 33 -> 16 + 16); the 32
+            // quarter-rate v_exp_f32 stay.
+            float mx;
+            {
+                float ma = max3f(s[0][0], s[0][1], s[0][2]), mb = max3f(s[1][0], s[1][1], s[1][2]);    // two chains: no max waits for its predecessor
 #pragma unroll
-            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s[0][r], s[1][r]));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float m_new = fmaxf(m_run, mx);
+                for (int r = 3; r < 15; r += 2) { ma = max3f(ma, s[0][r], s[0][r + 1]); mb = max3f(mb, s[1][r], s[1][r + 1]); }
+                mx = max3f(ma, mb, s[0][15]);
+                mx = max3f(mx, s[1][15], s[1][15]);
+            }
+            mx = max3f(mx, __shfl_xor(mx, 32), mx);
+            const float m_new = max3f(m_run, mx, mx);
             // (a part whose first tile is fully masked for this query keeps m = -inf; exp2(-inf - -inf) must not be NaN)
             const float m_use = m_new == -INFINITY ? 0.f : m_new;
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
-            float rs = 0.f;
+            f32x2 rs2 = {0.f, 0.f};
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    s[kb][r] = __builtin_amdgcn_exp2f(s[kb][r] - m_use);
-                    rs += s[kb][r];
+                for (int r = 0; r < 16; r += 2) {
+                    f32x2 x = pk_sub(f32x2{s[kb][r], s[kb][r + 1]}, m_use);
+                    x[0] = __builtin_amdgcn_exp2f(x[0]);
+                    x[1] = __builtin_amdgcn_exp2f(x[1]);
+                    rs2 = pk_add(rs2, x);
+                    s[kb][r] = x[0];
+                    s[kb][r + 1] = x[1];
                 }
+            float rs = rs2[0] + rs2[1];
             rs += __shfl_xor(rs, 32);
             l_run = l_run * alpha + rs;
             m_run = m_new;
@@ -385,6 +436,14 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bf16_kernel(
             if (more && !(sp.ablate & 2)) store_tile(smem + ((kt + 1) & 1) * BUF);
             __syncthreads();
         }
+    };
+    if (DMA && NBUF == 2) {                                 // the first tile of the range sits in buffer 0
+        for (int kt = kt0; kt < kt1; kt += 2) {
+            tile_step(kt, std::integral_constant<int, 0>{});
+            if (kt + 1 < kt1) tile_step(kt + 1, std::integral_constant<int, 1>{});
+        }
+    } else {
+        for (int kt = kt0; kt < kt1; ++kt) tile_step(kt, std::integral_constant<int, -1>{});
     }
 
     // ---- normalise (or, in split mode, keep un-normalised and record m, l), transpose through LDS
@@ -452,6 +511,11 @@ int launch_flash_attn_bf16(const float* Q, int ldq, const float* K, const float*
             return fail(-1, "flash_attn: incomplete split-key workspace");
     }
     if (split) sp.ablate = split->ablate;
+    // The LDS-direct K / V staging addresses a scene with 32-bit byte offsets (buffer descriptor of n_tok * ldkv * 4 bytes, row * ld4
+    // VGPR offsets): only where every scene's rows are known to span less than 4 GiB -- the caller states the rows of the whole
+    // tensor in FlashSplit::rows (an upper bound of any scene, and of the batch-wide attention of batch_mode 'reference').  Unknown
+    // or larger: the register-staged kernel, which addresses rows with size_t.
+    if (io_split == 2 && use_tr && use_tr != 2 && !(split && split->rows > 0 && (size_t)split->rows * (size_t)ldkv * 4 < (1ull << 32))) use_tr = 2;
 #define VLSAT_FA(T, R, S) hipLaunchKernelGGL((flash_attn_bf16_kernel<T, R, S>), dim3(n_tiles), dim3(256), 0, s, Q, K, V, O, ldq, ldkv, ldo, tiles, n_tiles, scale_log2e, sp)
 #define VLSAT_FAD(T, S, P, D) hipLaunchKernelGGL((flash_attn_bf16_kernel<T, true, S, P, D>), dim3(n_tiles), dim3(256), 0, s, Q, K, V, O, ldq, ldkv, ldo, tiles, n_tiles, scale_log2e, sp)
     if (FB_D != 64) {          // 16 / 4 heads: the formats the forward uses (the transpose-read path; split-bf16 only at 32)
@@ -469,8 +533,7 @@ int launch_flash_attn_bf16(const float* Q, int ldq, const float* K, const float*
     } else
     if (io_split == 2) {
         if (!use_tr || terms != 1) return fail(-1, "flash_attn_bf16: half-row tensors need terms = 1 and the transpose-read path");
-        // LDS-direct K/V staging (scene-relative 32-bit byte offsets: a scene of < 2^32 / (4 ldkv) rows, which the GEMM launchers'
-        // own 32-bit guards already imply).  Measured on one box, interleaved (profiles/r04_probes/flash_bf16_dma_ab.txt): register-
+        // LDS-direct K/V staging (scene-relative 32-bit byte offsets: checked above).  Measured on one box, interleaved (profiles/r04_probes/flash_bf16_dma_ab.txt): register-
         // staged 596 TFLOP/s; ring of 3 buffers (3 blocks per CU) 745-773; ring of 4 (2 blocks per CU) 650-659; ring of 2 = one
         // tile ahead with FOUR blocks per CU (34 KB of LDS, 120 VGPRs) 813-817: occupancy beats look-ahead depth.
         if (use_tr == 3)            // (experiments: vlsat_debug_option "flash_dma" 3 | 4 = rings of three / four buffers)

@@ -7,7 +7,10 @@
 namespace vlsat {
 
 // max into a float cell from concurrent waves: in the integer order of IEEE bit patterns a non-negative value wins by signed max,
-// a negative one by unsigned min (the cell starts at -inf or holds another run's result); exact and order-independent
+// a negative one by unsigned min (the cell starts at -inf or holds another run's result); exact and order-independent FOR FINITE
+// VALUES, where it returns the bits of the separate CSR aggregate kernel.  Corner cases differ and are not promised: a -0.0 / +0.0
+// tie resolves to +0.0 here; a NaN from an upstream overflow may win (positive bit pattern), be dropped (negative), or be dropped
+// by the per-lane fmaxf pre-reduction, where the aggregate kernel's fmaxf chain drops it always.
 __device__ __forceinline__ void atomic_max_f32(float* p, float x) {
     const int b = __float_as_int(x);
     if (b >= 0) atomicMax(reinterpret_cast<int*>(p), b);

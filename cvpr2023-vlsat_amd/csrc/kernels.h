@@ -205,6 +205,10 @@ int launch_scene_checksums(const float* obj3d, const float* obj2d, long N, int C
 // ---- per-object input preparation ----
 int launch_prepare_objects(const float* scene, const int32_t* choice, int N, int P, float* obj_points, float* desc,
                            hipStream_t s);
+// *mismatches += rows of a DEVICE edge list [2,E] (int64) that differ from a plan's own (src, dst) tables, + nodes whose batch id
+// run structure differs from the plan's scene partition (batch_ids may be null)
+int launch_check_graph(const int64_t* edges, int64_t n_edges, const int32_t* src, const int32_t* dst, const int64_t* batch_ids,
+                       int64_t n_nodes, const int32_t* scene_ptr, int n_scenes, int32_t* mismatches, hipStream_t s);
 int launch_fc_edges(const int32_t* node_ptr, const int64_t* edge_ptr, int n_scenes, int64_t n_nodes, int64_t n_edges,
                     int64_t* edges, int64_t* batch_ids, hipStream_t s);
 

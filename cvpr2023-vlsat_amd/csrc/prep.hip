@@ -81,6 +81,33 @@ __global__ void fc_edges_kernel(const int32_t* __restrict__ node_ptr, const int6
     edges[n_edges + e] = node_ptr[lo] + jj + (jj >= i);
 }
 
+// mismatches += #{e : (edges[e], edges[E + e]) != (src[e], dst[e])} + #{i : batch_ids starts a new run at i  XOR  i is a scene start}
+__global__ void check_graph_kernel(const int64_t* __restrict__ edges, int64_t n_edges, const int32_t* __restrict__ src,
+                                   const int32_t* __restrict__ dst, const int64_t* __restrict__ batch_ids, int64_t n_nodes,
+                                   const int32_t* __restrict__ scene_ptr, int n_scenes, int32_t* __restrict__ mismatches) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int bad = 0;
+    if (i < n_edges) bad += edges[i] != (int64_t)src[i] || edges[n_edges + i] != (int64_t)dst[i];
+    if (batch_ids && i < n_nodes) {
+        int lo = 0, hi = n_scenes - 1;
+        while (lo < hi) { const int m = (lo + hi + 1) >> 1; if (scene_ptr[m] <= i) lo = m; else hi = m - 1; }
+        const bool start = scene_ptr[lo] == i;
+        bad += i > 0 && ((batch_ids[i] != batch_ids[i - 1]) != start);
+    }
+    const unsigned long long any = __ballot(bad != 0);
+    if (any && (threadIdx.x & 63) == 0) atomicAdd(mismatches, (int)__popcll(any));
+}
+
+int launch_check_graph(const int64_t* edges, int64_t n_edges, const int32_t* src, const int32_t* dst, const int64_t* batch_ids,
+                       int64_t n_nodes, const int32_t* scene_ptr, int n_scenes, int32_t* mismatches, hipStream_t s) {
+    const int64_t work = n_edges > n_nodes ? n_edges : n_nodes;
+    if (work <= 0) return 0;
+    hipLaunchKernelGGL(check_graph_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, edges, n_edges, src, dst,
+                       batch_ids, n_nodes, scene_ptr, n_scenes, mismatches);
+    VLSAT_LAUNCH_CHECK("check_graph");
+    return 0;
+}
+
 int launch_prepare_objects(const float* scene, const int32_t* choice, int N, int P, float* obj_points, float* desc,
                            hipStream_t s) {
     if (N <= 0) return 0;

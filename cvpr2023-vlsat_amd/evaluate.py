@@ -106,12 +106,29 @@ def summarize(vec: np.ndarray, n_rel: int = N_REL) -> Dict[str, float]:
     return out
 
 
+_warned_sync = False
+
+
 def _n_scenes(b) -> int:
+    """Scenes in a batch.  ``n_scenes`` / ``fc_sizes`` are what the pipelined loop (validation(workers >= 1)) needs to stay free
+    of host round trips: without either the count is read back from ``batch_ids`` on the device -- a blocking copy per batch on
+    the worker's stream (and the forward then also reads the edge list back to key its plan).  Correct, but the loop runs at the
+    latency of every scene; said once."""
     if "n_scenes" in b:
         return int(b["n_scenes"])
     if "fc_sizes" in b:
         return len(b["fc_sizes"])
-    return int(b["batch_ids"].max().item()) + 1 if b["batch_ids"].numel() else 0
+    if not b["batch_ids"].numel():
+        return 0
+    if b["batch_ids"].is_cuda:
+        global _warned_sync
+        if not _warned_sync:
+            _warned_sync = True
+            import warnings
+            warnings.warn("evaluate: batch without 'n_scenes' / 'fc_sizes' -- the scene count (and the plan key) are read back from "
+                          "the device for every batch, which serialises the loop; add one of the hints to the loader's items",
+                          RuntimeWarning, stacklevel=3)
+    return int(b["batch_ids"].max().item()) + 1
 
 
 def merge_batches(bs) -> dict:

@@ -42,9 +42,9 @@ _SIGNATURES = {
     "vlsat_plan_create": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i32, C.POINTER(_vp)]),
     "vlsat_plan_destroy": (None, [_vp]),
     "vlsat_plan_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_sz), C.POINTER(_i32)]),
+    "vlsat_plan_check_graph": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "vlsat_forward": (C.c_int, [_vp] * 9 + [_vp]),
     "vlsat_forward_train": (C.c_int, [_vp] * 12 + [_vp]),
-    "vlsat_forward_graph": (C.c_int, [_vp] * 9 + [_vp]),
     "vlsat_set_gemm_precision": (C.c_int, [_vp, _i32]),
     "vlsat_set_edge_attention_scope": (C.c_int, [_vp, _i32]),
     "vlsat_profile_enable": (C.c_int, [_vp, _i32]),

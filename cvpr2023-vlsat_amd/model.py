@@ -61,6 +61,8 @@ class VLSATModel:
         self._zero_bid = {}
         self._plans: "OrderedDict[tuple, _Plan]" = OrderedDict()
         self._ident: "OrderedDict[tuple, tuple]" = OrderedDict()     # (id(edge tensor), id(batch tensor)) -> plan key
+        self._fc_verified = set()           # fc_sizes keys whose device edge list has been checked against the canonical graph
+        self._debug_options = {}            # vlsat_debug_option settings applied to this handle (replayed by replicate())
         self.plan_stats = {"hits": 0, "identity_hits": 0, "builds": 0, "d2h_copies": 0}
         self.training = False
         self.gemm_precision = "fp32"
@@ -134,8 +136,10 @@ class VLSATModel:
         'flash_bf16', 'flash_tr', 'flash_dma', 'gate_fuse_agg', 'flash_pv_terms', 'pointnet_bf16', 'gate_bf16', 'ln_resid', 'gemm_p8').  Defaults are the
         measured-best settings; none changes results beyond floating-point summation order / the mode's rounding."""
         L.check(self._lib.vlsat_debug_option(self._h, name.encode(), int(value)))
+        self._debug_options[name] = int(value)
         if name in ("dual_stream", "flash_split"):
             self._drop_plans()
+        self._drop_replicas()                   # (replicas built before this call run another kernel configuration)
         return self
 
     def _drop_plans(self):
@@ -203,7 +207,7 @@ class VLSATModel:
         return self
 
     def replicate(self) -> "VLSATModel":
-        """A second model with the same configuration, weights, precision and batch mode on the same GPU: its own library
+        """A second model with the same configuration, weights, precision, batch mode and debug options on the same GPU: its own library
         handle, plans and scratch, so it can be driven from another host thread on another stream at the same time
         (a handle serves one thread and one stream at a time, include/vlsat.h).  evaluate.validation(workers=K) uses K - 1."""
         if not self._loaded:
@@ -214,6 +218,8 @@ class VLSATModel:
             m.set_gemm_precision(self.gemm_precision)
         if self.batch_mode != "per_scene":
             m.set_batch_mode(self.batch_mode)
+        for name, value in self._debug_options.items():      # same kernel configuration as this model (A/B runs with workers > 1)
+            m.debug_option(name, value)
         m.training = self.training
         return m
 
@@ -267,9 +273,11 @@ class VLSATModel:
     def _plan(self, edge_indices, batch_ids, n, p, fc_sizes: Optional[Sequence[int]] = None) -> _Plan:
         """Plan for this graph, from a content-keyed LRU cache.  In order of cost:
           1. ``fc_sizes`` given: the caller states that edge_indices IS the canonical fully-connected edge list of
-             scenes with these object counts (source-major, ``synth.fc_edges`` order) -> key (sizes, P); nothing is read
-             from the device.  Host-side edge tensors are compared with the canonical list; device tensors are taken
-             on trust (UNCHECKED: a different order would attribute every rel_cls row to the wrong edge);
+             scenes with these object counts (source-major, ``synth.fc_edges`` order) -> key (sizes, P).  The claim is
+             CHECKED once per new key: host-side edge tensors against the canonical list on the host, device tensors (and
+             device batch_ids) by a kernel against the new plan's own tables (``vlsat_plan_check_graph``: one 4-byte
+             read-back when the plan is built; a wrongly ordered list would attribute every rel_cls row to the wrong
+             edge).  A key that is already cached reads nothing from the device;
           2. the same tensor OBJECTS as an earlier call, unmodified -> no copy either;
           3. edge_indices / batch_ids on the host (the reference's loader yields them there) -> hashed on the host;
           4. device tensors never seen before -> one D2H copy (a stream sync) to hash them.
@@ -326,6 +334,15 @@ class VLSATModel:
             if ei is None:
                 ei, bid = self._fc_host(sizes)
             plan = self._build(ei, bid, n, p)
+            if fc_sizes is not None and (edge_indices.is_cuda or batch_ids.is_cuda) and key not in self._fc_verified:
+                try:
+                    self._check_device_graph(plan, edge_indices, batch_ids)
+                except L.VlsatError:
+                    plan.destroy()
+                    raise
+                if len(self._fc_verified) > 8192:
+                    self._fc_verified.clear()
+                self._fc_verified.add(key)         # (a key checked once stays checked when its plan is evicted and rebuilt)
             self._plans[key] = plan
             self.plan_stats["builds"] += 1
             total = sum(q.ws_bytes for q in self._plans.values())
@@ -339,6 +356,19 @@ class VLSATModel:
             while len(self._ident) > 4 * self.MAX_PLANS:
                 self._ident.popitem(last=False)
         return plan
+
+    def _check_device_graph(self, plan: "_Plan", edge_indices, batch_ids):
+        """fc_sizes with device tensors, first use of the key: the device edge list / batch ids against the plan's tables."""
+        if plan.perm is not None:
+            raise L.VlsatError("fc_sizes: the canonical edge list is grouped by scene; this plan is not")
+        flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+        ei_d = edge_indices.to(self.device).contiguous()
+        bid_d = batch_ids.to(self.device).view(-1).contiguous()
+        L.check(self._lib.vlsat_plan_check_graph(plan.handle, L.ptr(ei_d), L.ptr(bid_d), L.ptr(flag), L.stream_ptr()))
+        bad = int(flag.item())
+        if bad:
+            raise L.VlsatError(f"fc_sizes: edge_indices / batch_ids on the device are not the canonical fully-connected graph of "
+                               f"these scenes ({bad} mismatching entries)")
 
     def _build(self, ei: torch.Tensor, bid: torch.Tensor, n: int, p: int) -> _Plan:
         e = ei.shape[1]
@@ -436,37 +466,6 @@ class VLSATModel:
         if istrain:
             scale = torch.tensor(math.exp(c.obj_logit_scale), dtype=torch.float32, device=self.device)
             return (obj3, obj2, rel3, rel2) + extras + (scale,)
-        return obj3, obj2, rel3, rel2
-
-    @torch.no_grad()
-    def forward_replay(self, obj_points, obj_2d_feats, edge_indices, descriptor=None, batch_ids=None,
-                       fc_sizes: Optional[Sequence[int]] = None):
-        """``forward`` through a hipGraph (``vlsat_forward_graph``): for hosts that run the SAME graph on the SAME input
-        buffers again and again (a static serving slot).  The first call for a (graph, input addresses) pair captures
-        the forward, later calls replay it with one launch.  The four outputs are buffers owned by the plan and are
-        OVERWRITTEN by the next replay of that graph -- consume or clone them first.  Inputs must be contiguous fp32
-        CUDA tensors (anything else is converted into a fresh tensor, i.e. new addresses, i.e. a re-capture every call).
-        An evaluation loop over ever-new scenes gains nothing from this."""
-        pts, f2d, desc, n, p, e = self._inputs(obj_points, obj_2d_feats, edge_indices, descriptor)
-        c = self.config
-        with torch.cuda.device(self.device):
-            plan = self._plan(edge_indices, batch_ids, n, p, fc_sizes)
-            if plan.perm is not None:
-                raise L.VlsatError("forward_replay: edges must be grouped by scene (a permuted plan needs a gather after the graph)")
-            if getattr(plan, "graph_out", None) is None:
-                plan.graph_out = (torch.empty(n, c.num_obj_class, dtype=torch.float32, device=self.device),
-                                  torch.empty(n, c.num_obj_class, dtype=torch.float32, device=self.device),
-                                  torch.empty(e, c.num_rel_class, dtype=torch.float32, device=self.device),
-                                  torch.empty(e, c.num_rel_class, dtype=torch.float32, device=self.device))
-            if getattr(self, "_gstream", None) is None:
-                self._gstream = torch.cuda.Stream(device=self.device)      # (the NULL stream cannot be captured)
-            cur = torch.cuda.current_stream()
-            self._gstream.wait_stream(cur)
-            obj3, obj2, rel3, rel2 = plan.graph_out
-            L.check(self._lib.vlsat_forward_graph(self._h, plan.handle, pts.data_ptr(), f2d.data_ptr(), desc.data_ptr(),
-                                                  obj3.data_ptr(), obj2.data_ptr(), rel3.data_ptr(), rel2.data_ptr(),
-                                                  self._gstream.cuda_stream))
-            cur.wait_stream(self._gstream)
         return obj3, obj2, rel3, rel2
 
     @torch.no_grad()

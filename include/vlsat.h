@@ -107,6 +107,14 @@ void vlsat_plan_destroy(vlsat_plan p);
 /* n_scenes, workspace bytes, and whether the fully-connected fast paths were selected */
 int vlsat_plan_info(vlsat_plan p, int32_t* n_scenes, size_t* workspace_bytes, int32_t* is_fc);
 
+/* Does a DEVICE copy of a graph equal what this plan was built from?  *mismatches (device int32, zeroed by the caller) receives
+ * the number of columns of edges_dev ([2,E] int64, the layout Mmgnet.forward takes) that differ from the plan's edge list plus the
+ * nodes at which batch_ids_dev ([N] int64, may be NULL) starts a new run where the plan has no scene boundary (or the reverse).
+ * Asynchronous on `stream`; no host wait.  For hosts that name a graph by a key (e.g. the object counts of fully-connected
+ * scenes) instead of handing the edge list over: one call per new key makes the key's claim checked -- a permuted edge list
+ * would otherwise attribute every relation row to the wrong edge (reference edge order: src/dataset/dataset_3dssg.py:264-266). */
+int vlsat_plan_check_graph(vlsat_plan p, const int64_t* edges_dev, const int64_t* batch_ids_dev, int32_t* mismatches, void* stream);
+
 /* Mmgnet.forward(..., istrain=False), reference SGFN_MMG/model.py:288-335.
  * Device pointers: obj_points [N,dim_point,P], obj_2d_feats [N,512], descriptor [N,11];
  * outputs obj_logits_3d/2d [N,n_obj_class] (logits x exp(scale)), rel_cls_3d/2d
@@ -130,14 +138,6 @@ int vlsat_forward_train(vlsat_handle h, vlsat_plan p,
                         float* obj_feature_3d_mimic, float* obj_features_2d_mimic, float* gcn_edge_feature_2d_dis,
                         void* stream);
 
-/* vlsat_forward through a hipGraph: the first call for a (plan, tensor addresses, handle configuration) triple records the
- * forward -- every launch, both streams of a two-stream plan -- and later calls with the same triple replay it with one
- * hipGraphLaunch; other addresses or a changed configuration (weights, precision, options) re-capture.  For hosts that
- * run the same graph on static buffers; an evaluation loop over ever-new graphs gains nothing (launch
- * gaps are 6-12 % of a one-scene forward).  `stream` must be a created stream (the NULL stream cannot be captured). */
-int vlsat_forward_graph(vlsat_handle h, vlsat_plan plan, const float* obj_points, const float* obj_2d_feats,
-                        const float* descriptor, float* obj_logits_3d, float* obj_logits_2d, float* rel_cls_3d,
-                        float* rel_cls_2d, void* stream);
 
 /* Operand precision of the matrix kernels inside vlsat_forward (BASELINE configs[2], "bf16 MFMA for the
  * QKV/FFN GEMMs"): 0 = exact fp32 MFMA (default; BASELINE configs[1]); 3 = split-bf16 (a_hi.w_hi + a_lo.w_hi +

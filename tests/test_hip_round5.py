@@ -1,0 +1,86 @@
+"""Round-5 cases of the HIP path.  Needs an MI355X."""
+import numpy as np
+import pytest
+import torch
+
+import vlsat_amd  # noqa: F401
+from vlsat_amd import VLSATConfig, synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+NAMES = ("obj_logits_3d", "obj_logits_2d", "rel_cls_3d", "rel_cls_2d")
+
+
+def _model(cfg, weights):
+    from vlsat_amd.model import VLSATModel
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: the HIP path cannot run and there is no fallback")
+    return VLSATModel(cfg, DEV).load_state(weights).eval()
+
+
+def test_fc_sizes_with_a_device_edge_list_is_checked_not_trusted():
+    """`fc_sizes` names the graph by the scenes' object counts so that nothing is read back from the device.  The first use of a
+    key now runs vlsat_plan_check_graph: a DEVICE edge list that is not the canonical source-major fully-connected list of
+    those scenes (reference dataset_3dssg.py:264-266) -- here: two columns swapped, and separately batch ids with the scene
+    boundary in the wrong place -- raises instead of silently attributing every rel_cls row to the wrong edge; the canonical
+    list passes, also after the rejected attempts, and gives the outputs of the call without the hint."""
+    from vlsat_amd import lib as L
+    cfg = VLSATConfig(N_LAYERS=1)
+    m = _model(cfg, synth.make_weights(cfg))
+    sizes = [7, 12]
+    d = {k: torch.from_numpy(v).to(DEV) for k, v in synth.collate([synth.make_scene(n, 64, 300 + i) for i, n in enumerate(sizes)]).items()}
+    args = (d["obj_points"], d["obj_2d_feats"])
+    bad = d["edge_indices"].clone()
+    bad[:, [3, 40]] = bad[:, [40, 3]]
+    with pytest.raises(L.VlsatError, match="not the canonical"):
+        m(*args, bad, d["descriptor"], d["batch_ids"], fc_sizes=sizes)
+    bid = d["batch_ids"].clone()
+    bid[sizes[0]] = 0                                   # the second scene starts one node late
+    with pytest.raises(L.VlsatError, match="not the canonical"):
+        m(*args, d["edge_indices"], d["descriptor"], bid, fc_sizes=sizes)
+    builds = m.plan_stats["builds"]
+    hinted = [o.clone() for o in m(*args, d["edge_indices"], d["descriptor"], d["batch_ids"], fc_sizes=sizes)]
+    again = m(*args, d["edge_indices"], d["descriptor"], d["batch_ids"], fc_sizes=sizes)       # cached key: no build, no check
+    assert m.plan_stats["builds"] == builds + 1
+    plain = m(*args, d["edge_indices"], d["descriptor"], d["batch_ids"])
+    for n, a, b, c in zip(NAMES, hinted, again, plain):
+        assert torch.equal(a, b) and torch.equal(a, c), n
+    m.close()
+
+
+def test_flash_half_rows_beyond_4_gib_take_the_64_bit_kernel():
+    """The LDS-direct K / V staging of the half-row edge attention addresses a scene with 32-bit byte offsets; tensors whose rows
+    span 4 GiB or more (2^21 rows of 512 floats here -- a plan accepts E up to 2^30, and batch_mode 'reference' makes one
+    attention span the whole batch) must take the register-staged kernel, which addresses rows with size_t.  Checked on the
+    first and the last scene of such a tensor (the last one lies wholly beyond the 4 GiB mark)."""
+    from vlsat_amd import lib as L
+    free, _ = torch.cuda.mem_get_info()
+    if free < 24 << 30:
+        pytest.skip("needs 20 GB of free device memory")
+    l = L.load()
+    T, S = 1 << 21, 512                                  # rows, tokens per scene
+    rows = T + S
+    g = torch.Generator(device=DEV).manual_seed(11)
+    sc = 0.125 * 1.4426950408889634
+
+    def half_rows(scale=1.0):
+        x = torch.zeros(rows, 512, dtype=torch.float32, device=DEV)
+        v = (torch.randn(rows, 512, generator=g, device=DEV, dtype=torch.float32) * scale).to(torch.bfloat16)
+        x.view(torch.bfloat16).view(rows, 1024)[:, :512] = v
+        return x, v
+    q, qv = half_rows(sc)                                  # (Q arrives pre-scaled by scale * log2 e in this format)
+    k, kv = half_rows()
+    v, vv = half_rows()
+    o = torch.zeros(rows, 512, dtype=torch.float32, device=DEV)
+    tok = torch.arange(0, rows + 1, S, dtype=torch.int64)
+    L.check(l.vlsat_k_flash_attn_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), 512, tok.data_ptr(), len(tok) - 1, 8,
+                                      0.125, 1, 3, L.stream_ptr()))
+    torch.cuda.synchronize()
+    got = o.view(torch.bfloat16).view(rows, 1024)[:, :512].float()
+    for a in (0, rows - S):
+        qq = (qv[a:a + S].double() / sc).view(S, 8, 64).permute(1, 0, 2)
+        kk = kv[a:a + S].double().view(S, 8, 64).permute(1, 2, 0)
+        vh = vv[a:a + S].double().view(S, 8, 64).permute(1, 0, 2)
+        ref = (torch.softmax(qq @ kk * 0.125, -1) @ vh).permute(1, 0, 2).reshape(S, 512).float()
+        err = float((got[a:a + S] - ref).abs().max())
+        assert err < 2e-2, (a, err)

@@ -119,20 +119,6 @@ def main():
     print(f"  fresh tensors + fc_sizes hint, new sizes build a plan: {hi.mean():6.2f} ms mean ({np.median(hi):.2f} median)")
     print(f"  back to back, no host sync between scenes: {t_pipe * 1e3:6.2f} ms per scene (cached plans, found by tensor identity); "
           f"{t_pipe_hint * 1e3:.2f} (fresh tensors + fc_sizes hint); {t_pipe_hash * 1e3:.2f} (fresh tensors, no hint: edge list hashed on the host)")
-    # the same graphs once more through vlsat_forward_graph: captured in a first pass, replayed (and timed) in a second
-    for it in items:
-        n = it["obj_points"].shape[0]
-        model.forward_replay(it["obj_points"], it["obj_2d_feats"], it["edge_indices"], it["descriptor"], it["batch_ids"])
-    torch.cuda.synchronize()
-    t_rep = []
-    for it in items:
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        model.forward_replay(it["obj_points"], it["obj_2d_feats"], it["edge_indices"], it["descriptor"], it["batch_ids"])
-        torch.cuda.synchronize()
-        t_rep.append(time.perf_counter() - t0)
-    print(f"  same graphs, hipGraph replay: forward {1e3 * np.mean(t_rep):6.2f} ms mean ({1e3 * np.median(t_rep):.2f} median; "
-          f"vlsat_forward_graph, captured beforehand)")
     print(f"  plan cache: {model.plan_stats}")
     # by scene size: what is launch-bound and what is compute-bound (flops of the minimal-algebra count, bench.py f_alg)
     from bench import f_alg
