@@ -1,6 +1,9 @@
 """Build libvlsat_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
 
-    python -m vlsat_amd.build        (or: python cvpr2023-vlsat_amd/build.py)
+    python -m vlsat_amd.build        (or: python cvpr2023-vlsat_amd/build.py)        the RELEASE library
+    python cvpr2023-vlsat_amd/build.py --experiments      tools/bin/libvlsat_hip_exp.so: -DVLSAT_EXPERIMENTS -- timing-ablation
+                                                          kernels and the lab switches of vlsat_debug_option (csrc/common.h);
+                                                          `bench.py --lib tools/bin/libvlsat_hip_exp.so` and the probes load it
 
 Objects are rebuilt only when a source or header is newer.  The .so is git-ignored but
 travels to the GPU box with the repo snapshot.
@@ -37,18 +40,25 @@ def _newest_header() -> float:
     return t
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    os.makedirs(OBJ, exist_ok=True)
+EXP_LIB = os.path.join(os.path.dirname(HERE), "tools", "bin", "libvlsat_hip_exp.so")
+
+
+def build(force: bool = False, verbose: bool = False, experiments: bool = False) -> str:
+    obj_dir = OBJ + "_exp" if experiments else OBJ
+    lib = EXP_LIB if experiments else LIB
+    flags = FLAGS + (["-DVLSAT_EXPERIMENTS"] if experiments else [])
+    os.makedirs(obj_dir, exist_ok=True)
+    os.makedirs(os.path.dirname(lib), exist_ok=True)
     hipcc = _hipcc()
     hdr_t = _newest_header()
     jobs = []
     objs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(OBJ, src.replace(".hip", ".o"))
+        o = os.path.join(obj_dir, src.replace(".hip", ".o"))
         objs.append(o)
         if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr_t):
-            jobs.append([hipcc, *FLAGS, "-c", s, "-o", o])
+            jobs.append([hipcc, *flags, "-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -62,10 +72,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
         for warn in ex.map(run, jobs):
             if warn and verbose:
                 print(warn, file=sys.stderr)
-    if jobs or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB])
-    return LIB
+    if jobs or not os.path.exists(lib) or any(os.path.getmtime(o) > os.path.getmtime(lib) for o in objs):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", lib])
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, experiments="--experiments" in sys.argv))

@@ -35,28 +35,24 @@ int vlsat_set_edge_attention_scope(vlsat_handle h, int32_t scope) {
     return 0;
 }
 
-// debug / experiment switches of one handle (they replace the VLSAT_* environment variables of round 1; defaults are
-// the measured-best settings and none changes results beyond fp32 summation order):
-//   "dual_stream" 0|1|2 2D twin stages on a second stream: 1 small plans only, 2 every plan (plans created afterwards)
+// Switches of one handle (none changes results beyond fp32 summation order / the mode's rounding; defaults are the measured-best
+// settings).  The RELEASE library knows the ones a deployment or a test has a use for:
+//   "dual_stream" 0|1|2 a second (and third) stream for the 2D chains: 1 small plans only, 2 every plan (plans created afterwards)
 //   "sched"       -1|0|1  two-stream plans: dependency-exact three-lane schedule (1), the fork / join schedule of round 4 (0), or by
 //                       mode (-1, default: exact in the bf16 modes, fork / join in exact fp32)
 //   "flash_split" 0|1   split-key edge attention for plans that cannot fill the chip (plans created afterwards)
-//   "gemm_dma"    0|1   LDS-direct staging of fp32 GEMM operands (0: VGPR-staged)
-//   "gemm_p8"     0|1   single-rounding bf16 modes: large half-row launches on the 256 x 256 8-phase kernel (0: ring kernel)
-//   "gate_grid"   n     persistent grid of the gate kernel (0: default)
-//   "prof_dual"   0|1   per-class profiling keeps the two-stream execution (1, default) or serialises on the launch stream
-//   "gate_heads_bf16" 0|1   bf16 modes at other head geometries: the gate on the bf16 kernel (1, default) or the fp32 one
-//   "flash_heads_bf16" 0|1  bf16 modes at 4 / 16 heads: edge attention on the bf16 kernel (1, default) or the fp32 one
-//   "gate_heads_mfma" 0|1  non-default head geometries: the MFMA gate kernel (1, default) or the VALU one
-//   "gate_row_map" 0|1  rows of a gate wave: 32 edges of one head (1, default) or 4 edges x 8 heads (0)
-//   "node_attn_split" n  node attention with sixteen lanes per query for plans of fewer than n one-query-per-lane waves
-//   "gemm_splitk" 0|1   small GEMM launches on the split-K kernel (0: everything on the persistent kernel)
-//   "split_fmt"   0|1   bf16 modes: edge tensors between matrix kernels as bf16 hi/lo pairs (0: plain fp32, split on read)
-//   "ln_resid"    0|1   split-bf16 mode: edge-attention residual added by the LayerNorm kernel (0: in the out-projection GEMM)
-//   "half_fmt"    0|1   single-rounding modes: those tensors as plain bf16 at half the traffic (0: split pairs)
-//   "flash_bf16"  0|1   bf16 modes: edge attention on the bf16 matrix cores (0: keep the fp32 kernel)
-//   "pointnet_bf16", "gate_bf16" 0|1   bf16 modes: object encoder / edge gate on the bf16 matrix cores (0: fp32 kernels)
-//   "flash_tr"    0|1   bf16 attention: V operand by ds_read_b64_tr_b16 (0: ds_read_u16 gather)
+//   "prof_dual"   0|1   per-class profiling keeps the multi-stream execution (1, default) or serialises on the launch stream
+//   "gemm_p8" / "gemm_dma" / "gemm_splitk" 0|1   GEMM kernel selection: 256 x 256 8-phase kernel for large launches, LDS-direct staging of
+//                       fp32 operands, split-K kernel for small launches (0: the older kernels; parity-tested both ways)
+//   "split_fmt" / "flash_bf16" / "flash_tr" / "pointnet_bf16" / "gate_bf16" / "ln_resid" 0|1   bf16 modes: edge tensors between matrix
+//                       kernels as bf16 hi/lo pairs or half rows, attention / object encoder / gate on the bf16 matrix cores, V operand by
+//                       LDS transpose read, attention residual added by the LayerNorm kernel (0: the fp32 forms; parity-tested both ways)
+//   "flash_pv_terms" 3|2   split-bf16 edge attention: MFMAs per P.V product
+//   "gate_fuse_agg" 0|1|2  max aggregation inside the gate kernel: never / bf16 modes (default) / fp32 too
+//   "gate_row_map" 0|1, "gate_heads_mfma" 0|1|2   gate kernel variants the tests compare bit for bit
+// An EXPERIMENTS build (build.py --experiments, -DVLSAT_EXPERIMENTS) also accepts the lab switches -- "gate_grid" n, "gate_heads_bf16",
+// "flash_heads_bf16", "node_attn_split" n, "half_fmt", "flash_dma" 0|1|3|4, "flash_ablate" bits (GARBAGE results: timing only) -- and
+// honours the ablation bits of GemmArgs / FlashSplit; the release library answers them with an error.
 int vlsat_debug_option(vlsat_handle h, const char* name, int32_t value) {
     if (!h || !name) return fail(VLSAT_EINVAL, "vlsat_debug_option: null argument");
     const std::string k(name);
@@ -66,25 +62,31 @@ int vlsat_debug_option(vlsat_handle h, const char* name, int32_t value) {
     else if (k == "flash_split") h->fa_split = value != 0;
     else if (k == "gemm_dma") h->gemm_no_dma = value == 0;
     else if (k == "gemm_p8") h->gemm_no_p8 = value == 0;
-    else if (k == "gate_grid") h->gate_grid = value > 0 ? value : 0;
     else if (k == "gate_row_map") h->gate_row_map = value != 0;
     else if (k == "prof_dual") h->prof_dual = value != 0;
-    else if (k == "gate_heads_bf16") h->gate_heads_bf16 = value != 0;
-    else if (k == "flash_heads_bf16") h->flash_heads_bf16 = value != 0;
     else if (k == "gate_heads_mfma") h->gate_heads_mfma = value < 0 ? 0 : value > 2 ? 2 : value;
     else if (k == "gemm_splitk") h->gemm_splitk = value != 0;
-    else if (k == "node_attn_split") h->node_attn_split = value;
     else if (k == "split_fmt") h->split_fmt = value != 0;
-    else if (k == "half_fmt") h->half_fmt = value != 0;
     else if (k == "ln_resid") h->ln_resid = value != 0;
-    else if (k == "flash_dma") h->flash_dma = (value == 3 || value == 4) ? value : value != 0;
     else if (k == "gate_fuse_agg") h->gate_fuse_agg = value < 0 ? 0 : value > 2 ? 2 : value;
-    else if (k == "flash_ablate") h->flash_ablate = value;
     else if (k == "flash_pv_terms") h->flash_pv_terms = value == 2 ? 2 : 3;
     else if (k == "flash_bf16") h->flash_bf16 = value != 0;
     else if (k == "pointnet_bf16") h->pointnet_bf16 = value != 0;
     else if (k == "gate_bf16") h->gate_bf16 = value != 0;
     else if (k == "flash_tr") h->flash_tr = value != 0;
+#ifdef VLSAT_EXPERIMENTS
+    else if (k == "gate_grid") h->gate_grid = value > 0 ? value : 0;
+    else if (k == "gate_heads_bf16") h->gate_heads_bf16 = value != 0;
+    else if (k == "flash_heads_bf16") h->flash_heads_bf16 = value != 0;
+    else if (k == "node_attn_split") h->node_attn_split = value;
+    else if (k == "half_fmt") h->half_fmt = value != 0;
+    else if (k == "flash_dma") h->flash_dma = (value == 3 || value == 4) ? value : value != 0;
+    else if (k == "flash_ablate") h->flash_ablate = value;
+#else
+    else if (k == "gate_grid" || k == "gate_heads_bf16" || k == "flash_heads_bf16" || k == "node_attn_split" || k == "half_fmt" ||
+             k == "flash_dma" || k == "flash_ablate")
+        return fail(VLSAT_EINVAL, "vlsat_debug_option: " + k + " is a lab switch of the experiments build (build.py --experiments)");
+#endif
     else return fail(VLSAT_EINVAL, "vlsat_debug_option: unknown option " + k);
     return 0;
 }
@@ -114,8 +116,10 @@ int vlsat_k_gemm(const float* A, int32_t lda, const float* W, int32_t ldw, float
     if (relu_a & 2) a.prefetch = 0;             // (bit 1 of relu_a: no A-panel prefetch -- benchmarking)
     if (relu_a & 4) RUN(test_splitk_ws(a));     // (bit 2: small launches may take the split-K kernel)
     if (relu_a & 8) a.no_p8 = 1;                // (bit 3: large launches stay off the 256 x 256 8-phase kernel)
-    a.force_tile = (relu_a >> 4) & 7;           // (bits 4..6: tile of gemm_f32_kernel, GemmArgs::force_tile -- benchmarking)
-    if (a.force_tile) { a.no_p8 = 1; a.no_ring = 1; }
+    if (kExperiments) {
+        a.force_tile = (relu_a >> 4) & 7;       // (bits 4..6: tile of gemm_f32_kernel, GemmArgs::force_tile -- benchmarking; experiments build)
+        if (a.force_tile) { a.no_p8 = 1; a.no_ring = 1; }
+    }
     return launch_gemm(a, static_cast<hipStream_t>(stream));
 }
 
@@ -143,13 +147,17 @@ int vlsat_k_gemm_planes(const float* A, int32_t lda, const float* W, const uint1
     a.a_split = (fmt & 1) * code; a.r_split = ((fmt >> 1) & 1) * code; a.c_split = ((fmt >> 2) & 1) * code; a.c_scale = c_scale;
     // (bit 3 was the k-rotation experiment: removed; bit 4: no ring kernel -- benchmarking)
     a.no_ring = (fmt >> 4) & 1;
-    a.ring_wide = (fmt >> 7) & 1;              // (bit 7: ring kernel with 128 x 256 tiles where N allows)
-    a.ablate = ((fmt >> 8) & 3) | (((fmt >> 13) & 63) << 2);   // (bits 8, 9, 13..18: timing experiments, see GemmArgs::ablate)
-    a.ring_bk32 = (fmt >> 10) & 1;             // (bit 10: half-row ring kernel with 32-wide k slices)
-    a.ring_nodb = (fmt >> 11) & 1;             // (bit 11: ... without the double-buffered fragment sets)
     a.no_p8 = (fmt >> 12) & 1;                 // (bit 12: half-row launches skip the 256 x 256 8-phase kernel)
-    a.force_tile = (fmt >> 19) & 7;            // (bits 19..21: tile of gemm_f32_kernel, GemmArgs::force_tile -- benchmarking)
-    if (a.force_tile) { a.no_p8 = 1; a.no_ring = 1; }
+    if (kExperiments) {                        // lab bits (tools/gemm_bench.py, p8_check.py, gemm_tile_sweep.py): the experiments build only
+        a.ring_wide = (fmt >> 7) & 1;              // (bit 7: ring kernel with 128 x 256 tiles where N allows)
+        a.ablate = ((fmt >> 8) & 3) | (((fmt >> 13) & 63) << 2);   // (bits 8, 9, 13..18: timing experiments, see GemmArgs::ablate)
+        a.ring_bk32 = (fmt >> 10) & 1;             // (bit 10: half-row ring kernel with 32-wide k slices)
+        a.ring_nodb = (fmt >> 11) & 1;             // (bit 11: ... without the double-buffered fragment sets)
+        a.force_tile = (fmt >> 19) & 7;            // (bits 19..21: tile of gemm_f32_kernel, GemmArgs::force_tile -- benchmarking)
+        if (a.force_tile) { a.no_p8 = 1; a.no_ring = 1; }
+    } else if (fmt & ((1 << 7) | (3 << 8) | (3 << 10) | (0x1ff << 13))) {
+        return fail(VLSAT_EINVAL, "gemm_planes: timing / tile experiment bits need the experiments build (build.py --experiments)");
+    }
     if ((fmt >> 6) & 1) RUN(test_splitk_ws(a));    // (bit 6: small launches may take the split-K kernel)
     return launch_gemm(a, static_cast<hipStream_t>(stream));
 }

@@ -291,8 +291,8 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bf16_kernel(
         const bool more = kt + 1 < kt1;
         if (DMA) {
             // tile kt + LA goes into the buffer tile kt - 1 was read from: every wave passed the barrier that ended iteration kt - 1
-            if (kt + LA < kt1 && !(sp.ablate & 1)) dma_tile((kt + LA) * FB_KV, smem + (buf_i == 0 ? NBUF - 1 : buf_i - 1) * BUF);
-        } else if (more && !(sp.ablate & 1)) load_tile((kt + 1) * FB_KV);
+            if (kt + LA < kt1 && !(kExperiments && (sp.ablate & 1))) dma_tile((kt + LA) * FB_KV, smem + (buf_i == 0 ? NBUF - 1 : buf_i - 1) * BUF);
+        } else if (more && !(kExperiments && (sp.ablate & 1))) load_tile((kt + 1) * FB_KV);
 
         if (wave_active) {
             // ---- S^T[key][query] = sum_d K[key][d] * Q[query][d], two blocks of 32 keys ----
@@ -429,11 +429,11 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bf16_kernel(
         }   // wave_active
         if (DMA) {
             // tile kt + 1 has landed once only the tiles issued after it (kt + 2 .. kt + LA, as far as they exist) are outstanding
-            wait_tiles((sp.ablate & 1) ? 0 : min(LA - 1, kt1 - kt - 2));
+            wait_tiles((kExperiments && (sp.ablate & 1)) ? 0 : min(LA - 1, kt1 - kt - 2));
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             ring = ring == NBUF - 1 ? 0 : ring + 1;
         } else {
-            if (more && !(sp.ablate & 2)) store_tile(smem + ((kt + 1) & 1) * BUF);
+            if (more && !(kExperiments && (sp.ablate & 2))) store_tile(smem + ((kt + 1) & 1) * BUF);
             __syncthreads();
         }
     };

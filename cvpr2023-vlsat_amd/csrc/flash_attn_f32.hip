@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_f32_kernel(
         const float* sK = smem + (kt & 1) * BUF;
         const float* sV = sK + FA_KV * FA_PITCH;
         const bool more = kt + 1 < kt1;
-        if (more && !(sp.ablate & 1)) load_tile((kt + 1) * FA_KV);
+        if (more && !(kExperiments && (sp.ablate & 1))) load_tile((kt + 1) * FA_KV);
 
         if (wave_active) {
         // ---- S^T[key][query] = sum_d K[key][d] * Q[query][d] ----
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_f32_kernel(
             for (int b = 0; b < NO; ++b) o[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[32 * b], s[r], o[b], 0, 0, 0);
         }
         }   // wave_active
-        if (more && !(sp.ablate & 2)) store_tile(smem + ((kt + 1) & 1) * BUF);
+        if (more && !(kExperiments && (sp.ablate & 2))) store_tile(smem + ((kt + 1) & 1) * BUF);
         __syncthreads();
     }
 

@@ -574,6 +574,7 @@ int launch_gemm_p8(const GemmArgs& a, int n_tiles, int grid, hipStream_t s) {
             case 27: VLSAT_P8(2, 6, true, 1); break;
             default: return 1;
         }
+#ifdef VLSAT_EXPERIMENTS
     } else if (a.ablate && key == 27) {               // timing experiments on the gathered-row launch
         switch (a.ablate) {
             case 1: hipLaunchKernelGGL((gemm_p8_kernel<0, 6, true, 2, 256>), dim3(grid), dim3(512), 0, s, a, n_tiles, nbn); break;
@@ -593,6 +594,7 @@ int launch_gemm_p8(const GemmArgs& a, int n_tiles, int grid, hipStream_t s) {
             case 65: VLSAT_P8_ABL(65); break;
             default: VLSAT_P8_ABL(15); break;
         }
+#endif
     } else {
         switch (key) {
             case 0: VLSAT_P8(0, 0, false, 0); break;

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmArgs p, int n_til
     auto issue_next = [&]() {
         const int v = tile_of_round(ir);
         if (v >= n_tiles) return;
-        if (!(p.ablate & 1) || (ir == 0 && ikt < RST)) issue((v / nbn) * RBM, (v % nbn) * RBN, ikt * BK, smem + ibuf * STAGE);
+        if (!(kExperiments && (p.ablate & 1)) || (ir == 0 && ikt < RST)) issue((v / nbn) * RBM, (v % nbn) * RBN, ikt * BK, smem + ibuf * STAGE);
         ibuf = ibuf == RST - 1 ? 0 : ibuf + 1;
         if (++ikt == KT) { ikt = 0; ++ir; }
         ++ahead;
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmArgs p, int n_til
             }
         };
         auto mma = [&](const Frags& f) {
-            if (p.ablate & 2) return;
+            if (kExperiments && (p.ablate & 2)) return;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 bf16x8 a[TM];
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmArgs p, int n_til
                     __builtin_amdgcn_sched_barrier(0);
                 }
             };
-            if (p.ablate & 2) continue;                       // (timing experiment: no fragment reads, no MFMAs)
+            if (kExperiments && (p.ablate & 2)) continue;                       // (timing experiment: no fragment reads, no MFMAs)
             if (p.relu_a) slice(std::true_type{});
             else slice(std::false_type{});
         }

@@ -131,10 +131,9 @@ class VLSATModel:
         return self
 
     def debug_option(self, name: str, value: int):
-        """Experiment switches of the library (vlsat_debug_option; the names and meanings are listed in include/vlsat.h:
-        'dual_stream', 'flash_split', 'gemm_dma', 'gate_grid', 'gemm_splitk', 'node_attn_split', 'split_fmt', 'half_fmt',
-        'flash_bf16', 'flash_tr', 'flash_dma', 'gate_fuse_agg', 'flash_pv_terms', 'pointnet_bf16', 'gate_bf16', 'ln_resid', 'gemm_p8').  Defaults are the
-        measured-best settings; none changes results beyond floating-point summation order / the mode's rounding."""
+        """Switches of the library handle (``vlsat_debug_option``; names and meanings: include/vlsat.h).  Defaults are the
+        measured-best settings; none changes results beyond floating-point summation order / the mode's rounding.  Lab switches
+        (timing ablations and the like) exist in the experiments build only (``build.py --experiments``)."""
         L.check(self._lib.vlsat_debug_option(self._h, name.encode(), int(value)))
         self._debug_options[name] = int(value)
         if name in ("dual_stream", "flash_split"):

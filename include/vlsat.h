@@ -353,32 +353,23 @@ int vlsat_debug_read(vlsat_plan p, const char* name, float* dst, int64_t dst_ld)
  * cycles / (ticks / 1e8) is the shader clock the kernel actually ran at. NULL disables. */
 int vlsat_debug_gemm_clock_probe(int64_t* buf);
 
-/* Experiment switches of one handle; defaults are the measured-best settings and none changes results beyond
- * fp32 summation order.  "dual_stream" 0|1|2: 2D twin stages on a second stream (1: launch-bound plans only, 2 = default: every plan;
- * a two-stream plan owns a second scratch set, +7.3 KB per edge = 0.73 GB at the 64-scene bench batch, and falls back to one stream
- * when its workspace would pass 48 GiB with it); "sched" -1|0|1: schedule of a two-stream plan -- 1 = dependency-exact, three lanes
- * (3D chain / 2D edge chain / 2D node chain) coupled by one event per data-flow edge, 0 = the fork / join schedule (lanes meet twice
- * per layer), -1 (default) = exact in the bf16 modes, fork / join in exact fp32; bit-identical results; "gemm_p8" 0|1: large edge-row GEMM launches on the 256 x 256 8-phase kernel in
- * every precision mode (1, default; 0: the older 128 x 128 / ring kernels -- in the half-row mode the edge-attention residual then
- * goes back from the LayerNorm kernel into the out-projection); "flash_split" 0|1:
- * split-key edge attention for plans that cannot fill the chip (both: plans created afterwards); "gemm_dma" 0|1:
- * LDS-direct staging of fp32 GEMM operands; "gate_grid" n: persistent grid of the gate kernel (0 = default); "prof_dual" 0|1: per-class profiling keeps the two-stream execution (1, default) or serialises the forward on the launch stream; "gate_heads_bf16" 0|1: bf16 modes at head geometries other than 8 x (64, 32), the gate on the bf16 kernel (1, default) or the fp32 one; "flash_heads_bf16" 0|1: bf16 modes at NUM_HEADS 4 / 16, edge attention on the bf16 kernel (1, default) or the fp32 one; "gate_heads_mfma" 0|1|2: NUM_HEADS / DIM_ATTEN other than 8 / 256 on the MFMA gate kernel (1, default) or the VALU one; "gate_row_map" 0|1: a gate wave owns 32 edges of one head (1, default) or 4 edges x 8 heads;
- * "split_fmt" 0|1: in the bf16 modes, edge tensors between matrix kernels as bf16 hi/lo pairs (0: fp32, split on read);
- * "half_fmt" 0|1: in the single-rounding modes, those tensors as plain bf16 at half the traffic (0: hi/lo pairs);
- * "ln_resid" 0|1: split-bf16 mode, residual of the edge attention added by the LayerNorm kernel (0: by the out-projection);
- * "flash_pv_terms" 3|2: split-bf16 edge attention, MFMAs per P.V product (2: probabilities single-rounded; +3 % scenes/s,
- * twice the error on weights that make the attention peaked -- left at 3);
- * "gemm_splitk" 0|1: small GEMM launches on the split-K kernel; "node_attn_split" n: node attention with sixteen lanes per
- * query for plans with fewer than n one-query-per-lane waves;
- * "gate_fuse_agg" 0|1|2: MODEL.GCN_AGGR = max at 8 heads x 256: the aggregation by source node happens inside the gate kernel (no [E, 256]
- * tensor of gated messages, no aggregate launch; bit-identical results) -- 1 (default) in the bf16 modes, 2 in exact fp32 too, 0 never;
- * "flash_dma" 0|1|3|4: half-row bf16 edge attention at head dim 64, K / V tiles by LDS-direct loads (1, default: two tile buffers,
- * one tile ahead, four blocks per CU; 3 / 4: rings of three / four buffers; 0: the register-staged kernel of round 3);
- * "flash_ablate" bits: timing experiments on the edge attention, GARBAGE results (1: no K/V loads after the first tile, 2: no LDS
- * stores of them);
- * "flash_bf16" / "pointnet_bf16" / "gate_bf16" 0|1: in the bf16 modes, edge attention / object encoder / edge gate on
- * the bf16 matrix cores (0: the fp32 kernels); "flash_tr" 0|1: its V operand by
- * ds_read_b64_tr_b16 (0: ds_read_u16 gather). */
+/* Switches of one handle; defaults are the measured-best settings and none changes results beyond fp32 summation order / the
+ * precision mode's rounding.  The RELEASE library accepts:
+ *   "dual_stream" 0|1|2   extra streams for the 2D chains (1: launch-bound plans only, 2 = default: every plan; such a plan owns a second
+ *                         scratch set, +11.3 KB per edge, and falls back to one stream past 48 GiB of workspace) -- plans created afterwards;
+ *   "sched" -1|0|1        schedule of a multi-stream plan: 1 = dependency-exact, three lanes (3D chain / 2D edge chain / 2D node chain)
+ *                         coupled by one event per data-flow edge; 0 = fork / join, lanes meet twice per layer; -1 (default) = exact in
+ *                         the bf16 modes, fork / join in exact fp32.  Bit-identical results;
+ *   "flash_split" 0|1     split-key edge attention for plans that cannot fill the chip (plans created afterwards);
+ *   "prof_dual" 0|1       per-class profiling keeps the multi-stream execution (1, default) or serialises on the launch stream;
+ *   "gemm_p8", "gemm_dma", "gemm_splitk" 0|1          GEMM kernel selection (0: the older kernels);
+ *   "split_fmt", "flash_bf16", "flash_tr", "pointnet_bf16", "gate_bf16", "ln_resid" 0|1   bf16 modes: tensor formats and kernels (0: the
+ *                         fp32 forms) -- every one parity-tested both ways (tests/test_hip_forward.py);
+ *   "flash_pv_terms" 3|2  split-bf16 edge attention: MFMAs per P.V product;  "gate_fuse_agg" 0|1|2: max aggregation inside the gate
+ *                         kernel (never / bf16 modes / fp32 too);  "gate_row_map" 0|1, "gate_heads_mfma" 0|1|2: gate kernel variants.
+ * Lab switches ("gate_grid", "gate_heads_bf16", "flash_heads_bf16", "node_attn_split", "half_fmt", "flash_dma", "flash_ablate" -- the
+ * last one produces GARBAGE results for timing) exist in the experiments build only (`build.py --experiments`, -DVLSAT_EXPERIMENTS ->
+ * tools/bin/libvlsat_hip_exp.so); the release library answers them with VLSAT_EINVAL. */
 int vlsat_debug_option(vlsat_handle h, const char* name, int32_t value);
 
 /* ---- the one collective of the path: sum of a short fp64 metrics vector over ranks, on RCCL ---------------

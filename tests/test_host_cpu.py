@@ -58,6 +58,23 @@ def test_library_exports_every_declared_symbol(L):
     assert b"gfx950" in lib.vlsat_version()
 
 
+def test_release_library_carries_no_lab_code(L):
+    """The in-tree build is the RELEASE library (csrc/common.h): no timing-ablation instantiation of the 8-phase GEMM (template
+    argument ABL != 0 -- "results are garbage" by their own comment), and the lab switches of vlsat_debug_option are refused
+    (they exist in `build.py --experiments` -> tools/bin/libvlsat_hip_exp.so only)."""
+    import re
+    import shutil
+    import subprocess
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    out = subprocess.run([nm, "-C", L.LIB_PATH], capture_output=True, text=True).stdout
+    p8 = re.findall(r"gemm_p8_kernel<(\d+), (\d+), (?:true|false), (\d+), (\d+)>", out)
+    assert p8, "nm shows no gemm_p8_kernel instantiation at all"
+    assert all(abl == "0" for *_, abl in p8), sorted(set(p8))
+    src = open(os.path.join(ROOT, "cvpr2023-vlsat_amd", "csrc", "engine_api.hip")).read()
+    lab = src[src.index("#ifdef VLSAT_EXPERIMENTS"):src.index("#else", src.index("#ifdef VLSAT_EXPERIMENTS"))]
+    assert "flash_ablate" in lab and "gate_grid" in lab           # the lab switches sit behind the macro, not in the release path
+
+
 def test_c_abi_argument_validation_without_gpu(L):
     lib = L.load()
     h = C.c_void_p()
