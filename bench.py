@@ -28,6 +28,10 @@ from vlsat_amd import VLSATConfig, synth, dist as vdist  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 dense (never the 2:1-sparse figure)
+# what the bf16 matrix pipe SUSTAINS on these boxes with registers only and random operands (tools/mfma_peak_bf16.hip,
+# profiles/r04_probes/mfma_peak_bf16.txt: 1.78-1.83 PF; the clock drops to ~1.8 GHz under matrix load) -- printed next to the
+# 2.5 PF headline peak as `peak_sustained`, never instead of it
+SUSTAINED_BF16_MFMA_TFLOPS = 1800.0
 # peak of the mode's matrix work counted in ALGORITHMIC flops: split-bf16 issues three bf16 MFMAs per product
 MODE_PEAK = {"fp32": PEAK_FP32_MFMA_TFLOPS, "bf16x3": PEAK_BF16_MFMA_TFLOPS / 3, "bf16": PEAK_BF16_MFMA_TFLOPS,
              "bf16_mixed": PEAK_BF16_MFMA_TFLOPS}
@@ -98,19 +102,35 @@ PMC_TAG = {("cfg2", "fp32"): "_bench_pmc.json", ("cfg2", "bf16x3"): "_cfg3_bf16x
 def committed_traffic(workload, mode, dom):
     """HBM bytes per launch of kernel class `dom` from the newest committed rocprofv3 PMC summary of this workload and mode
     (profiles/rNN_*_pmc.json, written by tools/profile_run.sh from FETCH_SIZE / WRITE_SIZE passes of this very command:
-    FETCH_SIZE x 2 per MI355X_MICROARCH.md + WRITE_SIZE).  NOT measured in this run: the caller labels it so."""
+    FETCH_SIZE x 2 per MI355X_MICROARCH.md + WRITE_SIZE).  NOT measured in this run: the caller labels it so, and `stale` says
+    whether the summary was collected on another build than the one running now (the summary's `collected_on` stamp against
+    vlsat_amd.lib.identity(): source digest first, library digest second; True when the summary has no stamp)."""
     tag = PMC_TAG.get((workload, mode))
     d = os.path.join(ROOT, "profiles")
     if not tag or not os.path.isdir(d):
-        return None, None
+        return None, None, None
     files = sorted(f for f in os.listdir(d) if f.endswith(tag))
     if not files:
-        return None, None
+        return None, None, None
     try:
-        cls = json.load(open(os.path.join(d, files[-1])))["classes"]
-        return round(cls[dom]["hbm_bytes_per_launch"]), "profiles/" + files[-1]
+        j = json.load(open(os.path.join(d, files[-1])))
+        st = j.get("collected_on") or {}
+        now = _identity()
+        stale = not st.get("source_sha256") or st["source_sha256"] != now["source_sha256"]
+        return round(j["classes"][dom]["hbm_bytes_per_launch"]), "profiles/" + files[-1], stale
     except Exception:
-        return None, None
+        return None, None, None
+
+
+_ID = None
+
+
+def _identity():
+    global _ID
+    if _ID is None:
+        from vlsat_amd import lib as _L
+        _ID = _L.identity(_L.LIB_PATH)
+    return _ID
 
 
 def measure_traffic(argv, dom):
@@ -142,7 +162,7 @@ def measure_traffic(argv, dom):
     return round(got["fetch"][dom] + got["write"][dom]), "measured in this run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
 
 
-def roofline_of(classes, mode, steps, falg, value, world, traffic=None, traffic_src=None, traffic_measured=False):
+def roofline_of(classes, mode, steps, falg, value, world, traffic=None, traffic_src=None, traffic_stale=None, traffic_measured=False):
     """`roofline` object of one timed run: the dominant kernel class by HIP-event time on the launch stream."""
     if not classes:
         return None
@@ -154,8 +174,12 @@ def roofline_of(classes, mode, steps, falg, value, world, traffic=None, traffic_
     return {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": round(peak, 1),
             "peak_note": {"fp32": "v_mfma_f32_32x32x2_f32", "bf16x3": "2.5 PF bf16 dense / 3 MFMAs per product",
                           "bf16": "2.5 PF bf16 dense", "bf16_mixed": "2.5 PF bf16 dense"}[mode],
-            "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+            "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+            "peak_sustained": None if mode == "fp32" else round(SUSTAINED_BF16_MFMA_TFLOPS / (3 if mode == "bf16x3" else 1), 1),
+            "frac_of_sustained": None if mode == "fp32" else round(achieved / (SUSTAINED_BF16_MFMA_TFLOPS / (3 if mode == "bf16x3" else 1)), 4),
+            "traffic": traffic,
             "traffic_unit": "HBM bytes per launch (PMC)", "traffic_source": traffic_src, "traffic_measured": bool(traffic_measured),
+            "traffic_stale": None if traffic is None else (False if traffic_measured else bool(traffic_stale)),
             "launches_per_step": c["launches"] // steps, "avg_launch_ms": round(c["ms"] / max(c["launches"], 1), 4),
             "flop_per_launch": c["flops"] / max(c["launches"], 1),
             "whole_forward_tflops": round(falg * value / world / 1e12, 2),
@@ -255,7 +279,10 @@ def main():
                          "and the evaluation leg")
     ap.add_argument("--measure-traffic", action="store_true",
                     help="measure roofline.traffic in this run: two extra rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of the same "
-                         "workload (adds minutes; without it the committed profiles/ summary is quoted and labelled traffic_measured=false)")
+                         "workload on 3 steps (< 1 min).  This is the DEFAULT at --gpus 1 when rocprofv3 is on the box and the run is the "
+                         "full one (no --no-extra); --no-measure-traffic quotes the committed profiles/ summary instead, labelled "
+                         "traffic_measured=false and traffic_stale=<collected on another build>")
+    ap.add_argument("--no-measure-traffic", action="store_true", help="never run the counter passes (see --measure-traffic)")
     ap.add_argument("--native-allreduce", action="store_true",
                     help="sum the metrics vector with the library's own RCCL entry point (vlsat_metrics_allreduce) "
                          "instead of torch.distributed.all_reduce")
@@ -326,16 +353,18 @@ def main():
     roofline = None
     if classes:
         dom = max(classes, key=lambda k: classes[k]["ms"])
-        traffic, traffic_src, measured = None, None, False
-        if args.measure_traffic and world == 1:
+        traffic, traffic_src, measured, stale = None, None, False, None
+        import shutil as _sh
+        want_measure = args.measure_traffic or (not args.no_measure_traffic and not args.no_extra and _sh.which("rocprofv3") is not None)
+        if want_measure and world == 1:
             # the counter passes of this very workload, now (minutes: opt-in; the driver's plain run reads the committed summary)
             wl = ["--scenes", str(args.scenes), "--objects", str(args.objects), "--points", str(args.points), "--layers", str(args.layers),
                   "--heads", str(args.heads), "--dim-atten", str(args.dim_atten), "--gemm-precision", args.gemm_precision]
             traffic, traffic_src = measure_traffic(wl, dom)
             measured = traffic is not None
         if traffic is None and default_wl:
-            traffic, traffic_src = committed_traffic("cfg2", args.gemm_precision, dom)
-        roofline = roofline_of(classes, args.gemm_precision, args.steps, falg, value, world, traffic, traffic_src, measured)
+            traffic, traffic_src, stale = committed_traffic("cfg2", args.gemm_precision, dom)
+        roofline = roofline_of(classes, args.gemm_precision, args.steps, falg, value, world, traffic, traffic_src, stale, measured)
 
     cpu, err, ref = None, None, None
     if world == 1 and not args.no_cpu:
@@ -350,16 +379,29 @@ def main():
         names = ("obj3d", "obj2d", "rel3d", "rel2d")
 
         def dom_traffic(workload, mode, cl):             # committed PMC summary of that configuration (not measured in this run)
-            return committed_traffic(workload, mode, max(cl, key=lambda k: cl[k]["ms"])) if cl else (None, None)
+            return committed_traffic(workload, mode, max(cl, key=lambda k: cl[k]["ms"])) if cl else (None, None, None)
+        def two_runs(batch_d, scenes_n, steps, warmup):
+            """An extra configuration is timed WITHOUT events on the schedule it ships with (in the bf16 modes the dependency-exact
+            three-lane one: `value`), and profiled per kernel class on ONE stream (`prof_dual` = 0), so that a class's time is its
+            kernels' own -- on three lanes the union of a class's intervals also holds what its launches wait for."""
+            r = timed_run(model, batch_d, scenes_n, steps, warmup, False, dev)
+            cl = {}
+            if prof:
+                model.debug_option("prof_dual", 0)
+                cl = timed_run(model, batch_d, scenes_n, steps, warmup, True, dev)["classes"]
+                model.debug_option("prof_dual", 1)
+            r["classes"] = cl
+            return r
         for mode in ("bf16x3", "bf16_mixed"):
             model.set_gemm_precision(mode)
-            r = timed_run(model, d, n_scenes, args.steps, args.warmup, prof, dev)
+            r = two_runs(d, n_scenes, args.steps, args.warmup)
             v = n_scenes * args.steps / r["dt"]
             e = None
             if ref is not None:
                 e = {k: float((g.cpu() - x).abs().max()) for k, g, x in zip(names, r["out"], ref)}
                 e["scenes_checked"] = f"{n_scenes}/{n_scenes}"
             extra.append({"workload": f"BASELINE configs[2]: 64 scenes x 40 objects x 256 pts, L=3, {mode}", "dtype": MODE_DTYPE[mode],
+                          "timing": "value: steps without events on the shipped schedule; roofline: the same steps profiled on one stream",
                           "tolerance": 1e-2, "value": round(v, 2), "unit": "scenes/s", "ms_per_step": round(r["dt"] / args.steps * 1e3, 3),
                           "median_ms_per_step": round(r["median_ms"], 3), "steps": args.steps, "max_abs_err_vs_cpu_oracle": e,
                           "roofline": roofline_of(r["classes"], mode, args.steps, falg, v, 1, *dom_traffic("cfg2", mode, r["classes"]))})
@@ -369,7 +411,7 @@ def main():
         gold = os.path.join(ROOT, "tests", "golden", "cfg5_n200_p1024_l3_sub.npz")
         for mode in ("fp32", "bf16_mixed"):
             model.set_gemm_precision(mode)
-            r = timed_run(model, db, 1, 5, 2, prof, dev)
+            r = two_runs(db, 1, 5, 2)
             v = 5 / r["dt"]
             e = None
             if os.path.exists(gold):                 # committed oracle subsample of this very scene (tests/golden/make_golden_cfg5.py)
@@ -404,6 +446,7 @@ def main():
         "allreduce": "vlsat_metrics_allreduce (RCCL via the C ABI)" if args.native_allreduce else "torch.distributed.all_reduce",
         "uninstrumented": plain,
         "evaluation": evaluation,
+        "library": _identity(),
         "roofline": roofline, "cpu_baseline": cpu, "max_abs_err_vs_cpu_oracle": err,
         "speedup_vs_cpu": round(value / cpu["value"], 1) if cpu else None,
         "extra_configs": extra or None,

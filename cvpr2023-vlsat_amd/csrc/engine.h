@@ -163,6 +163,9 @@ struct vlsat_plan_s {
     // overwrite X3 without waiting for the 2D side); two-stream plans keep one slot per layer
     float *Q2n = nullptr, *On2 = nullptr, *KVx = nullptr;
     int kvx_slots = 1;
+    // scratch of vlsat_process_val_counts: the four outputs and the two object-probability tables (floats), the rank tables (int32)
+    float* ev_f = nullptr;
+    int32_t* ev_i = nullptr;
     float* KVe2 = nullptr;                  // second K|V buffer of the edge cross-attention (two-stream plans: the 3D lane runs a layer ahead)
 };
 

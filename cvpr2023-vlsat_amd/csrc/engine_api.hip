@@ -1,4 +1,5 @@
 // Kernel-level C entry points (unit tests and tools drive single kernels through these) and debug hooks.
+#include <algorithm>
 #include <climits>
 #include <cstdint>
 #include <cstring>
@@ -272,6 +273,43 @@ int vlsat_eval_counts(const int32_t* obj_rank_3d, const int32_t* obj_rank_2d, co
     return launch_eval_counts(obj_rank_3d, obj_rank_2d, rel_rank_3d, rel_rank_2d, tri_rank_3d, tri_rank_2d, cnt, gt_class, gt_rel, edges,
                               n_nodes, n_edges, n_rel_class, n_scenes, reinterpret_cast<unsigned long long*>(counts),
                               static_cast<hipStream_t>(stream));
+}
+
+// One scene (or batch) of an evaluation loop in ONE call: forward + softmax of the object logits + both ranking passes + the
+// additive counts (vlsat_forward, vlsat_k_softmax_rows, vlsat_eval_ranks x 2, vlsat_eval_counts), all enqueued on `stream`,
+// intermediates in the plan's own scratch -- what Mmgnet.process_val (reference SGFN_MMG/model.py:458-480) computes per scene,
+// reduced to what MMGNet.validation keeps of it.  The host side of a one-scene-per-call loop is then one library call per scene
+// instead of six plus a dozen tensor allocations.  gt_rel: the multi-hot [E, R] int64 target; edges_e2: [E, 2] int64 (from, to) as
+// the loader yields it, in the plan's edge order; counts: device uint64 [1 + R + 2 (11 + 6 R)], zeroed once by the caller.
+// Top-k bounds and threshold are process_val's constants (topk 11 / 6 / 101, 0.5: reference :463-472).
+// MODEL.multi_rel_outputs only (the single-label variant ranks exp(log-softmax) in a second pass: use the separate entry points).
+int vlsat_process_val_counts(vlsat_handle h, vlsat_plan p, const float* obj_points, const float* obj_2d_feats, const float* descriptor,
+                             const int64_t* gt_class, const int64_t* gt_rel, const int64_t* edges_e2, int32_t n_scenes,
+                             uint64_t* counts, void* stream) {
+    if (!h || !p || !gt_class || !counts) return fail(VLSAT_EINVAL, "vlsat_process_val_counts: null argument");
+    if (p->h != h) return fail(VLSAT_EINVAL, "plan belongs to a different handle");
+    if (!h->d.multi_rel_outputs) return fail(VLSAT_EINVAL, "vlsat_process_val_counts: built for MODEL.multi_rel_outputs (use vlsat_forward + vlsat_eval_ranks + vlsat_eval_counts)");
+    const int N = (int)p->N, E = (int)p->E, C = h->d.n_obj_class, R = h->d.n_rel_class;
+    if (E > 0 && (!gt_rel || !edges_e2)) return fail(VLSAT_EINVAL, "vlsat_process_val_counts: null edge argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float* f = p->ev_f;
+    float *obj3 = f, *obj2 = f + (size_t)N * C, *prob3 = f + (size_t)2 * N * C, *prob2 = f + (size_t)3 * N * C;
+    float *rel3 = f + (size_t)4 * N * C, *rel2 = rel3 + (size_t)std::max(E, 1) * R;
+    int32_t* i = p->ev_i;
+    int32_t *or3 = i, *or2 = i + N, *rr3 = i + 2 * (size_t)N, *rr2 = rr3 + (size_t)std::max(E, 1) * R, *tr3 = rr2 + (size_t)std::max(E, 1) * R,
+            *tr2 = tr3 + (size_t)std::max(E, 1) * R, *cn3 = tr2 + (size_t)std::max(E, 1) * R, *cn2 = cn3 + std::max(E, 1);
+    RUN(vlsat_forward(h, p, obj_points, obj_2d_feats, descriptor, obj3, obj2, rel3, rel2, stream));
+    for (int br = 0; br < 2; ++br) {
+        const float* lg = br ? obj2 : obj3;
+        float* pr = br ? prob2 : prob3;
+        RUN(launch_softmax_rows(lg, C, N, C, pr, 0, s));
+        RUN(launch_eval_ranks(lg, pr, br ? rel2 : rel3, gt_class, gt_rel, edges_e2, N, E, C, R, 11, 6, 101, 0.5f, br ? or2 : or3, br ? rr2 : rr3,
+                              br ? tr2 : tr3, br ? cn2 : cn3, s));
+    }
+    RUN(launch_eval_counts(or3, or2, rr3, rr2, tr3, tr2, cn3, gt_class, gt_rel, edges_e2, N, E, R, n_scenes,
+                           reinterpret_cast<unsigned long long*>(counts), s));
+    VLSAT_HIP_CHECK(hipEventRecord(p->last_use, s));       // (the scratch is the plan's: its next owner orders behind the counting)
+    return 0;
 }
 
 int vlsat_scene_checksums(const float* obj3d, const float* obj2d, int64_t n_nodes, int32_t n_obj_class, const float* rel3d,

@@ -370,7 +370,10 @@ static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const fl
     size_t ev_i = 0;
     if (dual) {
         if (!h->side) VLSAT_HIP_CHECK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
-        if (!h->side2) VLSAT_HIP_CHECK(hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking));
+        // (the third lane exists only on handles that use it: HIP spreads streams over a few hardware queues in creation order, and
+        //  an idle extra stream per replica cost the one-scene-per-call loop its scaling with scenes in flight -- 454 vs 570
+        //  scenes/s at four in flight, profiles/r05_probes/val_loop_fp32.txt)
+        if (exact && !h->side2) VLSAT_HIP_CHECK(hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking));
         t = h->side;
         u = exact ? h->side2 : h->side;
     }

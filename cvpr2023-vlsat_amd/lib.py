@@ -72,6 +72,7 @@ _SIGNATURES = {
     "vlsat_k_softmax_rows": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "vlsat_eval_ranks": (C.c_int, [_vp] * 6 + [_i32] * 7 + [_f32] + [_vp] * 4 + [_vp]),
     "vlsat_eval_counts": (C.c_int, [_vp] * 10 + [_i32] * 4 + [_vp, _vp]),
+    "vlsat_process_val_counts": (C.c_int, [_vp] * 8 + [_i32, _vp, _vp]),
     "vlsat_scene_checksums": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
     "vlsat_comm_unique_id": (C.c_int, [_vp]),
     "vlsat_comm_init": (C.c_int, [_vp, _i32, _i32, C.POINTER(_vp)]),
@@ -84,6 +85,26 @@ _SIGNATURES = {
     "vlsat_debug_buffer": (C.c_int, [_vp, C.c_char_p, C.POINTER(_vp), C.POINTER(_i64), C.POINTER(_i32),
                                      C.POINTER(_i32)]),
 }
+
+
+def identity(lib_path: str = "") -> dict:
+    """What a measurement was taken on: SHA-256 of the shared library that is (or would be) loaded and of the sources it is
+    built from (csrc/*.hip, csrc/*.h, include/vlsat.h, build flags) -- the GPU box has no .git, so the source digest is what a
+    profile summary and a later bench run can compare; the commit is added when the summary is published (tools/)."""
+    import hashlib
+    path = lib_path or LIB_PATH
+    out = {"lib_sha256": None, "lib_bytes": None, "source_sha256": None}
+    if os.path.exists(path):
+        out["lib_sha256"] = hashlib.sha256(open(path, "rb").read()).hexdigest()
+        out["lib_bytes"] = os.path.getsize(path)
+    h = hashlib.sha256()
+    csrc = os.path.join(_HERE, "csrc")
+    for f in sorted(os.listdir(csrc)) + [HEADER_PATH, os.path.join(_HERE, "build.py")]:
+        fp = f if os.path.isabs(f) else os.path.join(csrc, f)
+        if fp.endswith((".hip", ".h", ".py")):
+            h.update(os.path.basename(fp).encode() + b"\0" + open(fp, "rb").read())
+    out["source_sha256"] = h.hexdigest()
+    return out
 
 
 def declared_symbols() -> list:

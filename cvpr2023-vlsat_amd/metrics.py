@@ -129,6 +129,11 @@ def process_val_counts(model, counts: torch.Tensor, obj_points, obj_2d_feats, gt
     ``edge_indices`` is [E,2] as the data loader yields it, on the device."""
     multi = bool(getattr(getattr(model, "config", None), "multi_rel_outputs", True))
     edges = edge_indices.to(torch.int64).contiguous()
+    if multi and hasattr(model, "process_val_counts"):           # one library call: forward + ranking + counts in the plan's scratch
+        r = model.config.num_rel_class
+        if model.process_val_counts(counts, obj_points, obj_2d_feats, gt_cls.to(torch.int64).contiguous().view(-1), descriptor,
+                                    multihot_targets(gt_rel_cls, r).to(torch.int64).contiguous(), edges, batch_ids, n_scenes, fc_sizes):
+            return counts
     # with the fully-connected hint the plan never reads the edge list: the [2,E] view is enough (no transpose kernel)
     ei_t = edges.t() if fc_sizes is not None else edges.t().contiguous()
     obj3, obj2, rel3, rel2 = model(obj_points, obj_2d_feats, ei_t, descriptor, batch_ids, istrain=False, fc_sizes=fc_sizes)

@@ -468,6 +468,24 @@ class VLSATModel:
         return obj3, obj2, rel3, rel2
 
     @torch.no_grad()
+    def process_val_counts(self, counts, obj_points, obj_2d_feats, gt_cls, descriptor, gt_rel_multihot, edges_e2, batch_ids=None,
+                           n_scenes: int = 1, fc_sizes: Optional[Sequence[int]] = None) -> bool:
+        """``vlsat_process_val_counts``: forward + ranking of both branches + the additive counts of ``evaluate.fields()`` for one
+        batch in ONE library call, intermediates in the plan's scratch (nothing allocated, nothing read back).  ``edges_e2`` is the
+        loader's int64 [E,2] list, ``gt_rel_multihot`` int64 [E,R], ``gt_cls`` int64 [N], ``counts`` the device int64 vector.
+        Returns False (nothing enqueued) when the plan had to permute the edges -- the caller then takes the separate calls."""
+        ei = edges_e2.t() if fc_sizes is not None else edges_e2.t().contiguous()
+        pts, f2d, desc, n, p, e = self._inputs(obj_points, obj_2d_feats, ei, descriptor)
+        with torch.cuda.device(self.device):
+            plan = self._plan(ei, batch_ids, n, p, fc_sizes)
+            if plan.perm is not None:
+                return False
+            L.check(self._lib.vlsat_process_val_counts(self._h, plan.handle, pts.data_ptr(), f2d.data_ptr(), desc.data_ptr(),
+                                                       gt_cls.data_ptr(), gt_rel_multihot.data_ptr(), edges_e2.data_ptr(), int(n_scenes),
+                                                       counts.data_ptr(), L.stream_ptr()))
+        return True
+
+    @torch.no_grad()
     def forward_3d(self, obj_points, edge_indices, descriptor, batch_ids=None, fc_sizes: Optional[Sequence[int]] = None):
         """3D-only deployment (no image features): returns (obj_logits_3d, rel_cls_3d), bit-identical to
         the first and third outputs of ``forward`` -- the 3D branch never reads the 2D branch

@@ -326,6 +326,16 @@ int vlsat_eval_counts(const int32_t* obj_rank_3d, const int32_t* obj_rank_2d, co
                       const int64_t* gt_rel, const int64_t* edges, int32_t n_nodes, int32_t n_edges, int32_t n_rel_class,
                       int32_t n_scenes, uint64_t* counts, void* stream);
 
+/* One scene (or batch) of an evaluation loop in ONE call: vlsat_forward + softmax of the object logits + vlsat_eval_ranks for both
+ * branches + vlsat_eval_counts, enqueued back to back on `stream` with every intermediate in the plan's own scratch -- what
+ * Mmgnet.process_val (reference src/model/SGFN_MMG/model.py:458-480) computes per scene, reduced to what MMGNet.validation keeps of
+ * it (src/model/model.py:201-242).  Top-k bounds 11 / 6 / 101 and threshold 0.5 are process_val's.  gt_rel is the multi-hot
+ * [E, R] int64 target, edges_e2 the [E, 2] int64 (from, to) list in the plan's edge order, counts as for vlsat_eval_counts.
+ * MODEL.multi_rel_outputs only.  All device pointers; asynchronous; one library call per scene on the host side. */
+int vlsat_process_val_counts(vlsat_handle h, vlsat_plan plan, const float* obj_points, const float* obj_2d_feats,
+                             const float* descriptor, const int64_t* gt_class, const int64_t* gt_rel, const int64_t* edges_e2,
+                             int32_t n_scenes, uint64_t* counts, void* stream);
+
 /* The additive fp64 metrics vector of one rank's batch -- what the path's one all-reduce carries when no labels are at hand
  * (bench.py; the label-based counts of validation(), reference src/model/model.py:214-242, come from vlsat_eval_ranks):
  * out9 = {n_scenes, n_nodes, n_edges, sum obj3d, sum obj2d, sum rel3d, sum rel2d, #nodes whose 3D and 2D top-1 class agree,

@@ -84,3 +84,31 @@ def test_flash_half_rows_beyond_4_gib_take_the_64_bit_kernel():
         ref = (torch.softmax(qq @ kk * 0.125, -1) @ vh).permute(1, 0, 2).reshape(S, 512).float()
         err = float((got[a:a + S] - ref).abs().max())
         assert err < 2e-2, (a, err)
+
+
+def test_process_val_counts_in_one_call_equals_the_separate_calls():
+    """vlsat_process_val_counts (forward + softmax + both ranking passes + counts in the plan's scratch, one library call per
+    scene) against the separate entry points it replaces on the host side (vlsat_forward, vlsat_k_softmax_rows, vlsat_eval_ranks x 2,
+    vlsat_eval_counts, which are pinned to the reference's eva_utils_acc functions by tests/test_hip_metrics.py): the same 361
+    counts, exactly, for one-scene calls of several sizes and a three-scene batch accumulated into one vector."""
+    from vlsat_amd import metrics as M, evaluate as EV
+    cfg = VLSATConfig(N_LAYERS=2)
+    m = _model(cfg, synth.make_weights(cfg))
+    g = np.random.default_rng(5)
+    one = torch.zeros(len(EV.fields()), dtype=torch.int64, device=DEV)
+    sep = torch.zeros_like(one)
+    for sizes in ([9], [23], [40], [12, 5, 31]):
+        b = {k: torch.from_numpy(v).to(DEV) for k, v in synth.collate([synth.make_scene(n, 96, 700 + n) for n in sizes]).items()}
+        n, e = b["obj_points"].shape[0], b["edge_indices"].shape[1]
+        gt_cls = torch.from_numpy(g.integers(0, cfg.num_obj_class, n)).to(DEV)
+        gt_rel = torch.from_numpy((g.random((e, cfg.num_rel_class)) < 0.05).astype(np.int64)).to(DEV)
+        edges = b["edge_indices"].t().contiguous()                        # [E,2], as the loader yields it
+        M.process_val_counts(m, one, b["obj_points"], b["obj_2d_feats"], gt_cls, b["descriptor"], gt_rel, edges, b["batch_ids"],
+                             len(sizes), fc_sizes=sizes)
+        obj3, obj2, rel3, rel2 = m(b["obj_points"], b["obj_2d_feats"], b["edge_indices"], b["descriptor"], b["batch_ids"])
+        t3 = M.rank_tables(obj3, rel3, gt_cls, gt_rel, edges, True)
+        t2 = M.rank_tables(obj2, rel2, gt_cls, gt_rel, edges, True)
+        M.eval_counts(sep, t3, t2, gt_cls, gt_rel, edges, len(sizes))
+    torch.cuda.synchronize()
+    assert int(one[0]) == 6 and torch.equal(one, sep), (one - sep).nonzero().view(-1).tolist()
+    m.close()

@@ -75,6 +75,27 @@ def test_release_library_carries_no_lab_code(L):
     assert "flash_ablate" in lab and "gate_grid" in lab           # the lab switches sit behind the macro, not in the release path
 
 
+def test_profile_stamps_and_stale_detection(L, tmp_path, monkeypatch):
+    """roofline.traffic is evidence only if it was collected on the build that is running: profile summaries carry the digest of
+    the sources and of the library (lib.identity()), and bench.committed_traffic() reports `stale` when the newest committed
+    summary has another one (or none, like the summaries of rounds 1-4)."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    ident = L.identity()
+    assert ident["lib_sha256"] and len(ident["source_sha256"]) == 64 and ident == L.identity()
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    body = {"classes": {"gemm_f32": {"hbm_bytes_per_launch": 123.0}}}
+    (prof / "r09_bench_pmc.json").write_text(json.dumps(body))
+    assert bench.committed_traffic("cfg2", "fp32", "gemm_f32") == (123, "profiles/r09_bench_pmc.json", True)
+    (prof / "r10_bench_pmc.json").write_text(json.dumps(dict(body, collected_on=ident)))
+    assert bench.committed_traffic("cfg2", "fp32", "gemm_f32") == (123, "profiles/r10_bench_pmc.json", False)
+    (prof / "r11_bench_pmc.json").write_text(json.dumps(dict(body, collected_on=dict(ident, source_sha256="0" * 64))))
+    assert bench.committed_traffic("cfg2", "fp32", "gemm_f32")[2] is True
+
+
 def test_c_abi_argument_validation_without_gpu(L):
     lib = L.load()
     h = C.c_void_p()

@@ -7,6 +7,7 @@ writes DIR/NAME_results.db on ROCm 7.2) into the per-kernel stats table kept und
 With the bench line of the traced run as third argument the table ends with a footer that recomputes roofline.achieved / frac
 from the trace (sum of GEMM kernel time / forwards against the GEMM flops of a forward).
 """
+import os
 import sqlite3
 import sys
 
@@ -57,6 +58,13 @@ def main(db, out, bench_json=None):
         lines.append(f"| `{name.split('(')[0]}` | {g} | {n} | {avg / 1e3:.1f} |")
     if bench_json:
         lines += footer(c, bench_json)
+    try:
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import pmc_summary
+        st = pmc_summary.stamp()
+        lines += ["", f"collected on: source_sha256 {st.get('source_sha256')}, lib_sha256 {st.get('lib_sha256')} ({st.get('lib_bytes')} B), git {st.get('git_head')}"]
+    except Exception:
+        pass
     open(out, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines[:14] + lines[-4:]))
 
