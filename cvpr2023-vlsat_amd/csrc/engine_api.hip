@@ -238,6 +238,16 @@ int vlsat_prepare_objects(const float* scene_points, const int32_t* choice, int3
     return launch_prepare_objects(scene_points, choice, n_obj, n_points, obj_points, descriptor, static_cast<hipStream_t>(stream));
 }
 
+// Per-object point selection on the device (the step in front of vlsat_prepare_objects; reference dataset_3dssg.py:279-289): see
+// include/vlsat.h.  vlsat_sample_objects_scratch gives the int32 count of `scratch`.
+size_t vlsat_sample_objects_scratch(int64_t n_points, int32_t n_obj) { return sample_objects_scratch_ints(n_points, n_obj); }
+int vlsat_sample_objects(const int32_t* instances, int64_t n_points, const int32_t* instance_ids, int32_t n_obj, int32_t n_sample,
+                         uint64_t seed, int32_t* id_map, int32_t map_size, int32_t* scratch, int32_t* choice, int32_t* counts, void* stream) {
+    if (!instances || !instance_ids || !id_map || !scratch || !choice || !counts) return fail(VLSAT_EINVAL, "sample_objects: null argument");
+    return launch_sample_objects(instances, n_points, instance_ids, n_obj, n_sample, seed, id_map, map_size, scratch, choice, counts,
+                                 static_cast<hipStream_t>(stream));
+}
+
 int vlsat_fc_edges(const int32_t* node_ptr, const int64_t* edge_ptr, int32_t n_scenes, int64_t n_nodes, int64_t n_edges,
                    int64_t* edges, int64_t* batch_ids, void* stream) {
     if (!node_ptr || !edge_ptr || !batch_ids || (n_edges > 0 && !edges) || n_scenes <= 0)

@@ -209,6 +209,11 @@ int launch_prepare_objects(const float* scene, const int32_t* choice, int N, int
 // run structure differs from the plan's scene partition (batch_ids may be null)
 int launch_check_graph(const int64_t* edges, int64_t n_edges, const int32_t* src, const int32_t* dst, const int64_t* batch_ids,
                        int64_t n_nodes, const int32_t* scene_ptr, int n_scenes, int32_t* mismatches, hipStream_t s);
+// per-object point selection (reference dataset_3dssg.py:279-289): stable per-instance index lists + n_sample draws with
+// replacement from a counter-based generator (prep.hip); scratch: sample_objects_scratch_ints(n_points, n_obj) int32
+size_t sample_objects_scratch_ints(int64_t n_points, int n_obj);
+int launch_sample_objects(const int32_t* instances, int64_t n_points, const int32_t* ids, int n_obj, int n_sample, unsigned long long seed,
+                          int32_t* id_map, int map_size, int32_t* scratch, int32_t* choice, int32_t* counts, hipStream_t s);
 int launch_fc_edges(const int32_t* node_ptr, const int64_t* edge_ptr, int n_scenes, int64_t n_nodes, int64_t n_edges,
                     int64_t* edges, int64_t* batch_ids, hipStream_t s);
 

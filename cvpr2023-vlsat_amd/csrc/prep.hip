@@ -81,6 +81,127 @@ __global__ void fc_edges_kernel(const int32_t* __restrict__ node_ptr, const int6
     edges[n_edges + e] = node_ptr[lo] + jj + (jj >= i);
 }
 
+// ---- per-object point selection on the device (reference src/dataset/dataset_3dssg.py:279-289) -------------------------------------
+//   obj_pointset = points[np.where(instances == instance_id)[0]];  choice = np.random.choice(len(obj_pointset), num_points, replace=True)
+// Here: (1) the point indices of every requested instance as ONE segmented list in ascending point order (np.where's order) --
+// a stable compaction: per 1024-point block and instance a count, an exclusive scan over blocks and instances, then every point
+// writes its index at offset[instance] + prefix[block][instance] + its rank among the block's earlier points of that instance;
+// (2) n_sample draws with replacement per instance from a COUNTER-BASED generator, so that a draw depends on (seed, object, draw
+// number) only -- deterministic, any launch geometry, no state:
+//   x = seed + 0x9E3779B97F4A7C15 * (obj * n_sample + draw + 1)   (mod 2^64)
+//   z = splitmix64 finaliser of x:  z = (x ^ x >> 30) * 0xBF58476D1CE4E5B9;  z = (z ^ z >> 27) * 0x94D049BB133111EB;  z ^= z >> 31
+//   k = ((z >> 32) * count) >> 32          (uniform on 0 .. count-1 up to count / 2^32)
+//   choice[obj, draw] = list[offset[obj] + k]
+// Not np.random's Mersenne stream (that is a property of the host library, not of the data path); oracle/prep_oracle.py restates
+// this one bit for bit.  Integer work, HBM-bound (4 B per point read twice, 4 B written).
+constexpr int SMP_CHUNK = 1024;      // points per block of the compaction (one wave walks them in 16 steps of 64)
+
+__global__ void smp_map_kernel(int32_t* __restrict__ id_map, int map_size) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < map_size) id_map[i] = -1;
+}
+__global__ void smp_map_set_kernel(const int32_t* __restrict__ ids, int n_obj, int32_t* __restrict__ id_map, int map_size) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_obj && ids[i] >= 0 && ids[i] < map_size) id_map[ids[i]] = i;      // (duplicate ids: the last writer wins; callers pass a set)
+}
+// pass 0: block_cnt[block][slot] = points of instance `slot` in the block;  pass 1: list[...] = point indices, stable
+template <int PASS>
+__global__ __launch_bounds__(64) void smp_scan_kernel(const int32_t* __restrict__ inst, int64_t n_points, const int32_t* __restrict__ id_map,
+                                                      int map_size, int n_obj, int32_t* __restrict__ block_cnt,
+                                                      const int32_t* __restrict__ offset, int32_t* __restrict__ list) {
+    extern __shared__ int32_t run[];                   // [n_obj]: counts so far in this block (pass 1: starting at the block's prefix)
+    const int lane = threadIdx.x;
+    int32_t* mine = block_cnt + (size_t)blockIdx.x * n_obj;
+    for (int i = lane; i < n_obj; i += 64) run[i] = PASS ? mine[i] : 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * SMP_CHUNK;
+    for (int c = 0; c < SMP_CHUNK / 64; ++c) {
+        const int64_t i = base + c * 64 + lane;
+        int slot = -1;
+        if (i < n_points) {
+            const int id = inst[i];
+            if (id >= 0 && id < map_size) slot = id_map[id];
+        }
+        // lanes of one instance are ranked together: leader = the first lane not yet served
+        unsigned long long todo = __ballot(slot >= 0);
+        while (todo) {
+            const int lead = __builtin_ctzll(todo);
+            const int ls = __shfl(slot, lead);
+            const unsigned long long same = __ballot(slot == ls);
+            if (slot == ls) {
+                const int rank = __popcll(same & ((1ull << lane) - 1));
+                if (PASS) list[(size_t)offset[ls] + run[ls] + rank] = (int32_t)i;
+            }
+            __syncthreads();                           // (one wave: orders the LDS read above against the update below)
+            if (lane == lead) run[ls] += __popcll(same);
+            __syncthreads();
+            todo &= ~same;
+        }
+    }
+    if (!PASS) for (int i = lane; i < n_obj; i += 64) mine[i] = run[i];
+}
+// per instance: exclusive scan of its block counts (in place) and its total; then the instances' offsets into the list
+__global__ void smp_prefix_kernel(int32_t* __restrict__ block_cnt, int n_blocks, int n_obj, int32_t* __restrict__ counts,
+                                  int32_t* __restrict__ offset) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n_obj) {
+        int32_t acc = 0;
+        for (int b = 0; b < n_blocks; ++b) {
+            const int32_t c = block_cnt[(size_t)b * n_obj + s];
+            block_cnt[(size_t)b * n_obj + s] = acc;
+            acc += c;
+        }
+        counts[s] = acc;
+    }
+}
+__global__ void smp_offset_kernel(const int32_t* __restrict__ counts, int n_obj, int32_t* __restrict__ offset) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int32_t acc = 0;
+        for (int s = 0; s < n_obj; ++s) { offset[s] = acc; acc += counts[s]; }
+    }
+}
+__global__ void smp_draw_kernel(const int32_t* __restrict__ list, const int32_t* __restrict__ offset, const int32_t* __restrict__ counts,
+                                int n_obj, int n_sample, unsigned long long seed, int32_t* __restrict__ choice) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)n_obj * n_sample) return;
+    const int obj = (int)(t / n_sample);
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(t + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    const unsigned cnt = (unsigned)counts[obj];
+    const unsigned k = (unsigned)(((z >> 32) * (unsigned long long)cnt) >> 32);
+    choice[t] = cnt ? list[(size_t)offset[obj] + k] : 0;       // (an instance without points: counts[obj] == 0 tells the caller)
+}
+
+size_t sample_objects_scratch_ints(int64_t n_points, int n_obj) {
+    const size_t n_blocks = (size_t)((n_points + SMP_CHUNK - 1) / SMP_CHUNK);
+    return n_blocks * (size_t)n_obj + (size_t)n_obj + (size_t)n_points;
+}
+
+int launch_sample_objects(const int32_t* instances, int64_t n_points, const int32_t* ids, int n_obj, int n_sample, unsigned long long seed,
+                          int32_t* id_map, int map_size, int32_t* scratch, int32_t* choice, int32_t* counts, hipStream_t s) {
+    if (n_obj <= 0 || n_sample <= 0) return 0;
+    if (n_obj > 8192) return fail(-1, "sample_objects: at most 8192 instances per call (LDS table)");
+    if (n_points <= 0 || n_points > 0x7fffffff || map_size <= 0) return fail(-1, "sample_objects: bad sizes");
+    const int n_blocks = (int)((n_points + SMP_CHUNK - 1) / SMP_CHUNK);
+    int32_t* block_cnt = scratch;
+    int32_t* offset = scratch + (size_t)n_blocks * n_obj;
+    int32_t* list = offset + n_obj;
+    hipLaunchKernelGGL(smp_map_kernel, dim3((map_size + 255) / 256), dim3(256), 0, s, id_map, map_size);
+    hipLaunchKernelGGL(smp_map_set_kernel, dim3((n_obj + 255) / 256), dim3(256), 0, s, ids, n_obj, id_map, map_size);
+    hipLaunchKernelGGL(smp_scan_kernel<0>, dim3(n_blocks), dim3(64), n_obj * sizeof(int32_t), s, instances, n_points, id_map, map_size, n_obj,
+                       block_cnt, offset, list);
+    hipLaunchKernelGGL(smp_prefix_kernel, dim3((n_obj + 255) / 256), dim3(256), 0, s, block_cnt, n_blocks, n_obj, counts, offset);
+    hipLaunchKernelGGL(smp_offset_kernel, dim3(1), dim3(64), 0, s, counts, n_obj, offset);
+    hipLaunchKernelGGL(smp_scan_kernel<1>, dim3(n_blocks), dim3(64), n_obj * sizeof(int32_t), s, instances, n_points, id_map, map_size, n_obj,
+                       block_cnt, offset, list);
+    const size_t draws = (size_t)n_obj * n_sample;
+    hipLaunchKernelGGL(smp_draw_kernel, dim3((unsigned)((draws + 255) / 256)), dim3(256), 0, s, list, offset, counts, n_obj, n_sample, seed, choice);
+    VLSAT_LAUNCH_CHECK("sample_objects");
+    return 0;
+}
+
 // mismatches += #{e : (edges[e], edges[E + e]) != (src[e], dst[e])} + #{i : batch_ids starts a new run at i  XOR  i is a scene start}
 __global__ void check_graph_kernel(const int64_t* __restrict__ edges, int64_t n_edges, const int32_t* __restrict__ src,
                                    const int32_t* __restrict__ dst, const int64_t* __restrict__ batch_ids, int64_t n_nodes,

@@ -69,6 +69,8 @@ _SIGNATURES = {
     "vlsat_k_dist_bias": (C.c_int, [_vp, _i32, _vp, _i32, _i32] + [_vp] * 10 + [_vp, _vp]),
     "vlsat_prepare_objects": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "vlsat_fc_edges": (C.c_int, [_vp, _vp, _i32, _i64, _i64, _vp, _vp, _vp]),
+    "vlsat_sample_objects_scratch": (_sz, [_i64, _i32]),
+    "vlsat_sample_objects": (C.c_int, [_vp, _i64, _vp, _i32, _i32, C.c_uint64, _vp, _i32, _vp, _vp, _vp, _vp]),
     "vlsat_k_softmax_rows": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "vlsat_eval_ranks": (C.c_int, [_vp] * 6 + [_i32] * 7 + [_f32] + [_vp] * 4 + [_vp]),
     "vlsat_eval_counts": (C.c_int, [_vp] * 10 + [_i32] * 4 + [_vp, _vp]),

@@ -1,7 +1,8 @@
 """Input preparation on the GPU: host-side mirror of the per-object part of
 ``SSGDatasetGraph.data_preparation`` (reference ``src/dataset/dataset_3dssg.py:279-294``), of the
 fully-connected edge list (``:264-266``) and of ``collate_fn_mmg`` (``src/dataset/DataLoader.py:153-176``).
-The random sampling (``np.random.choice``, ``:289``) stays with the caller: ``choice`` is an input."""
+The selection of an object's points (``np.where(instances == id)`` + ``np.random.choice``, ``:285-289``) runs on the device too
+(``sample_objects``): its index lists are np.where's, its draws come from a documented counter-based generator, not numpy's."""
 from __future__ import annotations
 
 from typing import Sequence
@@ -9,6 +10,25 @@ from typing import Sequence
 import torch
 
 from . import lib as L
+
+
+def sample_objects(instances: torch.Tensor, instance_ids: torch.Tensor, n_sample: int, seed: int):
+    """instances i32[Npts] (instance id per scene point), instance_ids i32[N] (distinct) -> choice i32[N, n_sample] (indices into the
+    scene's points, drawn with replacement from each instance's own points), counts i32[N] (points per instance).  Device tensors
+    in and out; nothing is read back.  ``choice`` feeds ``prepare_objects``."""
+    lib = L.load()
+    dev = instances.device
+    instances = instances.to(torch.int32).contiguous().view(-1)
+    ids = instance_ids.to(device=dev, dtype=torch.int32).contiguous().view(-1)
+    n_pts, n = instances.numel(), ids.numel()
+    map_size = 65536                      # instance ids are small integers (3RScan: < 1000); larger ids are ignored by the kernel
+    id_map = torch.empty(map_size, dtype=torch.int32, device=dev)
+    scratch = torch.empty(int(lib.vlsat_sample_objects_scratch(n_pts, n)), dtype=torch.int32, device=dev)
+    choice = torch.empty(n, int(n_sample), dtype=torch.int32, device=dev)
+    counts = torch.empty(n, dtype=torch.int32, device=dev)
+    L.check(lib.vlsat_sample_objects(instances.data_ptr(), n_pts, ids.data_ptr(), n, int(n_sample), int(seed) & (2 ** 64 - 1), id_map.data_ptr(),
+                                     map_size, scratch.data_ptr(), choice.data_ptr(), counts.data_ptr(), L.stream_ptr()))
+    return choice, counts
 
 
 def prepare_objects(scene_points: torch.Tensor, choice: torch.Tensor):

@@ -286,6 +286,20 @@ int vlsat_k_dist_bias(const float* desc, int32_t ld_desc, const int64_t* node_pt
 int vlsat_prepare_objects(const float* scene_points, const int32_t* choice, int32_t n_obj, int32_t n_points,
                           float* obj_points, float* descriptor, void* stream);
 
+/* Per-object point selection on the device -- the step in front of vlsat_prepare_objects (reference
+ * src/dataset/dataset_3dssg.py:279-289: obj_pointset = points[np.where(instances == id)[0]]; choice = np.random.choice(len, P,
+ * replace=True)).  instances int32 [Npts] (instance id of every scene point), instance_ids int32 [N] (the scene's objects, distinct,
+ * each < map_size).  Builds every instance's point indices in ascending order (np.where's) by a stable segmented compaction and
+ * draws n_sample of them with replacement from a counter-based generator: draw (obj, j) is a function of (seed, obj * n_sample + j)
+ * only -- splitmix64 of seed + 0x9E3779B97F4A7C15 (obj n_sample + j + 1), top 32 bits scaled to the instance's point count
+ * (csrc/prep.hip; oracle/prep_oracle.py restates it bit for bit; it is NOT numpy's Mersenne stream).  choice int32 [N, n_sample]
+ * feeds vlsat_prepare_objects; counts int32 [N] = points per instance (0: the instance does not occur; its choices are 0).
+ * id_map: int32 [map_size] scratch; scratch: int32 [vlsat_sample_objects_scratch(n_points, n_obj)].  Device pointers; asynchronous. */
+size_t vlsat_sample_objects_scratch(int64_t n_points, int32_t n_obj);
+int vlsat_sample_objects(const int32_t* instances, int64_t n_points, const int32_t* instance_ids, int32_t n_obj, int32_t n_sample,
+                         uint64_t seed, int32_t* id_map, int32_t map_size, int32_t* scratch, int32_t* choice, int32_t* counts,
+                         void* stream);
+
 /* Fully-connected directed edges without self loops, source-major, for a batch of scenes with node
  * offsets applied, and the batch ids (dataset_3dssg.py:264-266 + collate_fn_mmg DataLoader.py:160-172).
  * node_ptr int32 [S+1] and edge_ptr int64 [S+1] (edge_ptr[s+1]-edge_ptr[s] = n_s(n_s-1)) are device arrays;

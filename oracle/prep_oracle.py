@@ -9,7 +9,9 @@ Restates what the reference data loader does per object after sampling (SURVEY Â
 Parity status: PINNED for gen_descriptor by tests/test_prep_oracle.py against
 tests/golden/prep_small.npz (reference function called directly); zero_mean / edge list / collate
 are literal restatements (the reference's dataset module needs trimesh and cannot be imported here).
-The random sampling itself (np.random.choice, :289) is an input here (`choice`)."""
+The random sampling itself (np.random.choice, :289) is an input of prepare_objects (`choice`); sample_choice restates the
+library's OWN documented generator for the device-side selection (vlsat_sample_objects): that one has no reference
+counterpart to pin to beyond np.where's index order -- the tests check membership, uniformity and determinism."""
 from __future__ import annotations
 
 import numpy as np
@@ -34,6 +36,26 @@ def prepare_objects(scene_points: np.ndarray, choice: np.ndarray, dtype=torch.fl
         f -= f.mean(0).unsqueeze(0)
         obj[i] = f
     return obj.permute(0, 2, 1).contiguous(), desc
+
+
+def sample_choice(instances: np.ndarray, instance_ids, n_sample: int, seed: int):
+    """The point selection of dataset_3dssg.py:285-289 with the library's documented generator (include/vlsat.h,
+    vlsat_sample_objects) instead of np.random: per object the ascending index list np.where(instances == id)[0], and draw j =
+    list[((splitmix64(seed + 0x9E3779B97F4A7C15 (obj n_sample + j + 1)) >> 32) * len) >> 32].  -> choice [N, n_sample], counts [N]."""
+    M = (1 << 64) - 1
+    choice = np.zeros((len(instance_ids), n_sample), dtype=np.int64)
+    counts = np.zeros(len(instance_ids), dtype=np.int64)
+    for o, iid in enumerate(instance_ids):
+        lst = np.where(instances == iid)[0]
+        counts[o] = len(lst)
+        for j in range(n_sample):
+            z = (seed + 0x9E3779B97F4A7C15 * (o * n_sample + j + 1)) & M
+            z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+            z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+            z ^= z >> 31
+            if len(lst):
+                choice[o, j] = lst[((z >> 32) * len(lst)) >> 32]
+    return choice, counts
 
 
 def fc_edges_batch(n_per_scene):

@@ -112,3 +112,40 @@ def test_process_val_counts_in_one_call_equals_the_separate_calls():
     torch.cuda.synchronize()
     assert int(one[0]) == 6 and torch.equal(one, sep), (one - sep).nonzero().view(-1).tolist()
     m.close()
+
+
+def test_device_point_selection_equals_its_restatement_and_feeds_the_preparation():
+    """vlsat_sample_objects (reference dataset_3dssg.py:279-289 on the device): the per-instance index lists are np.where's, the
+    draws the documented counter-based generator's -- so the choices equal oracle.prep_oracle.sample_choice EXACTLY, every drawn
+    index belongs to its instance, an instance that does not occur reports 0 points, per-instance histograms are uniform within
+    4 sigma, and vlsat_prepare_objects on the drawn indices gives the descriptor / centred points of the CPU restatement on the
+    same indices (which is pinned to the reference's gen_descriptor)."""
+    from vlsat_amd import prep
+    from oracle import prep_oracle as PO
+    g = np.random.default_rng(11)
+    n_pts = 150_000                                                        # not a multiple of the 1024-point compaction block
+    inst = g.integers(1, 40, n_pts).astype(np.int32)
+    inst[g.integers(0, n_pts, 300)] = 55                                   # a sparse instance
+    inst[:3000] = 7                                                        # a contiguous one
+    pts = (g.normal(size=(n_pts, 3)) * 2 + inst[:, None] * 0.1).astype(np.float32)
+    ids = [7, 55, 12, 39, 1, 500]                                          # 500 does not occur
+    P = 256
+    choice, counts = prep.sample_objects(torch.from_numpy(inst).to(DEV), torch.tensor(ids), P, seed=20240917)
+    ref_choice, ref_counts = PO.sample_choice(inst, ids, P, seed=20240917)
+    torch.cuda.synchronize()
+    ch = choice.cpu().numpy()
+    assert counts.cpu().tolist() == ref_counts.tolist() and ref_counts[-1] == 0
+    assert (ch == ref_choice).all()
+    for o, iid in enumerate(ids[:-1]):
+        assert (inst[ch[o]] == iid).all()
+    # uniformity: many draws from the sparse instance (about 300 points)
+    many, cnt = prep.sample_objects(torch.from_numpy(inst).to(DEV), torch.tensor([55]), 300_000, seed=5)
+    k = int(cnt[0])
+    lst = np.where(inst == 55)[0]
+    h = np.bincount(np.searchsorted(lst, many[0].cpu().numpy()), minlength=k)
+    chi2 = ((h - 300_000 / k) ** 2 / (300_000 / k)).sum()
+    assert abs(chi2 - (k - 1)) < 4 * np.sqrt(2 * (k - 1)), (chi2, k)
+    # ... and into the preparation without a host round trip
+    obj, desc = prep.prepare_objects(torch.from_numpy(pts).to(DEV), choice[:5])
+    ref_obj, ref_desc = PO.prepare_objects(pts, ref_choice[:5])
+    assert float((obj.cpu() - ref_obj).abs().max()) < 1e-5 and float((desc.cpu() - ref_desc).abs().max()) < 2e-4
