@@ -53,8 +53,9 @@ struct vlsat_ctx {
     hipStream_t side = nullptr;          // lane 1: the 2D edge chain (two-stream schedule of round 4: every 2D twin stage)
     hipStream_t side2 = nullptr;         // lane 2: the 2D node chain of the dependency-exact schedule (adapter, node cross-attention, wnode, 2D object head)
     int sched = -1;          // two-stream plans: 1 = dependency-exact three-lane schedule (round 5), 0 = the fork / join schedule of round 4,
-                             // -1 = by mode: exact in the bf16 modes (+1.1 ... +1.7 %), fork / join in exact fp32, whose kernels are all
-                             // matrix-pipe-bound and lose 0.8 % to the extra concurrency (profiles/r05_probes/ab_sched.txt)
+                             // -1 = by mode and size: exact in the bf16 modes (+1.1 ... +2.5 %) on plans of more than 16 384 edges, fork / join
+                             // in exact fp32, whose kernels are all matrix-pipe-bound and lose 0.4-0.8 % to the extra concurrency
+                             // (profiles/r05_probes/ab_sched.txt), and on small plans (one scene per call: several replicas in flight)
                              // (vlsat_debug_option "sched"; results are bit-identical, the launches are the same)
     hipStream_t copy = nullptr;          // plan index uploads (non-blocking stream)
     std::vector<hipEvent_t> sync_ev;     // fork/join events (timing disabled), created on first use

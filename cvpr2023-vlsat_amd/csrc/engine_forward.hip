@@ -365,7 +365,10 @@ static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const fl
     // another.  "sched" = 0: the fork / join schedule of round 4 (u = t; the lanes meet twice per layer).  The launches, their
     // operands and therefore the results are the same in both; not while stopping at a debug stage or for the training outputs.
     const bool dual = p->dual && do2d && (!h->prof || h->prof_dual) && stop < 0 && !tr;
-    const bool exact = dual && (h->sched < 0 ? h->prec_edge != 0 : h->sched != 0);
+    // (default: exact for the bf16 modes on plans that fill the chip by themselves.  One-scene plans keep two streams: with K replicas
+    //  in flight on K host threads the third stream of every replica competes for the few hardware queues -- 551 vs 926-953 scenes/s at
+    //  four in flight in bf16_mixed, profiles/r05_probes/val_loop_bf16_mixed_three_lanes.txt)
+    const bool exact = dual && (h->sched < 0 ? (h->prec_edge != 0 && p->E > 16384) : h->sched != 0);
     hipStream_t t = s, u = s;
     size_t ev_i = 0;
     if (dual) {

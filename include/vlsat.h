@@ -383,7 +383,7 @@ int vlsat_debug_gemm_clock_probe(int64_t* buf);
  *                         scratch set, +11.3 KB per edge, and falls back to one stream past 48 GiB of workspace) -- plans created afterwards;
  *   "sched" -1|0|1        schedule of a multi-stream plan: 1 = dependency-exact, three lanes (3D chain / 2D edge chain / 2D node chain)
  *                         coupled by one event per data-flow edge; 0 = fork / join, lanes meet twice per layer; -1 (default) = exact in
- *                         the bf16 modes, fork / join in exact fp32.  Bit-identical results;
+ *                         the bf16 modes on plans of more than 16 384 edges, fork / join otherwise.  Bit-identical results;
  *   "flash_split" 0|1     split-key edge attention for plans that cannot fill the chip (plans created afterwards);
  *   "prof_dual" 0|1       per-class profiling keeps the multi-stream execution (1, default) or serialises on the launch stream;
  *   "gemm_p8", "gemm_dma", "gemm_splitk" 0|1          GEMM kernel selection (0: the older kernels);

@@ -33,14 +33,17 @@ def _run(m, b):
     return [o.cpu() for o in out]
 
 
-@pytest.mark.parametrize("mode,scale,tol", [("bf16_mixed", 1.0, 1e-2), ("bf16x3", 2.0, 1e-3)])
+@pytest.mark.parametrize("mode,scale,tol", [("bf16_mixed", 1.0, 1e-2), ("bf16x3", 1.5, 1e-3), ("bf16x3", 2.0, 1e-3)])
 def test_bf16_modes_on_stress_weights_at_the_bench_batch(mode, scale, tol):
     """The bf16 modes away from Xavier scale, at the 64-scene batch whose edge-row GEMMs run on the 8-phase kernel: GCN
     matrices x `scale`, LayerNorm gains from U(0.3, 3).  Scenes are independent, so four scenes of the batch are checked
     against the fp64 oracle run on those scenes alone.  What the modes can hold is set by their significands times the
     network's roundoff amplification (profiles/r03_probes/stress_scan.txt, tools/stress_scan.py): single-rounded bf16
     (8 bits) meets the 1e-2 of BASELINE configs[2] with the gains at scale 1 (7e-3) and leaves it at x1.5 (1.5e-2; x4: the
-    outputs are unrelated -- 2^-9 x ~4000); split-bf16 (16 bits) holds 1e-3 up to x2 (1.6e-4) and 1e-2 up to x3."""
+    outputs are unrelated -- 2^-9 x ~4000); split-bf16 (16 bits) holds 1e-3 up to x2 (1.6e-4) and 1e-2 up to x3.
+    x1.5 is where `bf16_mixed` ends (1.53e-2), and no mix of single-rounded and split layers short of "everything but the edge
+    attention split" brings it back under 1e-2 (profiles/r05_probes/precision_mix_study.txt): the mode for such weights is
+    split-bf16 (the x1.5 row), which `auto_precision` selects (tests/test_hip_round4.py, tests/test_hip_round5.py)."""
     from oracle import vlsat_oracle as O
     cfg = VLSATConfig(N_LAYERS=3)
     w = synth.make_weights_stress(cfg, scale)

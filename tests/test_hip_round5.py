@@ -149,3 +149,24 @@ def test_device_point_selection_equals_its_restatement_and_feeds_the_preparation
     obj, desc = prep.prepare_objects(torch.from_numpy(pts).to(DEV), choice[:5])
     ref_obj, ref_desc = PO.prepare_objects(pts, ref_choice[:5])
     assert float((obj.cpu() - ref_obj).abs().max()) < 1e-5 and float((desc.cpu() - ref_desc).abs().max()) < 2e-4
+
+
+def test_auto_precision_leaves_the_single_rounding_mode_at_stress_scale_1_5():
+    """BASELINE configs[2] tolerance 1e-2 away from Xavier scale: at x1.5 (GCN matrices x 1.5, LayerNorm gains from U(0.3, 3)) the
+    single-rounding mode is at 1.5e-2 and no depth mix repairs it (profiles/r05_probes/precision_mix_study.txt), so
+    VLSATModel.auto_precision must select split-bf16 there -- and what it selects must hold 1e-3 against the fp64 oracle."""
+    from oracle import vlsat_oracle as O
+    cfg = VLSATConfig(N_LAYERS=3)
+    w = synth.make_weights_stress(cfg, 1.5)
+    scenes = [synth.make_scene(40, 256, 1000 + s) for s in range(16)]
+    d = {k: torch.from_numpy(v).to(DEV) for k, v in synth.collate(scenes).items()}
+    m = _model(cfg, w)
+    r = m.auto_precision(d["obj_points"], d["obj_2d_feats"], d["edge_indices"], d["descriptor"], d["batch_ids"], tol=1e-2)
+    assert r["mode"] == "bf16x3" and m.gemm_precision == "bf16x3", r
+    got = [o.cpu() for o in m(d["obj_points"], d["obj_2d_feats"], d["edge_indices"], d["descriptor"], d["batch_ids"])]
+    c = {k: torch.from_numpy(v) for k, v in synth.collate([scenes[0]]).items()}
+    ref = O.forward(O.to_torch(w, torch.float64), cfg, c["obj_points"].double(), c["obj_2d_feats"].double(), c["edge_indices"],
+                    c["descriptor"].double(), c["batch_ids"])
+    err = max(float((g[:k] - x.float()).abs().max()) for g, x, k in zip(got, ref, (40, 40, 1560, 1560)))
+    assert err < 1e-3, (r, err)
+    m.close()

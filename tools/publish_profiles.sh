@@ -28,3 +28,13 @@ done
 for l in launches_fp32 launches_bf16_mixed; do [ -f $S/$l/launches.txt ] && cp $S/$l/launches.txt $P/$l.txt; done
 cp $S/tests_gpu.log $D/${R}_tests_gpu.txt
 ls $D $P
+# stamp the published summaries with the commit they were published from (the GPU box has no .git; the digests of sources and
+# library in `collected_on` were taken there)
+python - "$R" <<'PY'
+import glob, json, subprocess, sys
+head = subprocess.run(["git", "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip()
+for f in glob.glob(f"profiles/{sys.argv[1]}_*_pmc.json") + glob.glob(f"profiles/{sys.argv[1]}_bench_pmc.json"):
+    j = json.load(open(f))
+    j.setdefault("collected_on", {})["published_from_git_head"] = head
+    json.dump(j, open(f, "w"), indent=1)
+PY
