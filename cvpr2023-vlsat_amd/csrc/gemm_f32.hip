@@ -279,7 +279,10 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
         // less than one round left (the tail of a big launch, or a medium-sized one): a partial round costs a whole tile time
         // (one tile per CU), the 128 x 128 kernels ~0.7 (fp32) / ~0.5 (bf16) of it per full round of tiles -- from 5/8 of a
         // round on this kernel is the faster one
-        if (main_panels == 0 && panels * nbn >= (G1 * 5) / 8) main_panels = panels;
+        // (single-rounding bf16: a tile is 17-30 us against 8 + 0.4-0.7 us per tile-equivalent on the small kernels -- from 32 tiles on
+        //  the partial round wins; the cfg 5 scene's 7 032 remainder rows = 54 tiles took 27.7 us per launch on 64 x 64 tiles, as long
+        //  as the full round in front of them: profiles/r05_cfg5_bf16_mixed_kernel_stats_serial.md)
+        if (main_panels == 0 && panels * nbn >= (a.prec == 1 ? 32 : (G1 * 5) / 8)) main_panels = panels;
         if (main_panels > 0) {
             GemmArgs m = a;
             m.M = (int)(main_panels * 256);

@@ -70,8 +70,8 @@ def test_fused_gate_aggregation_is_bit_identical(mode, fuse):
     m.close()
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16_mixed"])
-def test_replicas_on_threads_are_bit_identical_to_the_single_threaded_forward(precision):
+@pytest.mark.parametrize("precision,sched", [("fp32", -1), ("bf16_mixed", -1), ("bf16_mixed", 1), ("fp32", 1)])
+def test_replicas_on_threads_are_bit_identical_to_the_single_threaded_forward(precision, sched):
     """Model replicas driven from several host threads on several streams (evaluate.validation(workers=K)) must give, scene by
     scene, the bits of the single-threaded forward -- no host wait between the forwards of a thread.  (The 1-in-20 000 fault
     this guards against needed ~10^5 forwards to show, tools/replica_race_probe.py; the short run here covers the machinery:
@@ -80,7 +80,9 @@ def test_replicas_on_threads_are_bit_identical_to_the_single_threaded_forward(pr
     import threading
     import numpy as np
     cfg = VLSATConfig(N_LAYERS=2)
-    m = _model(cfg, synth.make_weights(cfg)).set_gemm_precision(precision)
+    # sched = 1: the dependency-exact three-lane schedule of round 5 forced onto these one-scene plans (by default they keep two
+    # streams); replicas inherit the option (VLSATModel.replicate replays debug options)
+    m = _model(cfg, synth.make_weights(cfg)).set_gemm_precision(precision).debug_option("sched", sched)
     sizes = np.random.default_rng(3).integers(9, 41, 48)
     items = []
     for i, n in enumerate(sizes):
