@@ -57,12 +57,14 @@ def oracle_all_scenes(cfg, batch_np, threads):
                      c["descriptor"], c["batch_ids"])
 
 
-def cpu_baseline(cfg, n_obj, n_pts, budget_s=12.0, max_scenes=6, sweep_s=5.0):
+def cpu_baseline(cfg, n_obj, n_pts, budget_s=12.0, max_scenes=96, sweep_s=5.0):
     """The CPU oracle (torch fp32 port of the reference, one scene per call like validation())
     timed on this box's host cores on a bounded sample of the same workload.  torch's intra-op
     pool is tried at a few sizes (one scene each) and the fastest is used for the timed sample:
     with all cores of a many-core host the small per-scene ops are dominated by thread
-    synchronisation, which would understate what the CPU can do."""
+    synchronisation, which would understate what the CPU can do.  The sample is ~12 s of CPU work
+    (as many scenes as fit, at most 96), not a fixed handful: the hosts are shared and a six-scene
+    sample moved by +-30 % between runs."""
     from oracle import vlsat_oracle as O
     w = O.to_torch(synth.make_weights(cfg))
     ncpu = os.cpu_count() or 1
