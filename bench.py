@@ -34,11 +34,12 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf
 SUSTAINED_BF16_MFMA_TFLOPS = 1800.0
 # peak of the mode's matrix work counted in ALGORITHMIC flops: split-bf16 issues three bf16 MFMAs per product
 MODE_PEAK = {"fp32": PEAK_FP32_MFMA_TFLOPS, "bf16x3": PEAK_BF16_MFMA_TFLOPS / 3, "bf16": PEAK_BF16_MFMA_TFLOPS,
-             "bf16_mixed": PEAK_BF16_MFMA_TFLOPS}
+             "bf16_mixed": PEAK_BF16_MFMA_TFLOPS, "bf16x3_attn1": PEAK_BF16_MFMA_TFLOPS / 3}
 MODE_DTYPE = {"fp32": "f32",
               "bf16x3": "bf16x3 (split-bf16 MFMA operands, 3 MFMAs per product, f32 accumulate; softmax/LN and HBM tensors f32)",
               "bf16": "bf16 (single-rounded bf16 MFMA operands, f32 accumulate; softmax/LN and HBM tensors f32)",
-              "bf16_mixed": "bf16 on edge-row matrix work + bf16x3 on node rows (f32 accumulate; softmax/LN and HBM tensors f32)"}
+              "bf16_mixed": "bf16 on edge-row matrix work + bf16x3 on node rows (f32 accumulate; softmax/LN and HBM tensors f32)",
+              "bf16x3_attn1": "bf16x3 everywhere except a single-rounded bf16 edge cross-attention (f32 accumulate; softmax/LN f32)"}
 
 
 def f_alg(n, p, e, l):
@@ -175,10 +176,11 @@ def roofline_of(classes, mode, steps, falg, value, world, traffic=None, traffic_
     total_ms = max(sum(x["ms"] for x in classes.values()), 1e-9)
     return {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": round(peak, 1),
             "peak_note": {"fp32": "v_mfma_f32_32x32x2_f32", "bf16x3": "2.5 PF bf16 dense / 3 MFMAs per product",
-                          "bf16": "2.5 PF bf16 dense", "bf16_mixed": "2.5 PF bf16 dense"}[mode],
+                          "bf16": "2.5 PF bf16 dense", "bf16_mixed": "2.5 PF bf16 dense",
+                          "bf16x3_attn1": "2.5 PF bf16 dense / 3 MFMAs per product (GEMM class; the attention runs single-rounded)"}[mode],
             "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-            "peak_sustained": None if mode == "fp32" else round(SUSTAINED_BF16_MFMA_TFLOPS / (3 if mode == "bf16x3" else 1), 1),
-            "frac_of_sustained": None if mode == "fp32" else round(achieved / (SUSTAINED_BF16_MFMA_TFLOPS / (3 if mode == "bf16x3" else 1)), 4),
+            "peak_sustained": None if mode == "fp32" else round(SUSTAINED_BF16_MFMA_TFLOPS / (3 if mode in ("bf16x3", "bf16x3_attn1") else 1), 1),
+            "frac_of_sustained": None if mode == "fp32" else round(achieved / (SUSTAINED_BF16_MFMA_TFLOPS / (3 if mode in ("bf16x3", "bf16x3_attn1") else 1)), 4),
             "traffic": traffic,
             "traffic_unit": "HBM bytes per launch (PMC)", "traffic_source": traffic_src, "traffic_measured": bool(traffic_measured),
             "traffic_stale": None if traffic is None else (False if traffic_measured else bool(traffic_stale)),
@@ -290,7 +292,7 @@ def main():
                          "instead of torch.distributed.all_reduce")
     ap.add_argument("--debug-option", action="append", default=[], metavar="NAME=VALUE",
                     help="experiment switch of the library (vlsat_debug_option), e.g. node_attn_split=0; repeatable")
-    ap.add_argument("--gemm-precision", default="fp32", choices=["fp32", "bf16x3", "bf16_mixed", "bf16"],
+    ap.add_argument("--gemm-precision", default="fp32", choices=["fp32", "bf16x3", "bf16_mixed", "bf16", "bf16x3_attn1"],
                     help="fp32 = BASELINE configs[1] (default, the headline); bf16x3 / bf16_mixed = configs[2] "
                          "(split-bf16 MFMA: <=1e-3; mixed single/split bf16: <=1e-2)")
     ap.add_argument("--lib", default="", help="another build of libvlsat_hip.so to load instead of the in-tree one (same-box A/B of a kernel change)")
@@ -394,7 +396,7 @@ def main():
                 model.debug_option("prof_dual", 1)
             r["classes"] = cl
             return r
-        for mode in ("bf16x3", "bf16_mixed"):
+        for mode in ("bf16x3", "bf16x3_attn1", "bf16_mixed"):
             model.set_gemm_precision(mode)
             r = two_runs(d, n_scenes, args.steps, args.warmup)
             v = n_scenes * args.steps / r["dt"]

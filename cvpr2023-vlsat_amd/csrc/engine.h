@@ -115,6 +115,8 @@ struct vlsat_ctx {
     // GEMM operand precision: 0 exact fp32 MFMA, 1 bf16, 3 split-bf16 (vlsat_set_gemm_precision); prec_edge / prec_node
     // are what the edge-row / node-row launches actually use (mode 2 = mixed: bf16 on edge rows, bf16x3 on node rows)
     int prec = 0, prec_edge = 0, prec_node = 0;
+    int prec_attn = 0;       // ... and what the edge cross-attention (its three projections and the attention kernel) uses: prec_edge, except in
+                             // mode 4 = split-bf16 with a single-rounded edge attention (1)
     std::map<const float*, std::pair<uint16_t*, uint16_t*>> split;
     // workspace arenas of destroyed plans, re-used by the next plan that fits (an eval loop may build one plan per
     // scene; hipMalloc/hipFree per scene would dominate small scenes), pinned upload buffers, spare events

@@ -88,10 +88,11 @@ static void profile_close(vlsat_ctx* h, hipStream_t s) {
 // Every nn.Linear of the path.  Operand precision follows the handle's mode: node-row launches (M == number of nodes
 // of the running plan) take prec_node, everything else (edge rows, point rows) prec_edge; the bf16 planes of the
 // weights were made when the mode was set (engine_weights.hip), so nothing is allocated or converted here.
-int gemm(vlsat_ctx* h, hipStream_t s, const GemmArgs& a0) {
+// prec_override >= 0: this launch's operand precision whatever the row class says (the edge attention's projections in mode 4)
+int gemm(vlsat_ctx* h, hipStream_t s, const GemmArgs& a0, int prec_override = -1) {
     GemmArgs a = a0;
     const bool edge_fmt = a.a_split || a.c_split || a.r_split;            // tensors in an edge format: an edge-row launch whatever M is
-    const int prec = (a.M == h->cur_N && !edge_fmt) ? h->prec_node : h->prec_edge;
+    const int prec = prec_override >= 0 ? prec_override : (a.M == h->cur_N && !edge_fmt) ? h->prec_node : h->prec_edge;
     if (prec) {
         auto it = h->split.find(a.W);
         if (it == h->split.end()) return fail(VLSAT_ESTATE, "gemm: weight has no bf16 planes (set the precision after loading weights)");
@@ -534,8 +535,13 @@ static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const fl
             const float sc2e = (1.f / std::sqrt((float)(D / h->H))) * 1.4426950408889634f;   // 1/sqrt(d_k) * log2(e): the attention works in exp2
             const int dh = D / h->H;
             // format of Q / K|V / O: that of the chain when the bf16 attention kernel is built for this head dim and mode, else fp32
-            const bool fa16 = h->prec_edge && h->flash_bf16 && (dh == 64 || (h->flash_heads_bf16 && S && flash_attn_bf16_supports(dh, h->prec_edge == 3 ? 3 : 1, h->flash_tr, S)));
-            const int SA = fa16 ? S : 0;
+            // PA: operand precision of this block (mode 4: single rounding here, split-bf16 everywhere else -- the 3D outputs, which
+            // never see this block, keep the split-bf16 accuracy; profiles/r05_probes/precision_mix_study.txt)
+            const int PA = h->prec_attn;
+            const bool fa16 = PA && h->flash_bf16 && (dh == 64 || (h->flash_heads_bf16 && S && flash_attn_bf16_supports(dh, PA == 3 ? 3 : 1, h->flash_tr, S)));
+            // (mode 4: the chain tensors are split pairs, but Q / K|V / O feed a single-rounded attention only -- they travel as half rows,
+            //  which puts the attention on its LDS-direct kernel and the out-projection on the 8-phase one)
+            const int SA = fa16 ? ((PA == 1 && S == 1 && h->half_fmt && dh == 64) ? 2 : S) : 0;
             // K | V of layer l go to slot l % 2 on the dependency-exact schedule (the 3D lane may be a layer ahead of the attention
             // that reads them: it waits for the reader of the slot's previous content only)
             const int slot = exact ? (l & 1) : 0;
@@ -544,11 +550,11 @@ static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const fl
             GemmArgs gq = G(p->E2, D, w.wq, D, p->Qe, D, E, D, w.bq);
             gq.a_split = S; gq.c_split = SA;
             if (SA) gq.c_scale = sc2e;                                 // the split-format attention takes Q pre-scaled
-            RUN(gemm(h, t, gq));
+            RUN(gemm(h, t, gq, PA));
             RUN(wait(s, flash_done[slot]));
             GemmArgs gkv = G(p->E3, D, w.wkv, D, kve, 2 * D, E, 2 * D, w.bkv);
             gkv.a_split = S; gkv.c_split = SA;
-            RUN(gemm(h, s, gkv));
+            RUN(gemm(h, s, gkv, PA));
             if (exact) {
                 hipEvent_t kve_ready;
                 RUN(after(s, &kve_ready));
@@ -568,7 +574,7 @@ static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const fl
                                          1.f / std::sqrt((float)(D / h->H)), fs, h->node_attn_split));
                 else if (fa16)
                     RUN(launch_flash_attn_bf16(p->Qe, D, kve, kve + (SA == 2 ? D / 2 : D), 2 * D, p->Oe, D, p->d_tiles, p->n_tiles,
-                                               sc2e, h->prec_edge == 3 ? 3 : 1, h->flash_tr ? (h->flash_dma >= 3 ? h->flash_dma : h->flash_dma ? 1 : 2) : 0, SA, fs, &sp, h->flash_pv_terms, dh));    // (half rows: V starts at byte 2 D)
+                                               sc2e, PA == 3 ? 3 : 1, h->flash_tr ? (h->flash_dma >= 3 ? h->flash_dma : h->flash_dma ? 1 : 2) : 0, SA, fs, &sp, h->flash_pv_terms, dh));    // (half rows: V starts at byte 2 D)
                 else
                     RUN(launch_flash_attn(p->Qe, D, kve, kve + D, 2 * D, p->Oe, D, p->d_tiles, p->n_tiles, sc2e, fs, &sp, dh));   // (head dims 32 / 128: NUM_HEADS 16 / 4)
             }
@@ -583,7 +589,7 @@ static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const fl
             GemmArgs o = G(p->Oe, D, w.wo, D, pre_ln, D, E, D, w.bo);
             if (!ln_resid) { o.resid = p->E2; o.ldr = D; o.r_split = S; }
             o.a_split = SA;
-            RUN(gemm(h, fs, o));
+            RUN(gemm(h, fs, o, PA));
             Scope sc(h, fs, PC_LAYERNORM, 0);
             RUN(launch_layernorm_to(pre_ln, D, p->E2, D, E, D, w.lng, w.lnb, inter, S, fs, ln_resid ? p->E2 : nullptr, D, S));
         }

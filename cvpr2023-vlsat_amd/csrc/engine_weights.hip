@@ -447,11 +447,12 @@ int vlsat_finalize_weights(vlsat_handle h) {
 // The bf16 hi/lo copies of all weight matrices are made here, eagerly, not inside a forward.
 int vlsat_set_gemm_precision(vlsat_handle h, int32_t mode) {
     if (!h) return fail(VLSAT_EINVAL, "null handle");
-    if (mode < 0 || mode > 3) return fail(VLSAT_EINVAL, "gemm precision must be 0 (fp32), 1 (bf16), 2 (mixed) or 3 (bf16x3)");
+    if (mode < 0 || mode > 4) return fail(VLSAT_EINVAL, "gemm precision must be 0 (fp32), 1 (bf16), 2 (mixed), 3 (bf16x3) or 4 (bf16x3 with a single-rounded edge attention)");
     ++h->config_epoch;
     h->prec = mode;
-    h->prec_edge = mode == 2 ? 1 : mode;
-    h->prec_node = mode == 2 ? 3 : mode;
+    h->prec_edge = mode == 2 ? 1 : mode == 4 ? 3 : mode;
+    h->prec_node = mode == 2 || mode == 4 ? 3 : mode;
+    h->prec_attn = mode == 4 ? 1 : h->prec_edge;
     if (mode && h->finalized) RUN(split_all_weights(h));
     return 0;
 }

@@ -25,8 +25,7 @@
  *     vlsat_load_weight (when it replaces an already finalised set), vlsat_set_gemm_precision, vlsat_destroy and the
  *     vlsat_debug_* readers.
  *   - a handle (weights) may be shared by several plans; a plan owns its workspace and is NOT
- *     re-entrant (one forward at a time per plan; a hipGraph replay of a plan on another stream waits on the device for the
- *     previous replay), mirroring one nn.Module instance; a handle is driven from one
+ *     re-entrant (one forward at a time per plan; ), mirroring one nn.Module instance; a handle is driven from one
  *     host thread at a time, and its forwards are ordered on ONE stream at a time (small scratch buffers -- the split-K
  *     workspace of small GEMM launches -- belong to the handle: moving to another stream needs an event / sync between
  *     the last forward on the old stream and the first on the new one; separate handles are independent).
@@ -143,7 +142,10 @@ int vlsat_forward_train(vlsat_handle h, vlsat_plan p,
  * QKV/FFN GEMMs"): 0 = exact fp32 MFMA (default; BASELINE configs[1]); 3 = split-bf16 (a_hi.w_hi + a_lo.w_hi +
  * a_hi.w_lo on v_mfma_f32_32x32x16_bf16, fp32 accumulate, ~1e-5 error); 1 = single-rounded bf16 operands
  * everywhere (~2e-2 on the x14.29 object logits: outside the config's 1e-2); 2 = mixed: single-rounded bf16 on the
- * edge-row GEMMs / attention / gate and split-bf16 on the node-row GEMMs (meets 1e-2).
+ * edge-row GEMMs / attention / gate and split-bf16 on the node-row GEMMs (meets 1e-2 at Xavier-scale weights);
+ * 4 = split-bf16 everywhere except the edge cross-attention (reference network_MMG.py:228-234: its q / k|v / out projections and the
+ * attention itself), which is single-rounded -- the 3D outputs never read that block and keep mode 3's accuracy, the 2D outputs hold
+ * 1e-2 on weights where mode 2 does not.
  * Activations in HBM, softmax and LayerNorm stay fp32 in every mode.  May be changed between forwards; the bf16
  * planes of the weights are made inside this call (it waits for the device), never inside a forward. */
 int vlsat_set_gemm_precision(vlsat_handle h, int32_t mode);

@@ -435,7 +435,7 @@ def test_cfg3_split_bf16_gemms(golden_dir):
     m2.close()
 
 
-@pytest.mark.parametrize("mode,tol", [("bf16x3", 1e-3), ("bf16_mixed", 1e-2)])
+@pytest.mark.parametrize("mode,tol", [("bf16x3", 1e-3), ("bf16_mixed", 1e-2), ("bf16x3_attn1", 1e-2)])
 def test_cfg3_full_batch_all_scenes(bench_batch_oracle, mode, tol):
     """BASELINE configs[2] at the config's own batch (64 scenes x 40 x 256, L=3): every scene against the fp32 oracle.
     bf16x3 (three bf16 MFMAs per product) must stay inside the fp32 contract (1e-3); the mixed mode (single-rounded bf16
