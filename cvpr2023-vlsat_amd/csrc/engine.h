@@ -101,6 +101,7 @@ struct vlsat_ctx {
     int gemm_splitk = 1;                     // small GEMM launches take the split-K kernel (gemm_splitk.hip)
     float* sk_ws[3] = {nullptr, nullptr, nullptr};    // its workspace + counters, one set per lane: [0] launch stream, [1] / [2] the side streams
     unsigned* sk_cnt[3] = {nullptr, nullptr, nullptr};
+    int flash_bq_big = 1;                    // 256-query tiles for plans whose scenes all have >= 4096 edges (debug option "flash_bq_big" 0: always 128)
     int flash_dma = 1;                       // half-row bf16 edge attention: K / V by LDS-direct loads, one tile ahead (0: register-staged, round 3; 3 | 4: rings of three / four tile buffers)
     int gate_fuse_agg = 1;                   // gate at the default head geometry, GCN_AGGR = max: aggregation fused into the gate kernel: 0 never, 1 the bf16 modes, 2 fp32 as well ("gate_fuse_agg")
     int flash_ablate = 0;                    // timing experiments on the bf16 edge attention (FlashSplit::ablate; results are garbage)
@@ -146,6 +147,8 @@ struct vlsat_plan_s {
     int64_t* d_bias_ptr;
     int4* d_tiles;
     int n_tiles = 0;
+    int4* d_tiles_big = nullptr;             // the same attention cut into FLASH_BQ_BIG-query tiles: only when every scene has >= 4096 edges (engine_plan.hip)
+    int n_tiles_big = 0;
     // split-key mode of the edge attention for plans with too few blocks to fill the chip (flash_attn_*.hip)
     int fa_parts = 1;
     int4* d_krange = nullptr;

@@ -49,6 +49,7 @@ int vlsat_set_edge_attention_scope(vlsat_handle h, int32_t scope) {
 //                       kernels as bf16 hi/lo pairs or half rows, attention / object encoder / gate on the bf16 matrix cores, V operand by
 //                       LDS transpose read, attention residual added by the LayerNorm kernel (0: the fp32 forms; parity-tested both ways)
 //   "flash_pv_terms" 3|2   split-bf16 edge attention: MFMAs per P.V product
+//   "flash_bq_big" 0|1   half-row edge attention on plans whose scenes all have >= 4096 edges: 256 queries per block (1, default) or 128
 //   "gate_fuse_agg" 0|1|2  max aggregation inside the gate kernel: never / bf16 modes (default) / fp32 too
 //   "gate_row_map" 0|1, "gate_heads_mfma" 0|1|2   gate kernel variants the tests compare bit for bit
 // An EXPERIMENTS build (build.py --experiments, -DVLSAT_EXPERIMENTS) also accepts the lab switches -- "gate_grid" n, "gate_heads_bf16",
@@ -75,6 +76,7 @@ int vlsat_debug_option(vlsat_handle h, const char* name, int32_t value) {
     else if (k == "pointnet_bf16") h->pointnet_bf16 = value != 0;
     else if (k == "gate_bf16") h->gate_bf16 = value != 0;
     else if (k == "flash_tr") h->flash_tr = value != 0;
+    else if (k == "flash_bq_big") h->flash_bq_big = value != 0;
 #ifdef VLSAT_EXPERIMENTS
     else if (k == "gate_grid") h->gate_grid = value > 0 ? value : 0;
     else if (k == "gate_heads_bf16") h->gate_heads_bf16 = value != 0;

@@ -572,9 +572,12 @@ static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const fl
                     RUN(launch_node_attn(p->Qe, D, kve, 2 * D, kve + D, 2 * D, p->Oe, D, nullptr, p->d_edge_ptr32, nullptr,
                                          h->edge_scope == 1 ? 1 : p->S, h->edge_scope == 1 ? E : p->max_e, h->H, D / h->H,
                                          1.f / std::sqrt((float)(D / h->H)), fs, h->node_attn_split));
-                else if (fa16)
-                    RUN(launch_flash_attn_bf16(p->Qe, D, kve, kve + (SA == 2 ? D / 2 : D), 2 * D, p->Oe, D, p->d_tiles, p->n_tiles,
+                else if (fa16) {
+                    const bool big = SA == 2 && dh == 64 && p->n_tiles_big && h->flash_tr && h->flash_dma == 1 && h->flash_bq_big;
+                    if (big) sp.bq = FLASH_BQ_BIG;
+                    RUN(launch_flash_attn_bf16(p->Qe, D, kve, kve + (SA == 2 ? D / 2 : D), 2 * D, p->Oe, D, big ? p->d_tiles_big : p->d_tiles, big ? p->n_tiles_big : p->n_tiles,
                                                sc2e, PA == 3 ? 3 : 1, h->flash_tr ? (h->flash_dma >= 3 ? h->flash_dma : h->flash_dma ? 1 : 2) : 0, SA, fs, &sp, h->flash_pv_terms, dh));    // (half rows: V starts at byte 2 D)
+                }
                 else
                     RUN(launch_flash_attn(p->Qe, D, kve, kve + D, 2 * D, p->Oe, D, p->d_tiles, p->n_tiles, sc2e, fs, &sp, dh));   // (head dims 32 / 128: NUM_HEADS 16 / 4)
             }

@@ -210,6 +210,22 @@ int vlsat_plan_create(vlsat_handle h, const int64_t* bid, const int64_t* edges, 
         }
     }
     p->n_tiles = (int)tiles.size();
+    // Scenes of thousands of edges (cfg 5: one of 39 800): 256 queries per block share every K / V tile -- half the L2 -> LDS bytes
+    // per query, and the partly filled last tile is < 1/16 of a scene.  Built only when EVERY scene is that large (one table, one
+    // block size per launch); the forward uses it for half rows at head dim 64 (engine_forward.hip).
+    std::vector<int4> tiles_big;
+    if (h->edge_scope == 0 && p->fa_parts <= 1 && E > 0 && E * (int64_t)(2 * D) * 4 < (int64_t)1 << 32) {
+        int64_t min_t = INT64_MAX;
+        for (int s = 0; s < p->S; ++s) { const int64_t T = p->edge_ptr[s + 1] - p->edge_ptr[s]; if (T > 0) min_t = std::min(min_t, T); }
+        if (min_t >= 4096 && min_t != INT64_MAX)
+            for (int s = 0; s < p->S; ++s) {
+                const int64_t T = p->edge_ptr[s + 1] - p->edge_ptr[s];
+                for (int hh = 0; hh < H; ++hh)
+                    for (int64_t q0 = 0; q0 < T; q0 += FLASH_BQ_BIG) tiles_big.push_back(make_int4((int)p->edge_ptr[s], (int)T, (int)q0, hh));
+            }
+        if (tiles_big.size() < 1024) tiles_big.clear();          // (two rounds of the 512 resident blocks, as for the key split above)
+    }
+    p->n_tiles_big = (int)tiles_big.size();
     // ---- one device arena; the index tables come first, in the order they are packed into the staging buffer ----
     struct Item { void** dst; size_t bytes; const void* host; };
     std::vector<Item> items;
@@ -225,6 +241,7 @@ int vlsat_plan_create(vlsat_handle h, const int64_t* bid, const int64_t* edges, 
     want(&p->d_edge_ptr32, (size_t)p->S + 1, edge_ptr32.data());
     want(&p->d_tiles, std::max<size_t>(tiles.size(), 1), tiles.empty() ? nullptr : tiles.data());
     if (p->fa_parts > 1) want(&p->d_krange, krange.size(), krange.data());
+    if (!tiles_big.empty()) want(&p->d_tiles_big, tiles_big.size(), tiles_big.data());
     const size_t n_index_items = items.size();
     want(&p->F, Ns * 768); want(&p->X3, Ns * LDX); want(&p->X2, Ns * LDX); want(&p->NP, Ns * NPC);
     want(&p->QKVn, Ns * 1536); want(&p->On, Ns * 512); want(&p->T256, Ns * 256); want(&p->T768, Ns * LDX);

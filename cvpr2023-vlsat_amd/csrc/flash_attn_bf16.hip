@@ -123,8 +123,11 @@ __device__ __forceinline__ void planes_of(const f32x4& x, bf16x4& hi, bf16x4& lo
 // the 16-byte chunks XOR-swizzled by (row >> 1) & 7 on the global side and on the fragment reads (an LDS-direct load writes
 // lane-linear, so the 144-byte row pitch of the register-staged image cannot be produced); the V image is unchanged (four
 // [64 keys][16 d] sub-tiles: a wave instruction fills 32 keys x 32 B of one of them).
-template <int TERMS, bool TR, int IO, int PVT = 3, int FB_D = 64, int RING = 0>
-__global__ __launch_bounds__(256, 2) void flash_attn_bf16_kernel(
+// BQW: waves = 32-query groups per block: 4 (128 queries, the default) or -- LDS-direct staging only -- 8 (256 queries sharing every
+// K / V tile: half the L2 -> LDS bytes per query; for scenes of thousands of tokens, whose K / V no longer sit in one XCD's L2 and
+// whose last, partly filled query tile is a negligible share: round 5, +4 % at cfg 5)
+template <int TERMS, bool TR, int IO, int PVT = 3, int FB_D = 64, int RING = 0, int BQW = 4>
+__global__ __launch_bounds__(64 * BQW, 2) void flash_attn_bf16_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
     float* __restrict__ O, int ldq, int ldkv, int ldo, const int4* __restrict__ tiles, int n_tiles,
     float scale_log2e, FlashSplit sp) {
@@ -139,11 +142,12 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bf16_kernel(
     // (DMA) K image: 64 rows of ROWB = 2 FB_D bytes, unpadded (an LDS-direct load writes lane-linear), 16-byte chunks XOR-swizzled with
     // KSWZ(row) on the global side and on the fragment reads: 64-byte rows (row >> 2) & 3, 128-byte rows (row >> 1) & 7, 256-byte rows row & 15
     constexpr int ROWB = 2 * FB_D, CPR = ROWB / 16, RPI = 1024 / ROWB;          // bytes per K row, chunks per row, rows per load instruction
-    constexpr int KI = FB_KV / RPI / 4, VI = 2 * NSUB / 4, LPT = KI + VI;      // load instructions per wave and tile: K, V, both
+    static_assert(BQW == 4 || (BQW == 8 && RING != 0 && FB_D == 64), "eight waves: the LDS-direct variant at head dim 64");
+    constexpr int KI = FB_KV / RPI / BQW, VI = 2 * NSUB / BQW, LPT = KI + VI;      // load instructions per wave and tile: K, V, both
     constexpr int KBYTES = FB_KV * ROWB;
     constexpr int BUF = DMA ? KBYTES + FB_VPLANE : PL * (FB_KPLANE + FB_VPLANE);
     constexpr int NBUF = DMA ? RING : 2, LA = NBUF - 1;           // (DMA) tiles of look-ahead
-    constexpr int SMEM = NBUF * BUF > 4 * 32 * FB_OPITCH * 4 ? NBUF * BUF : 4 * 32 * FB_OPITCH * 4;
+    constexpr int SMEM = NBUF * BUF > BQW * 32 * FB_OPITCH * 4 ? NBUF * BUF : BQW * 32 * FB_OPITCH * 4;
     __shared__ __attribute__((aligned(16))) char smem[SMEM];
 
     const int tile_id = xcd_remap(blockIdx.x, n_tiles);
@@ -510,7 +514,10 @@ int launch_flash_attn_bf16(const float* Q, int ldq, const float* K, const float*
         if (!sp.krange || !sp.o_part || !sp.m_part || !sp.l_part || sp.heads * FB_D > ldo)
             return fail(-1, "flash_attn: incomplete split-key workspace");
     }
-    if (split) sp.ablate = split->ablate;
+    if (split) { sp.ablate = split->ablate; sp.bq = split->bq; sp.rows = split->rows; }
+    if (sp.bq != FLASH_BQ && !(sp.bq == FLASH_BQ_BIG && FB_D == 64 && io_split == 2 && use_tr == 1 && sp.parts <= 1 && sp.rows > 0 &&
+                               (size_t)sp.rows * (size_t)ldkv * 4 < (1ull << 32)))
+        return fail(-1, "flash_attn_bf16: 256-query tiles are built for half rows, head dim 64, the LDS-direct kernel, no key split");
     // The LDS-direct K / V staging addresses a scene with 32-bit byte offsets (buffer descriptor of n_tok * ldkv * 4 bytes, row * ld4
     // VGPR offsets): only where every scene's rows are known to span less than 4 GiB -- the caller states the rows of the whole
     // tensor in FlashSplit::rows (an upper bound of any scene, and of the batch-wide attention of batch_mode 'reference').  Unknown
@@ -540,6 +547,8 @@ int launch_flash_attn_bf16(const float* Q, int ldq, const float* K, const float*
             hipLaunchKernelGGL((flash_attn_bf16_kernel<1, true, 2, 3, 64, 3>), dim3(n_tiles), dim3(256), 0, s, Q, K, V, O, ldq, ldkv, ldo, tiles, n_tiles, scale_log2e, sp);
         else if (use_tr == 4)
             hipLaunchKernelGGL((flash_attn_bf16_kernel<1, true, 2, 3, 64, 4>), dim3(n_tiles), dim3(256), 0, s, Q, K, V, O, ldq, ldkv, ldo, tiles, n_tiles, scale_log2e, sp);
+        else if (use_tr != 2 && sp.bq == FLASH_BQ_BIG)
+            hipLaunchKernelGGL((flash_attn_bf16_kernel<1, true, 2, 3, 64, 2, 8>), dim3(n_tiles), dim3(512), 0, s, Q, K, V, O, ldq, ldkv, ldo, tiles, n_tiles, scale_log2e, sp);
         else if (use_tr != 2)       // (use_tr = 2: the register-staged kernel of round 3, for A/B -- "flash_dma" 0)
             hipLaunchKernelGGL((flash_attn_bf16_kernel<1, true, 2, 3, 64, 2>), dim3(n_tiles), dim3(256), 0, s, Q, K, V, O, ldq, ldkv, ldo, tiles, n_tiles, scale_log2e, sp);
         else

@@ -82,6 +82,7 @@ struct FlashSplit {
     size_t part_stride = 0;      // floats between parts of o_part (= rows * ldo)
     int rows = 0, heads = 0;
     int ablate = 0;              // timing experiments (garbage results): bit 0 no K/V loads after the first tile, bit 1 no LDS stores of them either
+    int bq = 128;                // queries per block of the tile table handed in: FLASH_BQ, or FLASH_BQ_BIG (half rows, head dim 64, LDS-direct kernel only)
 };
 int launch_flash_attn(const float* Q, int ldq, const float* K, const float* V, int ldkv, float* O, int ldo,
                       const int4* tiles, int n_tiles, float scale_log2e, hipStream_t s, const FlashSplit* split = nullptr,
@@ -95,6 +96,7 @@ int launch_flash_attn_bf16(const float* Q, int ldq, const float* K, const float*
                            hipStream_t s, const FlashSplit* split = nullptr, int pv_terms = 3, int head_dim = 64);
 bool flash_attn_bf16_supports(int head_dim, int terms, int use_tr, int io_split);   // which (head dim, format) combinations are built
 constexpr int FLASH_BQ = 128;   // queries per block
+constexpr int FLASH_BQ_BIG = 256;   // ... of the eight-wave variant for scenes of thousands of tokens (FlashSplit::bq)
 
 // ---- node attention with distance bias (per scene, per head) ----
 // scene_ptr: device [n_scenes+1] node offsets; bias_ptr: device [n_scenes] offsets into bias

@@ -204,3 +204,35 @@ def test_mode_bf16x3_attn1_keeps_the_3d_branch_and_holds_the_2d_branch_at_stress
     r = m.auto_precision(*args, tol=1e-2)
     assert r["mode"] == "bf16x3_attn1", r
     m.close()
+
+
+def test_256_query_attention_tiles_are_bit_identical_to_128_query_tiles():
+    """Plans whose scenes all have >= 4096 edges run the half-row edge attention (reference network_MMG.py:228-234) with 256 queries
+    per block (eight waves share every K / V tile: engine_plan.hip `tiles_big`).  A query's arithmetic does not depend on the block it
+    sits in -- one wave per 32 queries, keys in the same order -- so the outputs must equal the 128-query launch BIT FOR BIT; scene
+    sizes that are not multiples of 256 (and one that is not a multiple of 32) exercise the partly filled last tile.  Against the
+    fp64 oracle: one scene, BASELINE configs[2]'s 1e-2 for the single-rounding mode."""
+    from oracle import vlsat_oracle as O
+    cfg = VLSATConfig(N_LAYERS=2)
+    w = synth.make_weights(cfg, seed=5)
+    sizes = (66, 67, 70, 65, 72, 66, 69, 68)                     # 4290 ... 5112 edges each: 8 scenes x 8 heads x 17..20 tiles >= 1024
+    scenes = [synth.make_scene(n, 128, 300 + i) for i, n in enumerate(sizes)]
+    d = {k: torch.from_numpy(v).to(DEV) for k, v in synth.collate(scenes).items()}
+    args = (d["obj_points"], d["obj_2d_feats"], d["edge_indices"], d["descriptor"], d["batch_ids"])
+    m = _model(cfg, w).set_gemm_precision("bf16_mixed")
+    big = [o.clone() for o in m(*args)]
+    m.debug_option("flash_bq_big", 0)
+    small = [o.clone() for o in m(*args)]
+    for n, a, b in zip(NAMES, big, small):
+        assert torch.equal(a, b), n
+    m.debug_option("flash_bq_big", 1)
+    again = [o.clone() for o in m(*args)]
+    assert all(torch.equal(a, b) for a, b in zip(big, again))
+    c = {k: torch.from_numpy(v) for k, v in synth.collate([scenes[0]]).items()}
+    ref = O.forward(O.to_torch(w, torch.float64), cfg, c["obj_points"].double(), c["obj_2d_feats"].double(), c["edge_indices"],
+                    c["descriptor"].double(), c["batch_ids"])
+    n0, e0 = sizes[0], sizes[0] * (sizes[0] - 1)
+    errs = [float((g[:k].cpu() - r.float()).abs().max()) for g, r, k in zip(big, ref, (n0, n0, e0, e0))]
+    print("256-query tiles, scene 0 vs fp64 oracle", [f"{e:.2e}" for e in errs])
+    assert max(errs) < 1e-2, errs
+    m.close()
