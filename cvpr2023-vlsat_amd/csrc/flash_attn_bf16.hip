@@ -126,7 +126,9 @@ __device__ __forceinline__ void planes_of(const f32x4& x, bf16x4& hi, bf16x4& lo
 // BQW: waves = 32-query groups per block: 4 (128 queries, the default) or -- LDS-direct staging only -- 8 (256 queries sharing every
 // K / V tile: half the L2 -> LDS bytes per query; for scenes of thousands of tokens, whose K / V no longer sit in one XCD's L2 and
 // whose last, partly filled query tile is a negligible share: round 5, +4 % at cfg 5)
-template <int TERMS, bool TR, int IO, int PVT = 3, int FB_D = 64, int RING = 0, int BQW = 4>
+// ABL (experiments build only, compile-time so that the shipped code generation is what gets timed; results are GARBAGE): 4 no exponentials,
+// 8 no maximum, 16 no cross-half exchanges, 32 no P.V MFMAs, 64 no Q.K MFMAs, 256 no barrier per tile
+template <int TERMS, bool TR, int IO, int PVT = 3, int FB_D = 64, int RING = 0, int BQW = 4, int ABL = 0>
 __global__ __launch_bounds__(64 * BQW, 2) void flash_attn_bf16_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
     float* __restrict__ O, int ldq, int ldkv, int ldo, const int4* __restrict__ tiles, int n_tiles,
@@ -320,6 +322,10 @@ __global__ __launch_bounds__(64 * BQW, 2) void flash_attn_bf16_kernel(
                         s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh0, ql[ks], s[0], 0, 0, 0);
                         s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh1, ql[ks], s[1], 0, 0, 0);
                     }
+                    if ((ABL & 64)) {           // no QK MFMAs (the fragments stay read)
+                        asm volatile("" :: "v"(kh0), "v"(kh1));
+                        continue;
+                    }
                     s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh0, qh[ks], s[0], 0, 0, 0);
                     s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh1, qh[ks], s[1], 0, 0, 0);
                 }
@@ -355,7 +361,8 @@ __global__ __launch_bounds__(64 * BQW, 2) void flash_attn_bf16_kernel(
                 mx = max3f(ma, mb, s[0][15]);
                 mx = max3f(mx, s[1][15], s[1][15]);
             }
-            mx = max3f(mx, __shfl_xor(mx, 32), mx);
+            if (!((ABL & 16))) mx = max3f(mx, __shfl_xor(mx, 32), mx);       // (ablate 16: no cross-half exchanges)
+            if ((ABL & 8)) mx = 0.f;                                        // (ablate 8: no maximum at all)
             const float m_new = max3f(m_run, mx, mx);
             // (a part whose first tile is fully masked for this query keeps m = -inf; exp2(-inf - -inf) must not be NaN)
             const float m_use = m_new == -INFINITY ? 0.f : m_new;
@@ -366,14 +373,16 @@ __global__ __launch_bounds__(64 * BQW, 2) void flash_attn_bf16_kernel(
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
                     f32x2 x = pk_sub(f32x2{s[kb][r], s[kb][r + 1]}, m_use);
-                    x[0] = __builtin_amdgcn_exp2f(x[0]);
-                    x[1] = __builtin_amdgcn_exp2f(x[1]);
+                    if (!((ABL & 4))) {                                      // (ablate 4: no exponentials)
+                        x[0] = __builtin_amdgcn_exp2f(x[0]);
+                        x[1] = __builtin_amdgcn_exp2f(x[1]);
+                    }
                     rs2 = pk_add(rs2, x);
                     s[kb][r] = x[0];
                     s[kb][r + 1] = x[1];
                 }
             float rs = rs2[0] + rs2[1];
-            rs += __shfl_xor(rs, 32);
+            if (!((ABL & 16))) rs += __shfl_xor(rs, 32);
             l_run = l_run * alpha + rs;
             m_run = m_new;
             if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {
@@ -427,6 +436,10 @@ __global__ __launch_bounds__(64 * BQW, 2) void flash_attn_bf16_kernel(
                         for (int db = 0; db < NO; ++db) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db][0], pl, o[db], 0, 0, 0);
                     }
                 }
+                if ((ABL & 32)) {               // no PV MFMAs (P converted, V fragments read)
+                    asm volatile("" :: "v"(ph), "v"(vf[0][0]), "v"(vf[NO - 1][0]));
+                    continue;
+                }
 #pragma unroll
                 for (int db = 0; db < NO; ++db) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db][0], ph, o[db], 0, 0, 0);
             }
@@ -434,7 +447,8 @@ __global__ __launch_bounds__(64 * BQW, 2) void flash_attn_bf16_kernel(
         if (DMA) {
             // tile kt + 1 has landed once only the tiles issued after it (kt + 2 .. kt + LA, as far as they exist) are outstanding
             wait_tiles((kExperiments && (sp.ablate & 1)) ? 0 : min(LA - 1, kt1 - kt - 2));
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if ((ABL & 256)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (ablate 256: no barrier per tile)
+            else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             ring = ring == NBUF - 1 ? 0 : ring + 1;
         } else {
             if (more && !(kExperiments && (sp.ablate & 2))) store_tile(smem + ((kt + 1) & 1) * BUF);
@@ -487,6 +501,7 @@ __global__ __launch_bounds__(64 * BQW, 2) void flash_attn_bf16_kernel(
         }
     }
 }
+
 
 }  // namespace
 
@@ -547,6 +562,12 @@ int launch_flash_attn_bf16(const float* Q, int ldq, const float* K, const float*
             hipLaunchKernelGGL((flash_attn_bf16_kernel<1, true, 2, 3, 64, 3>), dim3(n_tiles), dim3(256), 0, s, Q, K, V, O, ldq, ldkv, ldo, tiles, n_tiles, scale_log2e, sp);
         else if (use_tr == 4)
             hipLaunchKernelGGL((flash_attn_bf16_kernel<1, true, 2, 3, 64, 4>), dim3(n_tiles), dim3(256), 0, s, Q, K, V, O, ldq, ldkv, ldo, tiles, n_tiles, scale_log2e, sp);
+#ifdef VLSAT_EXPERIMENTS
+#define VLSAT_FA_ABL(A) else if (use_tr != 2 && sp.bq == FLASH_BQ_BIG && (sp.ablate & ~3) == (A)) \
+            hipLaunchKernelGGL((flash_attn_bf16_kernel<1, true, 2, 3, 64, 2, 8, A>), dim3(n_tiles), dim3(512), 0, s, Q, K, V, O, ldq, ldkv, ldo, tiles, n_tiles, scale_log2e, sp);
+        VLSAT_FA_ABL(4) VLSAT_FA_ABL(8) VLSAT_FA_ABL(16) VLSAT_FA_ABL(28) VLSAT_FA_ABL(32) VLSAT_FA_ABL(64) VLSAT_FA_ABL(96) VLSAT_FA_ABL(256) VLSAT_FA_ABL(124) VLSAT_FA_ABL(380)
+#undef VLSAT_FA_ABL
+#endif
         else if (use_tr != 2 && sp.bq == FLASH_BQ_BIG)
             hipLaunchKernelGGL((flash_attn_bf16_kernel<1, true, 2, 3, 64, 2, 8>), dim3(n_tiles), dim3(512), 0, s, Q, K, V, O, ldq, ldkv, ldo, tiles, n_tiles, scale_log2e, sp);
         else if (use_tr != 2)       // (use_tr = 2: the register-staged kernel of round 3, for A/B -- "flash_dma" 0)

@@ -12,6 +12,18 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// KIND: 0 v_add_f32, 1 v_exp_f32, 2 v_pk_add_f32, 3 v_max3_f32, 4 v_cvt_pk_bf16_f32, 5 v_pk_mul_f32, 6 v_mul_f32 (round 5: which of the
+// softmax's instructions share something with the matrix pipe?)
+template <int KIND> __device__ __forceinline__ void valu(float& x, f32x2& y) {
+    if (KIND == 0) asm volatile("v_add_f32 %0, 1.0, %0" : "+v"(x));
+    else if (KIND == 1) asm volatile("v_exp_f32 %0, %0" : "+v"(x));
+    else if (KIND == 2) asm volatile("v_pk_add_f32 %0, %0, %0" : "+v"(y));
+    else if (KIND == 3) asm volatile("v_max3_f32 %0, %0, %0, %0" : "+v"(x));
+    else if (KIND == 4) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %0" : "+v"(x));
+    else if (KIND == 5) asm volatile("v_pk_mul_f32 %0, %0, %0" : "+v"(y));
+    else asm volatile("v_mul_f32 %0, %0, %0" : "+v"(x));
+}
 template <int NV, int KIND, bool INTER>
 __global__ __launch_bounds__(256, 2) void probe(const bf16x8* in, float* out, long long* cyc, int iters) {
     bf16x8 a[4], b[4];
@@ -19,6 +31,8 @@ __global__ __launch_bounds__(256, 2) void probe(const bf16x8* in, float* out, lo
     f32x16 c[4] = {};
     float v[8];
     for (int i = 0; i < 8; ++i) v[i] = (float)threadIdx.x * 1e-3f + i;
+    f32x2 v2[4];
+    for (int i = 0; i < 4; ++i) v2[i] = f32x2{v[i], v[i + 4]};
     const long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -29,16 +43,14 @@ __global__ __launch_bounds__(256, 2) void probe(const bf16x8* in, float* out, lo
 #pragma unroll
                 for (int k = 0; k < NV / 8; ++k) {
                     const int i = (m * (NV / 8) + k) & 7;
-                    if (KIND == 0) asm volatile("v_add_f32 %0, 1.0, %0" : "+v"(v[i]));
-                    else asm volatile("v_exp_f32 %0, %0" : "+v"(v[i]));
+                    valu<KIND>(v[i], v2[i & 3]);
                 }
             }
         }
         if (!INTER) {
 #pragma unroll
             for (int k = 0; k < NV; ++k) {
-                if (KIND == 0) asm volatile("v_add_f32 %0, 1.0, %0" : "+v"(v[k & 7]));
-                else asm volatile("v_exp_f32 %0, %0" : "+v"(v[k & 7]));
+                valu<KIND>(v[k & 7], v2[k & 3]);
             }
         }
     }
@@ -46,6 +58,7 @@ __global__ __launch_bounds__(256, 2) void probe(const bf16x8* in, float* out, lo
     float s = 0;
     for (int r = 0; r < 16; ++r) s += c[0][r] + c[1][r] + c[2][r] + c[3][r];
     for (int i = 0; i < 8; ++i) s += v[i];
+    for (int i = 0; i < 4; ++i) s += v2[i][0] + v2[i][1];
     out[blockIdx.x * 256 + threadIdx.x] = s;
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
@@ -70,7 +83,7 @@ static void run(const bf16x8* in, float* out, long long* cyc, int waves_per_simd
     // s_memtime counts at a constant 100 MHz on this part; convert with the wall time: cycles of the SIMD per iteration of ONE wave
     const double tf = (double)blocks * 4 * iters * 8 * 32768.0 / ms / 1e9;
     printf("%-5s %2d %s per 8 MFMAs, %s, %d wave(s)/SIMD: %7.3f ms, %6.1f TFLOP/s of MFMA, %6.1f ns per wave-iteration (MFMA pipe alone: %d waves x 256 cyc)\n",
-           KIND ? "exp" : "add", NV, "VALU", INTER ? "interleaved" : "grouped    ", waves_per_simd, ms, tf, ms * 1e6 / iters, waves_per_simd);
+           KIND == 0 ? "add" : KIND == 1 ? "exp" : KIND == 2 ? "pkadd" : KIND == 3 ? "max3" : KIND == 4 ? "cvtpk" : KIND == 5 ? "pkmul" : "mul", NV, "VALU", INTER ? "interleaved" : "grouped    ", waves_per_simd, ms, tf, ms * 1e6 / iters, waves_per_simd);
 }
 
 int main() {
@@ -90,5 +103,14 @@ int main() {
         run<32, 1, false>(in, out, cyc, w);
         run<32, 1, true>(in, out, cyc, w);
     }
+    // round 5: instruction kinds of the softmax, 4 waves per SIMD, grouped (what the attention kernels do)
+    run<64, 2, false>(in, out, cyc, 4);
+    run<64, 3, false>(in, out, cyc, 4);
+    run<64, 4, false>(in, out, cyc, 4);
+    run<64, 5, false>(in, out, cyc, 4);
+    run<64, 6, false>(in, out, cyc, 4);
+    run<64, 2, true>(in, out, cyc, 4);
+    run<64, 3, true>(in, out, cyc, 4);
+    run<64, 4, true>(in, out, cyc, 4);
     return 0;
 }
