@@ -67,3 +67,40 @@ def fc_edges_batch(n_per_scene):
         bids.append(torch.full((n, 1), s, dtype=torch.long))
         off += n
     return torch.cat(edges, 0), torch.cat(bids, 0)
+
+
+def scene_labels(instances: np.ndarray, instance2label: dict, class_names, rel_json, relation_names, multi_rel_outputs=True, all_edge=True):
+    """Node order, edge list and ground truth of one scene, loop by loop as the reference's data_preparation builds them
+    (src/dataset/dataset_3dssg.py:248-270 nodes and edges, :281-283 object labels, :300-314 adjacency, :322-336 per-edge labels).
+    Restated, not pinned: the dataset module imports trimesh, which this image lacks.  -> nodes, edges [E,2], gt_class [N], gt_rel."""
+    ids_with_points = list(np.unique(instances))
+    if 0 in ids_with_points:
+        ids_with_points.remove(0)                                   # background
+    nodes = []
+    for inst in list(instance2label.keys()):
+        if inst in ids_with_points:
+            nodes.append(inst)
+    if all_edge:
+        edges = []
+        for i in range(len(nodes)):
+            for j in range(len(nodes)):
+                if i != j:
+                    edges.append((i, j))
+    else:
+        edges = [(nodes.index(r[0]), nodes.index(r[1])) for r in rel_json if r[0] in nodes and r[1] in nodes]
+    gt_class = [list(class_names).index(instance2label[inst]) for inst in nodes]
+    n, R = len(nodes), len(relation_names)
+    adj = np.zeros([n, n, R]) if multi_rel_outputs else np.zeros([n, n])
+    for r in rel_json:
+        if r[0] not in nodes or r[1] not in nodes:
+            continue
+        assert r[3] in relation_names
+        k = list(relation_names).index(r[3])
+        if multi_rel_outputs:
+            adj[nodes.index(r[0]), nodes.index(r[1]), k] = 1
+        else:
+            adj[nodes.index(r[0]), nodes.index(r[1])] = k
+    gt = np.zeros([len(edges), R], dtype=np.float32) if multi_rel_outputs else np.zeros([len(edges)], dtype=np.int64)
+    for e, (a, b) in enumerate(edges):
+        gt[e] = adj[a, b]
+    return nodes, np.asarray(edges, dtype=np.int64).reshape(-1, 2), np.asarray(gt_class, dtype=np.int64), gt
