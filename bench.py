@@ -32,6 +32,9 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf
 # profiles/r04_probes/mfma_peak_bf16.txt: 1.78-1.83 PF; the clock drops to ~1.8 GHz under matrix load) -- printed next to the
 # 2.5 PF headline peak as `peak_sustained`, never instead of it
 SUSTAINED_BF16_MFMA_TFLOPS = 1800.0
+# the fp32 matrix pipe at the clock the chip holds under these GEMMs with real operands (2.04-2.09 GHz instead of 2.4: in-kernel
+# s_memtime against the wall clock, tools/gemm_clock_probe.py, profiles/r05_probes/gemm_clock_probe.txt) -- same role
+SUSTAINED_FP32_MFMA_TFLOPS = 136.0
 # peak of the mode's matrix work counted in ALGORITHMIC flops: split-bf16 issues three bf16 MFMAs per product
 MODE_PEAK = {"fp32": PEAK_FP32_MFMA_TFLOPS, "bf16x3": PEAK_BF16_MFMA_TFLOPS / 3, "bf16": PEAK_BF16_MFMA_TFLOPS,
              "bf16_mixed": PEAK_BF16_MFMA_TFLOPS, "bf16x3_attn1": PEAK_BF16_MFMA_TFLOPS / 3}
@@ -179,8 +182,8 @@ def roofline_of(classes, mode, steps, falg, value, world, traffic=None, traffic_
                           "bf16": "2.5 PF bf16 dense", "bf16_mixed": "2.5 PF bf16 dense",
                           "bf16x3_attn1": "2.5 PF bf16 dense / 3 MFMAs per product (GEMM class; the attention runs single-rounded)"}[mode],
             "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-            "peak_sustained": None if mode == "fp32" else round(SUSTAINED_BF16_MFMA_TFLOPS / (3 if mode in ("bf16x3", "bf16x3_attn1") else 1), 1),
-            "frac_of_sustained": None if mode == "fp32" else round(achieved / (SUSTAINED_BF16_MFMA_TFLOPS / (3 if mode in ("bf16x3", "bf16x3_attn1") else 1)), 4),
+            "peak_sustained": SUSTAINED_FP32_MFMA_TFLOPS if mode == "fp32" else round(SUSTAINED_BF16_MFMA_TFLOPS / (3 if mode in ("bf16x3", "bf16x3_attn1") else 1), 1),
+            "frac_of_sustained": round(achieved / SUSTAINED_FP32_MFMA_TFLOPS, 4) if mode == "fp32" else round(achieved / (SUSTAINED_BF16_MFMA_TFLOPS / (3 if mode in ("bf16x3", "bf16x3_attn1") else 1)), 4),
             "traffic": traffic,
             "traffic_unit": "HBM bytes per launch (PMC)", "traffic_source": traffic_src, "traffic_measured": bool(traffic_measured),
             "traffic_stale": None if traffic is None else (False if traffic_measured else bool(traffic_stale)),

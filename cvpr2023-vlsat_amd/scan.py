@@ -73,10 +73,13 @@ def read_ply(path: str) -> Dict[str, Optional[np.ndarray]]:
                 if not scalar:
                     raise ScanError(f"{path}: list property inside the vertex element")
                 if fmt == "ascii":
-                    rows = [f.readline().split() for _ in range(count)]
-                    if any(len(r) != len(props) for r in rows):
-                        raise ScanError(f"{path}: vertex rows do not have {len(props)} values")
-                    table = np.array(rows, dtype=np.float64).reshape(count, len(props))
+                    vals = b" ".join(f.readline() for _ in range(count)).split()
+                    if len(vals) != count * len(props):
+                        raise ScanError(f"{path}: vertex rows do not hold {count} x {len(props)} values")
+                    try:
+                        table = np.array(vals, dtype=np.float64).reshape(count, len(props))
+                    except ValueError:
+                        raise ScanError(f"{path}: a vertex value is not a number") from None
                     vert = {p: table[:, i] for i, (p, _) in enumerate(props)}
                 else:
                     dt = np.dtype([(p, "<" + t) for p, t in props])
