@@ -237,3 +237,53 @@ def test_256_query_attention_tiles_are_bit_identical_to_128_query_tiles(mode, to
     print("256-query tiles,", mode, "scene 0 vs fp64 oracle", [f"{e:.2e}" for e in errs])
     assert max(errs) < tol, errs
     m.close()
+
+
+def _fc_index(n, i, j):
+    """position of edge (i, j), i != j, in the source-major fully connected list of n nodes"""
+    return i * (n - 1) + (j if j < i else j - 1)
+
+
+@pytest.mark.parametrize("mode,tol_obj,tol_rel", [("fp32", 1e-4, 1e-5), ("bf16_mixed", 1e-2, 1e-2)])
+def test_object_permutation_equivariance_at_the_full_bench_size(mode, tol_obj, tol_rel):
+    """A property of the path that needs no oracle and holds at any size (BASELINE configs[1]: 64 scenes x 40 objects x 256 points,
+    L = 3): relabelling the objects of every scene permutes the outputs and changes nothing else -- node rows by the permutation,
+    the row of edge (i, j) moves to where (perm^-1 i, perm^-1 j) sits in the fully connected list (reference: every op of
+    network_MMG.py:212-250 is a per-node / per-edge map, a gather by edge index, a scatter by source node or an attention over a
+    scene's own rows).  Summation orders change (attention keys, aggregation), so equality is up to fp32 reassociation; in the
+    single-rounding mode up to its rounding noise.  Permuting the POINTS of every object must change nothing at all: the encoder
+    reduces over points with a maximum, and a point's features do not depend on its position."""
+    cfg = VLSATConfig(N_LAYERS=3)
+    S, N, P = 64, 40, 256
+    E = N * (N - 1)
+    b = synth.make_batch(S, N, P)
+    g = np.random.default_rng(7)
+    perms = [g.permutation(N) for _ in range(S)]                  # new node k of scene s = old node perms[s][k]
+    node_map = np.concatenate([s * N + p for s, p in enumerate(perms)])
+    pb = dict(b)
+    for k in ("obj_points", "obj_2d_feats", "descriptor"):
+        pb[k] = np.ascontiguousarray(b[k][node_map])
+    edge_map = np.empty(S * E, dtype=np.int64)                    # new edge row -> old edge row
+    for s, p in enumerate(perms):
+        i, j = np.divmod(np.arange(E), N - 1)
+        j = j + (j >= i)
+        oi, oj = p[i], p[j]
+        edge_map[s * E:(s + 1) * E] = s * E + oi * (N - 1) + np.where(oj < oi, oj, oj - 1)
+    assert _fc_index(N, 3, 1) == 3 * 39 + 1 and _fc_index(N, 3, 7) == 3 * 39 + 6
+    m = _model(cfg, synth.make_weights(cfg)).set_gemm_precision(mode)
+    dev = lambda d: [torch.from_numpy(d[k]).to(DEV) for k in ("obj_points", "obj_2d_feats", "edge_indices", "descriptor", "batch_ids")]
+    base = [o.clone() for o in m(*dev(b))]
+    perm = [o.clone() for o in m(*dev(pb))]
+    nm, em = torch.from_numpy(node_map).to(DEV), torch.from_numpy(edge_map).to(DEV)
+    errs = [float((perm[0] - base[0][nm]).abs().max()), float((perm[1] - base[1][nm]).abs().max()),
+            float((perm[2] - base[2][em]).abs().max()), float((perm[3] - base[3][em]).abs().max())]
+    print(mode, "object permutation, max abs difference", [f"{e:.2e}" for e in errs])
+    assert errs[0] < tol_obj and errs[1] < tol_obj and errs[2] < tol_rel and errs[3] < tol_rel, errs
+    assert not torch.equal(perm[0], base[0])                      # (the permutation did something)
+    qb = dict(b)
+    pp = g.permutation(P)
+    qb["obj_points"] = np.ascontiguousarray(b["obj_points"][:, :, pp])
+    shuffled = m(*dev(qb))
+    for n, x, y in zip(NAMES, base, shuffled):
+        assert torch.equal(x, y), f"{n}: the order of an object's points changed the output"
+    m.close()
