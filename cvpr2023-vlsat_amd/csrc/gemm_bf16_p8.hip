@@ -491,7 +491,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmArgs p, int n_tiles
             for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int row = m0 + wr * 128 + tm * 32 + g * 8 + (lane >> 3);
+                    const int row = min(m0 + wr * 128 + tm * 32 + g * 8 + (lane >> 3), p.M - 1);
                     const float* r0 = p.g0 + (size_t)p.gi0[row] * p.ldg0 + n0 + wc * 64 + (lane & 7) * 4;
                     const float* r1 = p.g1 + (size_t)p.gi1[row] * p.ldg1 + n0 + wc * 64 + (lane & 7) * 4;
 #pragma unroll
@@ -548,7 +548,9 @@ int launch_gemm_p8(const GemmArgs& a, int n_tiles, int grid, hipStream_t s) {
     if (f32 ? (a.a_split || a.c_split || a.r_split || a.c_scale != 1.f)
             : x3 ? (a.a_split != 1 || a.c_split == 2 || !a.Wlo) : (a.prec != 1 || a.a_split != 2 || a.c_split == 1)) return 1;
     const int kt = (f32 || x3) ? 32 : P8_BK;          // an output tile is an even number (>= 4) of K-tiles
-    if (a.N % P8_BN || a.K % (2 * kt) || a.K < 4 * kt || a.M % P8_BM) return 1;
+    // (M need not be a multiple of the tile: the last panel's rows past M are outside every buffer descriptor -- loads return zeros,
+    //  stores are dropped -- and tile_init clamps the row of an additive operand)
+    if (a.N % P8_BN || a.K % (2 * kt) || a.K < 4 * kt || n_tiles > (long)((a.M + P8_BM - 1) / P8_BM) * (a.N / P8_BN)) return 1;
     const int nbn = a.N / P8_BN;
     if (grid % 8 || (grid / 8) % nbn) return 1;      // the kernel keeps one column tile per block (bias registers)
 #define VLSAT_P8(MODE, ADD, RELU, CF) hipLaunchKernelGGL((gemm_p8_kernel<MODE, ADD, RELU, CF>), dim3(grid), dim3(512), 0, s, a, n_tiles, nbn)

@@ -274,7 +274,10 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
         ((size_t)a.M + 256) * a.lda * 4 < (1ull << 32) && ((size_t)a.M + 256) * a.ldc * 4 < (1ull << 32) &&
         ((size_t)a.N + 256) * a.ldw * 4 < (1ull << 32)) {
         const int G1 = G / 2;
-        const long nbn = a.N / 256, panels = a.M / 256, rounds = panels * nbn / G1;
+        // (a last, partly filled panel rides along with a partial round: rows past M read as zeros through the buffer descriptors,
+        //  their stores are dropped by them, additive operands clamp the row -- round 5: the 120-row remainder of the cfg 5 scene
+        //  no longer is a launch of its own)
+        const long nbn = a.N / 256, full = a.M / 256, panels = full + (a.M % 256 ? 1 : 0), rounds = full * nbn / G1;
         long main_panels = rounds * G1 / nbn;
         // less than one round left (the tail of a big launch, or a medium-sized one): a partial round costs a whole tile time
         // (one tile per CU), the 128 x 128 kernels ~0.7 (fp32) / ~0.5 (bf16) of it per full round of tiles -- from 5/8 of a
@@ -285,7 +288,7 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
         if (main_panels == 0 && panels * nbn >= (a.prec == 1 ? 32 : (G1 * 5) / 8)) main_panels = panels;
         if (main_panels > 0) {
             GemmArgs m = a;
-            m.M = (int)(main_panels * 256);
+            m.M = (int)std::min<long>(main_panels * 256, a.M);
             const int r = launch_gemm_p8(m, (int)(main_panels * nbn), G1, s);
             if (r < 0) return r;
             if (r == 0) {
