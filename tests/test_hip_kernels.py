@@ -632,13 +632,14 @@ def test_gemm_bf16_p8_kernel(lib, N, K, resid, gather, relu_a, act, c_half):
     assert float((got.double() - ref).abs().max()) <= tol
 
 
+@pytest.mark.parametrize("tail", [5, 90])          # remainder panels: 5 -> small kernels; 90 (+ 33 rows) -> a partial 8-phase round WITH the ragged last panel
 @pytest.mark.parametrize("N,K,resid,gather,relu_a,act", [(512, 512, 0, 0, 0, 1), (1024, 128, 0, 0, 1, 0), (512, 1024, 1, 0, 0, 0), (1024, 512, 0, 1, 0, 1)])
-def test_gemm_f32_p8_kernel_is_bit_identical(lib, N, K, resid, gather, relu_a, act):
+def test_gemm_f32_p8_kernel_is_bit_identical(lib, N, K, resid, gather, relu_a, act, tail):
     """Exact-fp32 launches with M >= one full round of 256 x 256 tiles take the 8-phase kernel for the full rounds.  Same k
     order per accumulator, same epilogue order (accumulator init, bias, activation) as the 128 x 128 kernel: the results must
     be BIT-IDENTICAL to the launch that stays off it (relu_a bit 3), with every additive operand."""
     l = lib.load()
-    M = (256 * 256 // (N // 256)) + 256 * 5 + 33
+    M = (256 * 256 // (N // 256)) + 256 * tail + 33
     g = torch.Generator().manual_seed(N * 3 + K)
     A = torch.randn(M, K, generator=g).to(DEV)
     W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV)
@@ -670,14 +671,15 @@ def test_gemm_f32_p8_kernel_is_bit_identical(lib, N, K, resid, gather, relu_a, a
     assert float((got - ref.cpu()).abs().max()) < 2e-4 * math.sqrt(K / 64)
 
 
+@pytest.mark.parametrize("tail", [5, 90])          # remainder panels: 5 -> small kernels; 90 (+ 33 rows) -> a partial 8-phase round WITH the ragged last panel
 @pytest.mark.parametrize("N,K,resid,gather,relu_a,act,c_pairs", [(512, 512, 0, 0, 0, 1, 1), (1024, 128, 0, 0, 1, 0, 1), (512, 1024, 0, 0, 0, 0, 0),
                                                                  (1024, 512, 0, 1, 1, 1, 1)])
-def test_gemm_bf16x3_p8_kernel_is_bit_identical(lib, N, K, resid, gather, relu_a, act, c_pairs):
+def test_gemm_bf16x3_p8_kernel_is_bit_identical(lib, N, K, resid, gather, relu_a, act, c_pairs, tail):
     """Split-bf16 launches on split-pair operands with M >= one full round of 256 x 256 tiles: the 8-phase kernel takes the
     full rounds.  Same term order per accumulator (w_hi.a_lo, w_lo.a_hi, w_hi.a_hi per 16 k) and the same epilogue order as
     the 128 x 128 kernel: BIT-IDENTICAL to the launch that stays off it (fmt bits 4, 12); and close to fp64."""
     l = lib.load()
-    M = (256 * 256 // (N // 256)) + 256 * 5 + 33
+    M = (256 * 256 // (N // 256)) + 256 * tail + 33
     g = torch.Generator().manual_seed(N * 5 + K)
     A = torch.randn(M, K, generator=g)
     Ap = _pack_split(A).to(DEV)
