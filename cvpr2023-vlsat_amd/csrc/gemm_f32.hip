@@ -285,7 +285,19 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
         // (single-rounding bf16: a tile is 17-30 us against 8 + 0.4-0.7 us per tile-equivalent on the small kernels -- from 32 tiles on
         //  the partial round wins; the cfg 5 scene's 7 032 remainder rows = 54 tiles took 27.7 us per launch on 64 x 64 tiles, as long
         //  as the full round in front of them: profiles/r05_cfg5_bf16_mixed_kernel_stats_serial.md)
-        if (main_panels == 0 && panels * nbn >= (a.prec == 1 ? 32 : (G1 * 5) / 8)) main_panels = panels;
+        const long part_min = a.prec == 1 ? 32 : (G1 * 5) / 8;          // tiles from which a partial round beats the small kernels
+        if (main_panels == 0 && panels * nbn >= part_min) main_panels = panels;
+        // Full rounds followed by a remainder that would be a partial round of its own (the cfg 5 scene: 312 tiles = 1.2 rounds at
+        // N = 512, 624 = 2.4 at N = 1024): ONE launch of rounds + 1 BALANCED rounds on T / (rounds + 1) blocks instead of a full and a
+        // partial launch -- the same number of tile times, one launch skeleton less, and the CUs it leaves out are free for the other
+        // lanes' kernels (round 5: kproj 41.7 -> 30.1 us, nn_edge.2 64.7 -> 48.6 at E = 39 800; cfg 5 step +3 %)
+        if (rounds >= 1 && main_panels > 0 && main_panels < panels && (panels - main_panels) * nbn >= part_min) {
+            const long step = 8 * nbn, g2 = ((panels * nbn + rounds) / (rounds + 1) + step - 1) / step * step;
+            if (g2 <= G1) {
+                const int r = launch_gemm_p8(a, (int)(panels * nbn), (int)g2, s);
+                if (r <= 0) return r;
+            }
+        }
         if (main_panels > 0) {
             GemmArgs m = a;
             m.M = (int)std::min<long>(main_panels * 256, a.M);
