@@ -101,7 +101,7 @@ def cpu_baseline(cfg, n_obj, n_pts, budget_s=12.0, max_scenes=96, sweep_s=5.0):
                       f"{ncpu}-cpu host; torch {torch.__version__} CPU fp32"}, first
 
 
-PMC_TAG = {("cfg2", "fp32"): "_bench_pmc.json", ("cfg2", "bf16x3"): "_cfg3_bf16x3_pmc.json", ("cfg2", "bf16_mixed"): "_cfg3_bf16_mixed_pmc.json",
+PMC_TAG = {("cfg2", "fp32"): "_bench_pmc.json", ("cfg2", "bf16x3"): "_cfg3_bf16x3_pmc.json", ("cfg2", "bf16_mixed"): "_cfg3_bf16_mixed_pmc.json", ("cfg2", "bf16x3_attn1"): "_cfg3_bf16x3_attn1_pmc.json",
            ("cfg5", "fp32"): "_cfg5_fp32_pmc.json", ("cfg5", "bf16_mixed"): "_cfg5_bf16_mixed_pmc.json"}
 
 

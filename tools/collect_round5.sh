@@ -14,6 +14,7 @@ python bench.py --gemm-precision bf16_mixed --no-extra > "$OUT/bench_cfg3_bf16_m
 tools/profile_run.sh r05/prof_fp32 --no-extra > /dev/null 2>&1
 tools/profile_run.sh r05/prof_cfg3 --gemm-precision bf16x3 --no-extra > /dev/null 2>&1
 tools/profile_run.sh r05/prof_cfg3_mixed --gemm-precision bf16_mixed --no-extra > /dev/null 2>&1
+tools/profile_run.sh r05/prof_cfg3_attn1 --gemm-precision bf16x3_attn1 --no-extra > /dev/null 2>&1
 fi
 if [[ $PART == *b* ]]; then
 tools/profile_run.sh r05/prof_cfg5_fp32 --scenes 1 --objects 200 --points 1024 --no-extra > /dev/null 2>&1

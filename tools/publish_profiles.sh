@@ -11,10 +11,10 @@ j $S/bench_fp32.json $D/${R}_bench_fp32.json
 j $S/bench_cfg3_bf16x3.json $D/${R}_cfg3_bf16x3_bench.json
 j $S/bench_cfg3_bf16_mixed.json $D/${R}_cfg3_bf16_mixed_bench.json
 cp $S/prof_fp32/kernel_stats.md $D/${R}_bench_kernel_stats.md;        cp $S/prof_fp32/pmc.md $D/${R}_bench_pmc.md
-for t in fp32:bench cfg3:cfg3_bf16x3 cfg3_mixed:cfg3_bf16_mixed cfg5_fp32:cfg5_fp32 cfg5_mixed:cfg5_bf16_mixed; do   # (round 4 on) serialised traces with the roofline footer; cfg 5 PMC
+for t in fp32:bench cfg3:cfg3_bf16x3 cfg3_mixed:cfg3_bf16_mixed cfg3_attn1:cfg3_bf16x3_attn1 cfg5_fp32:cfg5_fp32 cfg5_mixed:cfg5_bf16_mixed; do   # (round 4 on) serialised traces with the roofline footer; cfg 5 PMC
   a=${t%%:*}; b=${t##*:}
   [ -f $S/prof_$a/kernel_stats_serial.md ] && cp $S/prof_$a/kernel_stats_serial.md $D/${R}_${b}_kernel_stats_serial.md
-  case $a in cfg5_*) [ -f $S/prof_$a/pmc.json ] && { cp $S/prof_$a/pmc.json $D/${R}_${b}_pmc.json; cp $S/prof_$a/pmc.md $D/${R}_${b}_pmc.md; cp $S/prof_$a/kernel_stats.md $D/${R}_${b}_kernel_stats.md; };; esac
+  case $a in cfg5_*|cfg3_attn1) [ -f $S/prof_$a/pmc.json ] && { cp $S/prof_$a/pmc.json $D/${R}_${b}_pmc.json; cp $S/prof_$a/pmc.md $D/${R}_${b}_pmc.md; cp $S/prof_$a/kernel_stats.md $D/${R}_${b}_kernel_stats.md; };; esac
 done
 cp $S/prof_fp32/pmc.json $D/${R}_bench_pmc.json; cp $S/prof_cfg3/pmc.json $D/${R}_cfg3_bf16x3_pmc.json; cp $S/prof_cfg3_mixed/pmc.json $D/${R}_cfg3_bf16_mixed_pmc.json
 cp $S/prof_cfg3/kernel_stats.md $D/${R}_cfg3_bf16x3_kernel_stats.md;  cp $S/prof_cfg3/pmc.md $D/${R}_cfg3_bf16x3_pmc.md
