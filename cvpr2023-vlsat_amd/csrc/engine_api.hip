@@ -265,13 +265,18 @@ int vlsat_k_softmax_rows(const float* x, int32_t ld, int32_t rows, int32_t cols,
 int vlsat_eval_ranks(const float* obj_logits, const float* obj_probs, const float* rel_probs, const int64_t* gt_class,
                      const int64_t* gt_rel, const int64_t* edges, int32_t n_nodes, int32_t n_edges, int32_t n_obj_class,
                      int32_t n_rel_class, int32_t topk_obj, int32_t topk_rel, int32_t topk_triplet, float threshold,
-                     int32_t* obj_rank, int32_t* rel_rank, int32_t* tri_rank, int32_t* cnt, void* stream) {
+                     int32_t* obj_rank, int32_t* rel_rank, int32_t* tri_rank, int32_t* cnt, float* scratch, void* stream) {
     if (!obj_logits || !obj_probs || !gt_class || !obj_rank) return fail(VLSAT_EINVAL, "eval_ranks: null argument");
-    if (n_edges > 0 && (!rel_probs || !gt_rel || !edges || !rel_rank || !tri_rank || !cnt))
+    if (n_edges > 0 && (!rel_probs || !gt_rel || !edges || !rel_rank || !tri_rank || !cnt || !scratch))
         return fail(VLSAT_EINVAL, "eval_ranks: null edge argument");
     return launch_eval_ranks(obj_logits, obj_probs, rel_probs, gt_class, gt_rel, edges, n_nodes, n_edges, n_obj_class,
-                             n_rel_class, topk_obj, topk_rel, topk_triplet, threshold, obj_rank, rel_rank, tri_rank, cnt,
+                             n_rel_class, topk_obj, topk_rel, topk_triplet, threshold, obj_rank, rel_rank, tri_rank, cnt, scratch,
                              static_cast<hipStream_t>(stream));
+}
+
+int64_t vlsat_eval_ranks_scratch_floats(int32_t n_nodes, int32_t n_obj_class, int32_t topk_triplet) {
+    if (n_nodes < 0 || n_obj_class < 0 || topk_triplet < 0) return 0;
+    return (int64_t)n_nodes * eval_ranks_sorted_k(n_obj_class, topk_triplet);
 }
 
 int vlsat_eval_counts(const int32_t* obj_rank_3d, const int32_t* obj_rank_2d, const int32_t* rel_rank_3d, const int32_t* rel_rank_2d,
@@ -307,6 +312,7 @@ int vlsat_process_val_counts(vlsat_handle h, vlsat_plan p, const float* obj_poin
     float* f = p->ev_f;
     float *obj3 = f, *obj2 = f + (size_t)N * C, *prob3 = f + (size_t)2 * N * C, *prob2 = f + (size_t)3 * N * C;
     float *rel3 = f + (size_t)4 * N * C, *rel2 = rel3 + (size_t)std::max(E, 1) * R;
+    float* sorted = rel2 + (size_t)std::max(E, 1) * R;          // [N, min(C, 101)]: the ranking's per-node sorted probabilities
     int32_t* i = p->ev_i;
     int32_t *or3 = i, *or2 = i + N, *rr3 = i + 2 * (size_t)N, *rr2 = rr3 + (size_t)std::max(E, 1) * R, *tr3 = rr2 + (size_t)std::max(E, 1) * R,
             *tr2 = tr3 + (size_t)std::max(E, 1) * R, *cn3 = tr2 + (size_t)std::max(E, 1) * R, *cn2 = cn3 + std::max(E, 1);
@@ -316,7 +322,7 @@ int vlsat_process_val_counts(vlsat_handle h, vlsat_plan p, const float* obj_poin
         float* pr = br ? prob2 : prob3;
         RUN(launch_softmax_rows(lg, C, N, C, pr, 0, s));
         RUN(launch_eval_ranks(lg, pr, br ? rel2 : rel3, gt_class, gt_rel, edges_e2, N, E, C, R, 11, 6, 101, 0.5f, br ? or2 : or3, br ? rr2 : rr3,
-                              br ? tr2 : tr3, br ? cn2 : cn3, s));
+                              br ? tr2 : tr3, br ? cn2 : cn3, sorted, s));
     }
     RUN(launch_eval_counts(or3, or2, rr3, rr2, tr3, tr2, cn3, gt_class, gt_rel, edges_e2, N, E, R, n_scenes,
                            reinterpret_cast<unsigned long long*>(counts), s));

@@ -252,7 +252,7 @@ int vlsat_plan_create(vlsat_handle h, const int64_t* bid, const int64_t* edges, 
     want(&p->Q2n, Ns * 512); want(&p->On2, Ns * 512);
     {   // evaluation scratch (vlsat_process_val_counts): 0.6 KB per edge, 2.6 KB per node
         const size_t C = (size_t)h->d.n_obj_class, R = (size_t)h->d.n_rel_class;
-        want(&p->ev_f, Ns * C * 4 + Es * R * 2);
+        want(&p->ev_f, Ns * C * 4 + Es * R * 2 + Ns * C);      // (+ [N, <= C] sorted probabilities of the triplet ranking)
         want(&p->ev_i, Ns * 2 + Es * R * 4 + Es * 2);
     }
     // launch-bound plans (every edge GEMM fits one round of the grid): second scratch set for the 2D twin stages

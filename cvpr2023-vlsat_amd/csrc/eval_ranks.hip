@@ -6,9 +6,9 @@
 // 665 600-entry outer product: 74 ms/edge, ~116 s per cfg-2 scene).  A rank only needs COUNTS:
 // walking a descending sort until `pred[gt] >= pred[idx] or index > topk` stops after
 // min(#strictly-greater, topk) steps, and the position of the gt triple in the top-k list is
-// #{conf > gt_conf} + 1.  The outer product is never materialised: a block per edge counts
-// the triples above each threshold, pruning (i,j) pairs with the exact monotone bound
-// (s_i*o_j)*max_k r_k.  All comparisons use the same fp32 products ((s*o)*r, no FMA) as the
+// #{conf > gt_conf} + 1.  The outer product is never materialised: 32 lanes per edge count
+// the triples above each threshold along a staircase over the sorted class probabilities (below).
+// All comparisons use the same fp32 products ((s*o)*r, no FMA) as the
 // reference's two einsums, so counts are bit-exact functions of the fp32 inputs.
 // Integer / HBM-latency work: no MFMA.
 #include "common.h"
@@ -82,73 +82,95 @@ __global__ __launch_bounds__(256) void rel_rank_kernel(const float* __restrict__
     cnt[e] = n;
 }
 
-// One block per edge.  probs [N,C] (softmaxed object scores), rel [E,R], edges [E,2] = (from, to).
-__global__ __launch_bounds__(256) void tri_rank_kernel(const float* __restrict__ probs, const float* __restrict__ rel,
-                                                       const int64_t* __restrict__ gt_cls, const int64_t* __restrict__ gt_rel,
-                                                       const int64_t* __restrict__ edges, int C, int R, int topk, float thr,
-                                                       int32_t* __restrict__ out) {
-    __shared__ float s_sub[1024], s_obj[1024], s_rel[32], s_thr[32];
-    __shared__ int s_cnt[32], s_n, s_ge;
-    const int e = blockIdx.x, tid = threadIdx.x;
-    const int a = (int)edges[2 * e], b = (int)edges[2 * e + 1];
-    for (int c = tid; c < C; c += 256) {
-        s_sub[c] = probs[(size_t)a * C + c];
-        s_obj[c] = probs[(size_t)b * C + c];
-    }
-    if (tid < R) s_rel[tid] = rel[(size_t)e * R + tid];
-    if (tid < 32) s_cnt[tid] = 0;
+// ---- triplet ranks by counting a STAIRCASE, not the outer product ---------------------------------------------------------------
+// rank of a gt triple = min(#{(i,j,k): (s_i*o_j)*r_k > t}, topk) + 1 with s = probs[from], o = probs[to], t = (s_gt*o_gt)*r_gt.
+// fp32 rounding is monotone, so with both probability rows sorted descending the pairs (i, j) that pass for a fixed relation k
+// form a down-closed staircase: row i passes on a prefix of length len_k(i), and len_k is non-increasing in i.  A count below
+// topk means every passing cell has (i+1)(j+1) <= count, so only the topk largest entries of each row matter: they are sorted
+// ONCE PER NODE (N rows instead of E x C^2 products), and a lane per (edge, relation) walks its staircase -- a binary search on
+// row 0, then rows whose length only shrinks -- until the count reaches topk or the staircase ends: <= 2 topk steps, typically
+// a handful.  Every comparison is the reference's own fp32 product ((s*o)*r, eva_utils_acc.py:163-164), so the counts -- and the
+// ranks -- are bit-exact functions of the inputs, equal to the brute-force count whatever the tie order of the sort.
+// (Round 5's kernel walked the C^2 pairs of every edge with a pruning bound: 3.8 ms per branch on the 64-scene batch.)
+
+// sorted[n, 0:K] = the K largest entries of probs[n, :] in descending order; one wave per node, rank by counting
+__global__ __launch_bounds__(256) void sort_probs_kernel(const float* __restrict__ probs, int N, int C, int K, float* __restrict__ sorted) {
+    extern __shared__ float s_row[];                               // [4][C]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, n = blockIdx.x * 4 + w;
+    float* row = s_row + (size_t)w * C;
+    if (n < N)
+        for (int c = lane; c < C; c += 64) row[c] = probs[(size_t)n * C + c];
     __syncthreads();
-    if (tid == 0) {
-        const float gs = s_sub[gt_cls[a]] * s_obj[gt_cls[b]];
-        int n = 0;
-        for (int k = 0; k < R; ++k)
-            if (gt_rel[(size_t)e * R + k] == 1) s_thr[n++] = gs * s_rel[k];
-        s_ge = 0;
-        if (n == 0) { s_thr[n++] = thr; s_ge = 1; }         // no gt relation: count conf >= thr
-        s_n = n;
+    if (n >= N) return;
+    for (int c = lane; c < C; c += 64) {
+        const float v = row[c];
+        int r = 0;
+        for (int q = 0; q < C; ++q) {
+            const float x = row[q];
+            r += (x > v) || (x == v && q < c);
+        }
+        if (r < K) sorted[(size_t)n * K + r] = v;
+    }
+}
+
+// 32 lanes per edge (lane = relation class, R <= 32), 8 edges per block
+__global__ __launch_bounds__(256) void tri_rank_kernel(const float* __restrict__ probs, const float* __restrict__ sorted,
+                                                       const float* __restrict__ rel, const int64_t* __restrict__ gt_cls,
+                                                       const int64_t* __restrict__ gt_rel, const int64_t* __restrict__ edges, int E, int C,
+                                                       int R, int K, int topk, float thr, int32_t* __restrict__ out) {
+    extern __shared__ float s_so[];                                // [8][2][K] sorted rows + [8][32] ranks
+    const int tid = threadIdx.x, grp = tid >> 5, k = tid & 31;
+    const int e = blockIdx.x * 8 + grp;
+    float* S = s_so + (size_t)grp * 2 * K;
+    float* O = S + K;
+    int* ranks = reinterpret_cast<int*>(s_so + (size_t)16 * K) + grp * 32;
+    int a = 0, b = 0;
+    if (e < E) {
+        a = (int)edges[2 * (size_t)e]; b = (int)edges[2 * (size_t)e + 1];
+        for (int c = k; c < K; c += 32) { S[c] = sorted[(size_t)a * K + c]; O[c] = sorted[(size_t)b * K + c]; }
     }
     __syncthreads();
-    const int n = s_n, ge = s_ge;
-    float rmax = 0.f, tmin = INFINITY;
-    for (int k = 0; k < R; ++k) rmax = fmaxf(rmax, s_rel[k]);
-    for (int g = 0; g < n; ++g) tmin = fminf(tmin, s_thr[g]);
-    // Counts are only needed up to topk (ranks are capped): pairs are walked in chunks of 16 per
-    // thread and the block stops as soon as every threshold has >= topk hits.  With a flat score
-    // distribution (untrained weights) almost every triple beats the gt score and the cap is hit in
-    // the first chunk; with a peaked one the (s_i*o_j)*max r bound prunes almost every pair.
-    const int total = C * C;
-    for (int base = 0; base < total; base += 256 * 16) {
-        int local[4] = {0, 0, 0, 0};
-#pragma unroll 4
-        for (int it = 0; it < 16; ++it) {
-            const int p = base + it * 256 + tid;
-            if (p >= total) break;
-            const float ns = __fmul_rn(s_sub[p / C], s_obj[p % C]);
-            const float ub = __fmul_rn(ns, rmax);             // exact monotone upper bound of (ns * r_k)
-            if (ge ? ub < tmin : ub <= tmin) continue;
-            for (int k = 0; k < R; ++k) {
-                const float c = __fmul_rn(ns, s_rel[k]);
-#pragma unroll
-                for (int g = 0; g < 4; ++g)                   // static register indices
-                    if (g < n) local[g] += ge ? c >= s_thr[g] : c > s_thr[g];
-                for (int g = 4; g < n; ++g)
-                    if (c > s_thr[g]) atomicAdd(&s_cnt[g], 1);
+    if (e >= E) return;
+    const float r = k < R ? rel[(size_t)e * R + k] : 0.f;
+    const bool is_gt = k < R && gt_rel[(size_t)e * R + k] == 1;
+    const unsigned half = (unsigned)(__ballot(is_gt) >> (tid & 32));          // this edge's 32 lanes of the wave's 64-bit mask
+    const float gs = __fmul_rn(probs[(size_t)a * C + gt_cls[a]], probs[(size_t)b * C + gt_cls[b]]);
+    const int n = half ? __popc(half) : 1;
+    const bool ge = half == 0;                                                // no gt relation: count conf >= thr (one rank)
+    unsigned rest = half;
+    const float s0 = S[0];
+    for (int g = 0; g < n; ++g) {
+        float t = thr;
+        if (!ge) {
+            const int kg = __ffs(rest) - 1;
+            rest &= rest - 1;
+            t = __fmul_rn(gs, __shfl(r, (tid & 32) + kg));
+        }
+        int cnt = 0;
+        if (k < R) {
+            auto pass = [&](float s, float o) {
+                const float c = __fmul_rn(__fmul_rn(s, o), r);
+                return ge ? c >= t : c > t;
+            };
+            int lo = 0, hi = K;                                               // row 0: first column that fails
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (pass(s0, O[mid])) lo = mid + 1; else hi = mid;
             }
+            int len = lo;
+            cnt = len;
+            for (int i = 1; i < K && len > 0 && cnt < topk; ++i) {
+                const float s = S[i];
+                while (len > 0 && !pass(s, O[len - 1])) --len;
+                cnt += len;
+            }
+            cnt = min(cnt, topk);
         }
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-            if (g < n && local[g]) atomicAdd(&s_cnt[g], local[g]);
-        __syncthreads();
-        int lo = s_cnt[0];
-        for (int g = 1; g < n; ++g) lo = min(lo, s_cnt[g]);
-        __syncthreads();
-        if (lo >= topk) break;                                // block-uniform
+        for (int o = 16; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);          // (xor < 32: stays inside the edge's half)
+        if (k == 0) ranks[g] = min(cnt, topk) + 1;
     }
-    if (tid == 0) {
-        int r[32];
-        for (int g = 0; g < n; ++g) r[g] = min(s_cnt[g], topk) + 1;
-        finish_edge(r, n, out + (size_t)e * R, R);
-    }
+    if (k == 0) finish_edge(ranks, n, out + (size_t)e * R, R);                // (lane 0 wrote them, lane 0 reads them)
 }
 
 
@@ -382,16 +404,22 @@ int launch_softmax_rows(const float* x, int ld, int rows, int cols, float* out, 
 int launch_eval_ranks(const float* obj_logits, const float* obj_probs, const float* rel, const int64_t* gt_cls,
                       const int64_t* gt_rel, const int64_t* edges, int N, int E, int C, int R, int topk_obj,
                       int topk_rel, int topk_tri, float thr, int32_t* obj_rank, int32_t* rel_rank, int32_t* tri_rank,
-                      int32_t* cnt, hipStream_t s) {
+                      int32_t* cnt, float* sorted_probs, hipStream_t s) {
     if (C > 1024 || R > 32) return fail(-1, "eval_ranks: at most 1024 object and 32 relation classes");
+    if (topk_tri < 1) return fail(-1, "eval_ranks: topk_triplet must be positive");
     if (N > 0) {
         hipLaunchKernelGGL(obj_rank_kernel, dim3((N + 3) / 4), dim3(256), 0, s, obj_logits, C, gt_cls, N, C, topk_obj, obj_rank);
         VLSAT_LAUNCH_CHECK("obj_rank");
     }
     if (E > 0) {
+        if (!sorted_probs) return fail(-1, "eval_ranks: null scratch (vlsat_eval_ranks_scratch_floats)");
+        const int K = eval_ranks_sorted_k(C, topk_tri);
         hipLaunchKernelGGL(rel_rank_kernel, dim3((E + 255) / 256), dim3(256), 0, s, rel, gt_rel, E, R, topk_rel, thr, rel_rank, cnt);
         VLSAT_LAUNCH_CHECK("rel_rank");
-        hipLaunchKernelGGL(tri_rank_kernel, dim3(E), dim3(256), 0, s, obj_probs, rel, gt_cls, gt_rel, edges, C, R, topk_tri, thr, tri_rank);
+        hipLaunchKernelGGL(sort_probs_kernel, dim3((N + 3) / 4), dim3(256), (size_t)4 * C * sizeof(float), s, obj_probs, N, C, K, sorted_probs);
+        VLSAT_LAUNCH_CHECK("sort_probs");
+        hipLaunchKernelGGL(tri_rank_kernel, dim3((E + 7) / 8), dim3(256), (size_t)16 * K * sizeof(float) + 256 * sizeof(int), s, obj_probs, sorted_probs, rel, gt_cls,
+                           gt_rel, edges, E, C, R, K, topk_tri, thr, tri_rank);
         VLSAT_LAUNCH_CHECK("tri_rank");
     }
     return 0;

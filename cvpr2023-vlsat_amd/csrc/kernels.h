@@ -191,7 +191,9 @@ int launch_softmax_rows(const float* x, int ld, int rows, int cols, float* out, 
 int launch_eval_ranks(const float* obj_logits, const float* obj_probs, const float* rel, const int64_t* gt_cls,
                       const int64_t* gt_rel, const int64_t* edges, int N, int E, int C, int R, int topk_obj,
                       int topk_rel, int topk_tri, float thr, int32_t* obj_rank, int32_t* rel_rank, int32_t* tri_rank,
-                      int32_t* cnt, hipStream_t s);
+                      int32_t* cnt, float* sorted_probs, hipStream_t s);
+// columns of the per-node sorted-probability scratch of launch_eval_ranks ([N, K] floats): only the topk largest matter
+inline int eval_ranks_sorted_k(int C, int topk_tri) { return C < topk_tri ? C : topk_tri; }
 
 // rank arrays of one batch -> += the additive counts vector of evaluate.validation (uint64 [1 + R + 2 (11 + 6 R)]; layout:
 // evaluate.fields()); integer atomics only, safe from concurrent streams

@@ -7,7 +7,7 @@
 // and the fully-connected edge list / batch ids of a batch of scenes
 //   (dataset_3dssg.py:264-266, DataLoader.py:160-172).
 // HBM-bound gather (12 B per sampled point in, 12 B out); one block per object, wave-shuffle
-// reductions; statistics are two-pass (mean first, then centred sums) in fp32.
+// reductions; statistics are two-pass (mean first, then centred sums), accumulated in fp64 like the reference's descriptor.
 #include "common.h"
 #include "kernels.h"
 
@@ -28,37 +28,57 @@ __device__ __forceinline__ float block_reduce(float v, float* red, int op) {   /
     return r;
 }
 
+__device__ __forceinline__ double block_sum_f64(double v, double* red) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    double r = red[0];
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) r += red[i];
+    return r;
+}
+
+// The reference builds the descriptor from the mesh vertices as trimesh hands them over -- float64 -- and stores it in a float32
+// tensor (dataset_3dssg.py:273,290): the statistics here are accumulated in float64 and rounded once.  The object's points are
+// converted to float32 first and centred with their float32 mean (:291-292); the mean used here is the float64 mean rounded to
+// float32 (torch's float32 mean differs from it by at most an ulp of the mean).
 __global__ __launch_bounds__(256) void prepare_objects_kernel(const float* __restrict__ scene, const int32_t* __restrict__ choice,
                                                               int P, float* __restrict__ obj_points,
                                                               float* __restrict__ desc) {
     __shared__ float red[4];
+    __shared__ double red64[4];
     const int n = blockIdx.x, tid = threadIdx.x;
     const int32_t* ch = choice + (size_t)n * P;
-    float mean[3], dims[3], sd[3];
+    double mean[3], dims[3], sd[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        float s = 0.f, mx = -INFINITY, mn = INFINITY;
+        double s = 0.0;
+        float mx = -INFINITY, mn = INFINITY;
         for (int p = tid; p < P; p += 256) {
             const float v = scene[(size_t)ch[p] * 3 + c];
-            s += v; mx = fmaxf(mx, v); mn = fminf(mn, v);
+            s += (double)v; mx = fmaxf(mx, v); mn = fminf(mn, v);
         }
-        mean[c] = block_reduce(s, red, 0) / (float)P;
-        dims[c] = block_reduce(mx, red, 1) - block_reduce(mn, red, 2);
-        float q = 0.f;
+        mean[c] = block_sum_f64(s, red64) / (double)P;
+        dims[c] = (double)block_reduce(mx, red, 1) - (double)block_reduce(mn, red, 2);
+        const float mean32 = (float)mean[c];
+        double q = 0.0;
         for (int p = tid; p < P; p += 256) {
-            const float d = scene[(size_t)ch[p] * 3 + c] - mean[c];
+            const float v = scene[(size_t)ch[p] * 3 + c];
+            const double d = (double)v - mean[c];
             q += d * d;
-            obj_points[((size_t)n * 3 + c) * P + p] = d;                   // zero-meaned, [N,3,P]
+            obj_points[((size_t)n * 3 + c) * P + p] = v - mean32;          // zero-meaned, [N,3,P]
         }
-        sd[c] = sqrtf(block_reduce(q, red, 0) / (float)(P - 1));          // unbiased (torch.std default)
+        sd[c] = sqrt(block_sum_f64(q, red64) / (double)(P - 1));           // unbiased (torch.std default)
     }
     if (tid == 0) {
         float* d = desc + (size_t)n * 11;
-        d[0] = mean[0]; d[1] = mean[1]; d[2] = mean[2];
-        d[3] = sd[0]; d[4] = sd[1]; d[5] = sd[2];
-        d[6] = dims[0]; d[7] = dims[1]; d[8] = dims[2];
-        d[9] = dims[0] * dims[1] * dims[2];
-        d[10] = fmaxf(dims[0], fmaxf(dims[1], dims[2]));
+        d[0] = (float)mean[0]; d[1] = (float)mean[1]; d[2] = (float)mean[2];
+        d[3] = (float)sd[0]; d[4] = (float)sd[1]; d[5] = (float)sd[2];
+        d[6] = (float)dims[0]; d[7] = (float)dims[1]; d[8] = (float)dims[2];
+        d[9] = (float)(dims[0] * dims[1] * dims[2]);
+        d[10] = (float)fmax(dims[0], fmax(dims[1], dims[2]));
     }
 }
 

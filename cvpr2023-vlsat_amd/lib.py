@@ -72,7 +72,8 @@ _SIGNATURES = {
     "vlsat_sample_objects_scratch": (_sz, [_i64, _i32]),
     "vlsat_sample_objects": (C.c_int, [_vp, _i64, _vp, _i32, _i32, C.c_uint64, _vp, _i32, _vp, _vp, _vp, _vp]),
     "vlsat_k_softmax_rows": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp]),
-    "vlsat_eval_ranks": (C.c_int, [_vp] * 6 + [_i32] * 7 + [_f32] + [_vp] * 4 + [_vp]),
+    "vlsat_eval_ranks": (C.c_int, [_vp] * 6 + [_i32] * 7 + [_f32] + [_vp] * 5 + [_vp]),
+    "vlsat_eval_ranks_scratch_floats": (C.c_int64, [_i32] * 3),
     "vlsat_eval_counts": (C.c_int, [_vp] * 10 + [_i32] * 4 + [_vp, _vp]),
     "vlsat_process_val_counts": (C.c_int, [_vp] * 8 + [_i32, _vp, _vp]),
     "vlsat_scene_checksums": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),

@@ -59,17 +59,18 @@ def eval_ranks(obj_logits: torch.Tensor, rel_probs: torch.Tensor, gt_class: torc
     rel_rank = torch.empty(e, r, dtype=torch.int32, device=dev)
     tri_rank = torch.empty(e, r, dtype=torch.int32, device=dev)
     cnt = torch.empty(e, dtype=torch.int32, device=dev)
+    scratch = torch.empty(max(int(lib.vlsat_eval_ranks_scratch_floats(n, c, TOPK_TRIPLET)), 1), dtype=torch.float32, device=dev)
     L.check(lib.vlsat_eval_ranks(obj_logits.data_ptr(), obj_probs.data_ptr(), rel_probs.data_ptr(), gt_class.data_ptr(),
                                  gt_rel.data_ptr(), edges.data_ptr(), n, e, c, r, TOPK_OBJ, TOPK_REL, TOPK_TRIPLET,
                                  THRESHOLD, obj_rank.data_ptr(), rel_rank.data_ptr(), tri_rank.data_ptr(), cnt.data_ptr(),
-                                 L.stream_ptr()))
+                                 scratch.data_ptr(), L.stream_ptr()))
     if not multi_rel_outputs:            # triplet scores use exp(log_softmax); predicate ranks above used the raw values
         tri_rank = torch.empty(e, r, dtype=torch.int32, device=dev)
         rel_exp = (rel_probs.exp() if rel_exp is None else rel_exp).contiguous()
         L.check(lib.vlsat_eval_ranks(obj_logits.data_ptr(), obj_probs.data_ptr(), rel_exp.data_ptr(), gt_class.data_ptr(),
                                      gt_rel.data_ptr(), edges.data_ptr(), n, e, c, r, TOPK_OBJ, TOPK_REL, TOPK_TRIPLET,
                                      THRESHOLD, obj_rank.data_ptr(), torch.empty_like(rel_rank).data_ptr(),
-                                     tri_rank.data_ptr(), torch.empty_like(cnt).data_ptr(), L.stream_ptr()))
+                                     tri_rank.data_ptr(), torch.empty_like(cnt).data_ptr(), scratch.data_ptr(), L.stream_ptr()))
     used = torch.arange(r, device=dev)[None, :] < cnt[:, None]          # first cnt[e] slots of each edge row
     return {"top_k_obj": obj_rank, "top_k_rel": rel_rank[used], "top_k_triplet": tri_rank[used], "cnt": cnt,
             "obj_probs": obj_probs}
@@ -90,17 +91,18 @@ def rank_tables(obj_logits: torch.Tensor, rel_probs: torch.Tensor, gt_class: tor
     rel_rank = torch.empty(e, r, dtype=torch.int32, device=dev)
     tri_rank = torch.empty(e, r, dtype=torch.int32, device=dev)
     cnt = torch.empty(e, dtype=torch.int32, device=dev)
+    scratch = torch.empty(max(int(lib.vlsat_eval_ranks_scratch_floats(n, c, TOPK_TRIPLET)), 1), dtype=torch.float32, device=dev)
     L.check(lib.vlsat_eval_ranks(obj_logits.data_ptr(), obj_probs.data_ptr(), rel_probs.data_ptr(), gt_class.data_ptr(),
                                  gt_rel.data_ptr(), edges.data_ptr(), n, e, c, r, TOPK_OBJ, TOPK_REL, TOPK_TRIPLET,
                                  THRESHOLD, obj_rank.data_ptr(), rel_rank.data_ptr(), tri_rank.data_ptr(), cnt.data_ptr(),
-                                 L.stream_ptr()))
+                                 scratch.data_ptr(), L.stream_ptr()))
     if not multi_rel_outputs:            # triplet scores use exp(log_softmax); the predicate ranks above used the raw values
         tri_rank = torch.empty(e, r, dtype=torch.int32, device=dev)
         rel_exp = rel_probs.exp()
         L.check(lib.vlsat_eval_ranks(obj_logits.data_ptr(), obj_probs.data_ptr(), rel_exp.data_ptr(), gt_class.data_ptr(),
                                      gt_rel.data_ptr(), edges.data_ptr(), n, e, c, r, TOPK_OBJ, TOPK_REL, TOPK_TRIPLET,
                                      THRESHOLD, torch.empty_like(obj_rank).data_ptr(), torch.empty_like(rel_rank).data_ptr(),
-                                     tri_rank.data_ptr(), torch.empty_like(cnt).data_ptr(), L.stream_ptr()))
+                                     tri_rank.data_ptr(), torch.empty_like(cnt).data_ptr(), scratch.data_ptr(), L.stream_ptr()))
     return {"obj_rank": obj_rank, "rel_rank": rel_rank, "tri_rank": tri_rank, "cnt": cnt}
 
 

@@ -12,16 +12,20 @@ import torch
 from . import lib as L
 
 
-def sample_objects(instances: torch.Tensor, instance_ids: torch.Tensor, n_sample: int, seed: int):
+def sample_objects(instances: torch.Tensor, instance_ids: torch.Tensor, n_sample: int, seed: int, map_size: int = 65536):
     """instances i32[Npts] (instance id per scene point), instance_ids i32[N] (distinct) -> choice i32[N, n_sample] (indices into the
     scene's points, drawn with replacement from each instance's own points), counts i32[N] (points per instance).  Device tensors
-    in and out; nothing is read back.  ``choice`` feeds ``prepare_objects``."""
+    in and out; nothing is read back.  ``choice`` feeds ``prepare_objects``.  ``map_size`` bounds the instance ids the kernel can
+    see: a requested id >= map_size gets count 0 and choice 0, and of two equal ids only one gets points -- callers that hold the
+    ids on the host (``scan.prepare_scan``) check both and size the map from the largest id."""
     lib = L.load()
     dev = instances.device
     instances = instances.to(torch.int32).contiguous().view(-1)
     ids = instance_ids.to(device=dev, dtype=torch.int32).contiguous().view(-1)
     n_pts, n = instances.numel(), ids.numel()
-    map_size = 65536                      # instance ids are small integers (3RScan: < 1000); larger ids are ignored by the kernel
+    map_size = int(map_size)              # instance ids are small integers (3RScan: < 1000)
+    if map_size <= 0:
+        raise L.VlsatError("sample_objects: map_size must be positive")
     id_map = torch.empty(map_size, dtype=torch.int32, device=dev)
     scratch = torch.empty(int(lib.vlsat_sample_objects_scratch(n_pts, n)), dtype=torch.int32, device=dev)
     choice = torch.empty(n, int(n_sample), dtype=torch.int32, device=dev)

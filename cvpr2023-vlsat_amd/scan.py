@@ -12,9 +12,12 @@ class does on the host before ``Mmgnet.forward`` sees a scene, without trimesh -
                                ``:279-294``) -> one batch dict in the layout ``evaluate.validation`` and ``VLSATModel.forward`` take.
 
 The union point sets (``rel_points``, ``:337-359``) are not produced: ``Mmgnet.forward`` never reads them.  The host-side
-functions are plain numpy (tested on CPU against ``oracle/prep_oracle.py``'s loop-by-loop restatement); ``prepare_scan`` needs the GPU
-library.  Parity note: the reference's dataset class cannot be imported here (trimesh is absent), so this module is restated from its
-source, not pinned to its output; the device half (descriptor, sampling layout) is pinned by ``tests/golden/prep_small.npz``."""
+functions are plain numpy; ``prepare_scan`` needs the GPU library.  Parity: PINNED to the reference's own dataset code --
+``tests/golden/make_golden_scan.py`` imports ``dataset_3dssg`` / ``DataLoader`` / ``util`` / ``util_ply`` (with a stand-in for the
+absent ``trimesh`` that only hands over the vertex table) and records what ``load_mesh``, ``read_relationship_json``,
+``data_preparation`` (every combination of ``all_edge`` x ``multi_rel_outputs``, colour / normal channels, the draws of
+``np.random.choice``), ``__getitem__`` + ``collate_fn_mmg`` and the name-list readers return; ``tests/test_scan_golden_cpu.py``
+compares every function of this module with those fixtures, ``tests/test_hip_scan.py`` the device half on the recorded draws."""
 from __future__ import annotations
 
 import json
@@ -80,7 +83,9 @@ def read_ply(path: str) -> Dict[str, Optional[np.ndarray]]:
                         table = np.array(vals, dtype=np.float64).reshape(count, len(props))
                     except ValueError:
                         raise ScanError(f"{path}: a vertex value is not a number") from None
-                    vert = {p: table[:, i] for i, (p, _) in enumerate(props)}
+                    # a value is parsed INTO its declared property type (a float32 written in decimal is that float32 again), as a
+                    # PLY reader that fills the element's record does; integer columns go through int64 first
+                    vert = {p: (table[:, i].astype(t) if t[0] == "f" else table[:, i].astype(np.int64).astype(t)) for i, (p, t) in enumerate(props)}
                 else:
                     dt = np.dtype([(p, "<" + t) for p, t in props])
                     raw = f.read(dt.itemsize * count)
@@ -132,9 +137,11 @@ def scene_points(mesh: Dict[str, Optional[np.ndarray]], use_rgb: bool = False, u
 
 
 def read_name_list(path: str) -> List[str]:
-    """classes.txt / relations.txt: one name per line."""
-    with open(path) as f:
-        return [ln.rstrip("\n").rstrip("\r") for ln in f if ln.strip()]
+    """classes.txt / relationships.txt: one name per line, exactly as the reference reads them (utils/util.py:15-21 ``read_txt_to_list``,
+    :34-40 ``read_relationships``): trailing white space stripped, lower-cased, EVERY line kept -- an empty line is an entry (it
+    takes an index), leading blanks stay."""
+    with open(path, "r") as f:
+        return [ln.rstrip().lower() for ln in f]
 
 
 def read_relationships(path_or_data, selected_scans: Sequence[str],
@@ -202,7 +209,7 @@ def ground_truth(nodes: Sequence[int], edges: np.ndarray, instance2label: Dict[i
         else:
             adj[pos[r[0]], pos[r[1]]] = k
     edges = np.asarray(edges, dtype=np.int64).reshape(-1, 2)
-    gt_rel = adj[edges[:, 0], edges[:, 1]] if len(edges) else adj.reshape(0, *adj.shape[2:])
+    gt_rel = adj[edges[:, 0], edges[:, 1]] if len(edges) else np.zeros((0,) + adj.shape[2:], dtype=adj.dtype)   # (a one-object scan: no edge)
     return gt_class, gt_rel
 
 
@@ -237,7 +244,9 @@ def prepare_scan(mesh_or_path, instance2label: Dict[int, str], class_names: Sequ
     dev = torch.device(device)
     d_inst = torch.from_numpy(mesh["instances"].astype(np.int32)).to(dev)
     d_ids = torch.tensor(nodes, dtype=torch.int32, device=dev)
-    choice, counts = prep.sample_objects(d_inst, d_ids, num_points, seed)
+    if len(set(nodes)) != len(nodes) or min(nodes) < 0 or max(nodes) >= (1 << 24):
+        raise ScanError("instance ids of the scene's nodes must be distinct integers in [0, 2^24)")
+    choice, counts = prep.sample_objects(d_inst, d_ids, num_points, seed, map_size=max(65536, max(nodes) + 1))
     d_xyz = torch.from_numpy(np.ascontiguousarray(pts[:, :3], dtype=np.float32)).to(dev)
     obj_points, descriptor = prep.prepare_objects(d_xyz, choice)
     if pts.shape[1] > 3:                 # colour / normal channels ride along with the same selection

@@ -321,12 +321,15 @@ int vlsat_k_softmax_rows(const float* x, int32_t ld, int32_t rows, int32_t cols,
  * the `edge_indices` the reference passes.  Outputs: obj_rank [N]; rel_rank / tri_rank [E,R] hold, for
  * edge e, its cnt[e] = max(#gt relations, 1) ranks already sorted and position-adjusted as the reference
  * appends them (first cnt[e] slots, rest 0).  Flattening the used slots in edge order gives exactly
- * the reference's result arrays. */
+ * the reference's result arrays.  Triplet ranks are counted along a staircase over each node's sorted class probabilities
+ * (csrc/eval_ranks.hip): `scratch` holds vlsat_eval_ranks_scratch_floats(n_nodes, n_obj_class, topk_triplet) floats of device
+ * memory the call may overwrite (the topk largest probabilities per node; required when n_edges > 0). */
 int vlsat_eval_ranks(const float* obj_logits, const float* obj_probs, const float* rel_probs,
                      const int64_t* gt_class, const int64_t* gt_rel, const int64_t* edges,
                      int32_t n_nodes, int32_t n_edges, int32_t n_obj_class, int32_t n_rel_class,
                      int32_t topk_obj, int32_t topk_rel, int32_t topk_triplet, float threshold,
-                     int32_t* obj_rank, int32_t* rel_rank, int32_t* tri_rank, int32_t* cnt, void* stream);
+                     int32_t* obj_rank, int32_t* rel_rank, int32_t* tri_rank, int32_t* cnt, float* scratch, void* stream);
+int64_t vlsat_eval_ranks_scratch_floats(int32_t n_nodes, int32_t n_obj_class, int32_t topk_triplet);
 
 /* Rank arrays of one batch (the outputs of two vlsat_eval_ranks calls, 3D and 2D; cnt is the same for both: it depends on
  * the labels only) -> the ADDITIVE counts MMGNet.validation's summaries are functions of (reference src/model/model.py:

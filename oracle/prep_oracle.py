@@ -6,9 +6,11 @@ Restates what the reference data loader does per object after sampling (SURVEY Â
   layout     = permute [N,P,3] -> [N,3,P]                    reference src/model/model.py:79
   FC edges   = product(range(n), range(n)) minus diagonal    reference src/dataset/dataset_3dssg.py:264-266
   batching   = node offsets + batch_ids                       reference src/dataset/DataLoader.py:160-172
-Parity status: PINNED for gen_descriptor by tests/test_prep_oracle.py against
-tests/golden/prep_small.npz (reference function called directly); zero_mean / edge list / collate
-are literal restatements (the reference's dataset module needs trimesh and cannot be imported here).
+Parity status: PINNED.  gen_descriptor by tests/test_prep_oracle.py against tests/golden/prep_small.npz (reference function called
+directly); zero_mean, node order, edge list, labels, the [N,P,C] object tensors, the descriptor as data_preparation stores it
+(float64 arithmetic on trimesh's float64 vertices, cast to float32) and collate_fn_mmg by tests/test_scan_golden_cpu.py against
+tests/golden/scan_small.npz, which tests/golden/make_golden_scan.py makes by running the reference's dataset module itself
+(trimesh, absent here, replaced by a stand-in that hands over the vertex table; np.random.choice recorded).
 The random sampling itself (np.random.choice, :289) is an input of prepare_objects (`choice`); sample_choice restates the
 library's OWN documented generator for the device-side selection (vlsat_sample_objects): that one has no reference
 counterpart to pin to beyond np.where's index order -- the tests check membership, uniformity and determinism."""
@@ -24,17 +26,22 @@ def gen_descriptor(pts: torch.Tensor) -> torch.Tensor:
     return torch.cat([pts.mean(0), pts.std(0), dims, (dims[0] * dims[1] * dims[2]).unsqueeze(0), dims.max().unsqueeze(0)], 0)
 
 
+def zero_mean(point: torch.Tensor) -> torch.Tensor:
+    """[P,3] -> centred copy (dataset_3dssg.py:189-191; the reference centres in place)."""
+    return point - torch.mean(point, dim=0).unsqueeze(0)
+
+
 def prepare_objects(scene_points: np.ndarray, choice: np.ndarray, dtype=torch.float32):
-    """scene_points [Npts,3], choice [N,P] (sampled point ids) -> obj_points [N,3,P] f32, descriptor [N,11] f32."""
+    """scene_points [Npts,3], choice [N,P] (sampled point ids) -> obj_points [N,3,P] f32, descriptor [N,11] f32.  ``dtype`` is the
+    arithmetic of the descriptor: the reference computes it on the mesh's vertices as trimesh returns them, float64, and stores the
+    result in a float32 tensor (dataset_3dssg.py:290, 273) -- torch.float64 with float64 ``scene_points`` reproduces that exactly."""
     n, p = choice.shape
     obj = torch.zeros(n, p, 3)
     desc = torch.zeros(n, 11)
     for i in range(n):
         pts = torch.from_numpy(scene_points[choice[i]])
         desc[i] = gen_descriptor(pts.to(dtype))
-        f = pts.to(torch.float32).clone()
-        f -= f.mean(0).unsqueeze(0)
-        obj[i] = f
+        obj[i] = zero_mean(pts.to(torch.float32))
     return obj.permute(0, 2, 1).contiguous(), desc
 
 
@@ -72,7 +79,7 @@ def fc_edges_batch(n_per_scene):
 def scene_labels(instances: np.ndarray, instance2label: dict, class_names, rel_json, relation_names, multi_rel_outputs=True, all_edge=True):
     """Node order, edge list and ground truth of one scene, loop by loop as the reference's data_preparation builds them
     (src/dataset/dataset_3dssg.py:248-270 nodes and edges, :281-283 object labels, :300-314 adjacency, :322-336 per-edge labels).
-    Restated, not pinned: the dataset module imports trimesh, which this image lacks.  -> nodes, edges [E,2], gt_class [N], gt_rel."""
+    Pinned by tests/test_scan_golden_cpu.py to what the reference's data_preparation returns.  -> nodes, edges [E,2], gt_class [N], gt_rel."""
     ids_with_points = list(np.unique(instances))
     if 0 in ids_with_points:
         ids_with_points.remove(0)                                   # background

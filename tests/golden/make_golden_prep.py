@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Golden vectors for the per-object input preparation: the reference's
 gen_descriptor (src/utils/op_utils.py:47-64) called on sampled object points, as
-data_preparation does (src/dataset/dataset_3dssg.py:289-293).  dataset_3dssg.py itself cannot be
-imported here (needs trimesh); zero_mean (:189-191) is two torch lines, restated in oracle/prep_oracle.py."""
+data_preparation does (src/dataset/dataset_3dssg.py:289-293).  The dataset class itself (data_preparation, zero_mean,
+collate_fn_mmg, the readers) is run by tests/golden/make_golden_scan.py -> scan_small.npz."""
 import os
 import sys
 

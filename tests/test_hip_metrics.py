@@ -326,3 +326,45 @@ def test_merged_validation_matches_the_one_scene_loop():
     for b in batches:
         b.pop("fc_sizes")
     check(EV._validation_pipelined(model, batches, DEV, 1, merge=5))
+
+
+@pytest.mark.parametrize("regime", ["flat", "peaked", "ties", "few_classes", "one_hot"])
+def test_triplet_staircase_counts_equal_the_brute_force_oracle(regime):
+    """The triplet ranks come from a staircase walk over each node's sorted class probabilities (csrc/eval_ranks.hip) instead of
+    the C x C x R outer product the reference sorts (eva_utils_acc.py:161-178).  Bit-exact against the oracle's brute-force
+    counts in every shape the staircase can take: flat scores (count capped in row 0), peaked ones (a few cells), exact ties
+    between classes and between triples, fewer classes than topk (K = C), probabilities that are exactly 0 and 1; edges with no,
+    one, several and all relations labelled; self loops; R = 27."""
+    _need_gpu()
+    from vlsat_amd import metrics as M
+    from oracle import metrics_oracle as MO
+    g = torch.Generator().manual_seed({"flat": 1, "peaked": 2, "ties": 3, "few_classes": 4, "one_hot": 5}[regime])
+    n, e, C, R = 40, 260, 160, 27
+    if regime == "few_classes":
+        C = 9
+    scale = {"flat": 0.05, "peaked": 9.0, "ties": 3.0, "few_classes": 2.0, "one_hot": 60.0}[regime]
+    logits = torch.randn(n, C, generator=g) * scale
+    if regime == "ties":
+        logits = torch.round(logits)                                     # many classes share a score exactly
+        logits[::4] = logits[0]                                          # and whole nodes share a row
+    gt = torch.randint(0, C, (n,), generator=g)
+    edges = torch.stack([torch.randint(0, n, (e,), generator=g), torch.randint(0, n, (e,), generator=g)], 1)
+    edges[7] = torch.tensor([3, 3])
+    rel = torch.sigmoid(torch.randn(e, R, generator=g) * (0.2 if regime == "flat" else 4.0))
+    if regime == "ties":
+        rel = torch.round(rel * 8) / 8
+    gt_rel = (torch.rand(e, R, generator=g) < 0.06).long()
+    gt_rel[5] = 1
+    gt_rel[6] = 0
+    probs = F.softmax(logits, dim=-1)
+    r = M.eval_ranks(logits.to(DEV), rel.to(DEV), gt.to(DEV), gt_rel.to(DEV), edges.to(DEV), obj_probs=probs.to(DEV))
+    torch.cuda.synchronize()
+    obj = MO.topk_object(logits, gt, 11)
+    tri, _ = MO.triplet_topk(logits, rel, gt, gt_rel, edges, 101, obj, obj_probs=probs)
+    got = r["top_k_triplet"].cpu().numpy()
+    assert got.shape == tri.shape and np.array_equal(got, tri), (regime, int((got != tri).sum()))
+    assert np.array_equal(r["top_k_rel"].cpu().numpy(), MO.topk_predicate(rel, gt_rel, 6))
+    if regime in ("flat",):
+        assert (got >= 90).mean() > 0.5                                  # the cap is what this regime exercises
+    if regime in ("peaked", "one_hot"):
+        assert (got <= 50).mean() > 0.2                                  # and real counts what this one does

@@ -79,3 +79,43 @@ def test_colour_channels_ride_along_with_the_selection(tmp_path):
     choice = b["choice"].cpu().numpy()
     want = (rgb[choice] / 255.0).astype(np.float32).transpose(0, 2, 1)
     assert np.allclose(b["obj_points"][:, 3:].cpu().numpy(), want, atol=1e-7)
+
+
+def test_device_preparation_equals_the_reference_on_its_recorded_draws(golden_dir):
+    """The device half (vlsat_prepare_objects) against the REAL data_preparation (reference dataset_3dssg.py:285-293), fixture
+    tests/golden/scan_small.npz (made by make_golden_scan.py from the reference's dataset class): the same mesh file read by
+    scan.read_ply, the draws np.random.choice made inside the reference, -> obj_points and descriptor within 1e-6 (the reference
+    computes the descriptor in float64 and centres float32 points with their float32 mean; so does the kernel, up to the rounding
+    of that mean)."""
+    import os
+    z = np.load(os.path.join(golden_dir, "scan_small.npz"))
+    e = json.load(open(os.path.join(golden_dir, "scan_small_expect.json")))
+    mesh = S.read_ply(os.path.join(golden_dir, "scan_small.ply"))
+    rel, objs, scans = S.read_relationships(os.path.join(golden_dir, "scan_small_relationships.json"), ["scan-a"])
+    rel, objs = rel["scan-a_0"], objs["scan-a_0"]
+    nodes = S.scene_nodes(mesh["instances"], objs)
+    assert nodes == e["nodes_scan_a_0"]
+    from vlsat_amd import prep
+    for tag, use_extra in (("prep_multi_all_xyz", False), ("prep_multi_all_xyz_rgb_normal", True)):
+        choice = np.stack([np.where(mesh["instances"] == i)[0][z[tag + "_choice"][k]] for k, i in enumerate(nodes)]).astype(np.int32)
+        d_xyz = torch.from_numpy(np.ascontiguousarray(mesh["points"], dtype=np.float32)).to(DEV)
+        d_choice = torch.from_numpy(choice).to(DEV)
+        obj, desc = prep.prepare_objects(d_xyz, d_choice)
+        want = torch.from_numpy(z[tag + "_obj_points"]).permute(0, 2, 1)                 # reference layout [N,P,C] -> [N,C,P]
+        assert float((obj.cpu() - want[:, :3]).abs().max()) <= 1e-6
+        assert float((desc.cpu() - torch.from_numpy(z[tag + "_descriptor"])).abs().max()) <= 1e-6
+    # the whole entry on the same files: everything but the (library-drawn) selection equals the reference's outputs
+    b = S.prepare_scan(os.path.join(golden_dir, "scan_small.ply"), objs, e["classes"], rel, e["relations"], num_points=16, seed=1, device=DEV,
+                       use_rgb=True, use_normal=True, feature_loader=lambda i, name: z["multi_view_feats"][nodes.index(i)])
+    assert b["instance_ids"] == nodes and b["obj_points"].shape == (5, 9, 16)
+    assert np.array_equal(b["edge_indices"].cpu().numpy(), z["prep_multi_all_xyz_edge_indices"])
+    assert np.array_equal(b["gt_class"].cpu().numpy(), z["prep_multi_all_xyz_label_node"])
+    assert np.array_equal(b["gt_rel_cls"].cpu().numpy(), z["prep_multi_all_xyz_gt_rels"])
+    assert np.array_equal(b["obj_2d_feats"].cpu().numpy(), z["prep_multi_all_xyz_obj_2d_feats"])
+    assert b["points_per_instance"].cpu().tolist() == z["prep_multi_all_xyz_count"].tolist()
+    ch = b["choice"].cpu().numpy()
+    extra = z["mesh_points_xyz_rgb_normal"][:, 3:][ch].astype(np.float32).transpose(0, 2, 1)
+    assert np.array_equal(b["obj_points"][:, 3:].cpu().numpy(), extra)                     # colour / normal channels: gathered, not centred
+    big = {**mesh, "instances": np.where(mesh["instances"] == 5, 1 << 24, mesh["instances"])}      # an instance id the id map cannot hold
+    with pytest.raises(S.ScanError, match="distinct"):
+        S.prepare_scan(big, {**objs, (1 << 24): "chair"}, e["classes"], rel, e["relations"], 16, 1, device=DEV)
