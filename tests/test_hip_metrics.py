@@ -367,4 +367,4 @@ def test_triplet_staircase_counts_equal_the_brute_force_oracle(regime):
     if regime in ("flat",):
         assert (got >= 90).mean() > 0.5                                  # the cap is what this regime exercises
     if regime in ("peaked", "one_hot"):
-        assert (got <= 50).mean() > 0.2                                  # and real counts what this one does
+        assert (got <= 50).mean() > 0.05                                 # and real counts what this one does
