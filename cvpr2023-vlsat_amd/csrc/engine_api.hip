@@ -64,6 +64,7 @@ int vlsat_debug_option(vlsat_handle h, const char* name, int32_t value) {
     else if (k == "flash_split") h->fa_split = value != 0;
     else if (k == "gemm_dma") h->gemm_no_dma = value == 0;
     else if (k == "gemm_p8") h->gemm_no_p8 = value == 0;
+    else if (k == "gemm_k_rot") h->gemm_k_rot = value < 0 ? 0 : value;
     else if (k == "gate_row_map") h->gate_row_map = value != 0;
     else if (k == "prof_dual") h->prof_dual = value != 0;
     else if (k == "gate_heads_mfma") h->gate_heads_mfma = value < 0 ? 0 : value > 2 ? 2 : value;
@@ -77,6 +78,7 @@ int vlsat_debug_option(vlsat_handle h, const char* name, int32_t value) {
     else if (k == "gate_bf16") h->gate_bf16 = value != 0;
     else if (k == "flash_tr") h->flash_tr = value != 0;
     else if (k == "flash_bq_big") h->flash_bq_big = value != 0;
+    else if (k == "flash_asmv") h->flash_asmv = value != 0;
 #ifdef VLSAT_EXPERIMENTS
     else if (k == "gate_grid") h->gate_grid = value > 0 ? value : 0;
     else if (k == "gate_heads_bf16") h->gate_heads_bf16 = value != 0;
@@ -148,9 +150,10 @@ int vlsat_k_gemm_planes(const float* A, int32_t lda, const float* W, const uint1
     a.prec = prec; a.Whi = Whi; a.Wlo = Wlo; a.no_dma = no_dma; a.prefetch = prefetch;
     const int code = (fmt >> 5) & 1 ? 2 : 1;   // (bit 5: the flagged operands are half rows instead of split pairs)
     a.a_split = (fmt & 1) * code; a.r_split = ((fmt >> 1) & 1) * code; a.c_split = ((fmt >> 2) & 1) * code; a.c_scale = c_scale;
-    // (bit 3 was the k-rotation experiment: removed; bit 4: no ring kernel -- benchmarking)
+    // (bit 3: free; bit 4: no ring kernel -- benchmarking)
     a.no_ring = (fmt >> 4) & 1;
     a.no_p8 = (fmt >> 12) & 1;                 // (bit 12: half-row launches skip the 256 x 256 8-phase kernel)
+    a.k_rot = (fmt >> 22) & 7;                 // (bits 22..24: K-tile rotation per column tile of the 8-phase kernel -- A/B)
     if (kExperiments) {                        // lab bits (tools/gemm_bench.py, p8_check.py, gemm_tile_sweep.py): the experiments build only
         a.ring_wide = (fmt >> 7) & 1;              // (bit 7: ring kernel with 128 x 256 tiles where N allows)
         a.ablate = ((fmt >> 8) & 3) | (((fmt >> 13) & 63) << 2);   // (bits 8, 9, 13..18: timing experiments, see GemmArgs::ablate)

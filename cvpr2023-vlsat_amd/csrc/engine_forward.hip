@@ -102,6 +102,7 @@ int gemm(vlsat_ctx* h, hipStream_t s, const GemmArgs& a0, int prec_override = -1
     }
     a.no_dma = h->gemm_no_dma;
     a.no_p8 = h->gemm_no_p8;
+    a.k_rot = h->gemm_k_rot;
     a.launches = &h->gemm_launches;
     if (h->gemm_splitk) {
         const int w = prof_lane(h, s);             // (a split-K workspace per lane: launches of different lanes overlap)
@@ -566,6 +567,7 @@ static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const fl
                 Scope sc(h, fs, PC_FLASH, p->flash_flops);
                 FlashSplit sp;
                 sp.ablate = h->flash_ablate;
+                sp.asmv = h->flash_asmv;
                 sp.parts = p->fa_parts; sp.krange = p->d_krange; sp.o_part = p->fa_opart; sp.m_part = p->fa_m;
                 sp.l_part = p->fa_l; sp.part_stride = (size_t)E * D; sp.rows = E; sp.heads = h->H;
                 if (dh != 32 && dh != 64 && dh != 128)   // any other head dim: VALU attention over the scenes' edge ranges (no bias)

@@ -66,6 +66,12 @@ enum { P8_MID = 0, P8_LAST = 1, P8_FIRST = 2, P8_SECOND = 3, P8_FIRST0 = 4 };   
 // the lo plane side by side, 128 rows x 64 bytes each (chunks swizzled with (row >> 2) & 3), one LDS-direct load per plane
 // -- so a half-tile is still two loads and every counted wait is unchanged.  Term order per accumulator and epilogue order
 // as in the older split-bf16 kernels: bit-identical results.
+// (round 6, measured and dropped: the g0 rows of a gathered-row tile DEDUPLICATED per 32-row strip -- source-major edge lists name
+//  one or two g0 rows per strip; each distinct 256-byte segment fetched once by 16 lanes into the wave's idle transposition
+//  buffer, every lane reading its run's values from LDS, bit-identical results -- 213.6 / 218.5 us against 209.5 / 210.6 us for the
+//  per-lane gather on the bench batch's indices, 9852-9867 vs 9839-9880 scenes/s per step: the repeated g0 lines were L1 hits
+//  already, what the launch pays for is the L2 -> CU traffic of the DISTINCT lines, which the deduplication does not change.
+//  profiles/r06_probes/p8_dedup_krot_{kernel,step}_ab.txt)
 template <int MODE, int ADD, bool RELU, int CF, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmArgs p, int n_tiles, int nbn) {
     constexpr bool F32 = MODE == 1, X3 = MODE == 2, WORDS = MODE != 0;      // WORDS: 4-byte A elements, K-tiles of 32
@@ -140,6 +146,10 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmArgs p, int n_tiles
     auto advance = [&](Cur& c) {
         if (++c.kt == KT) { c.kt = 0; ++c.r; locate(c); }
     };
+    // (A/B, GemmArgs::k_rot) column tile tn of a row panel walks its K-tiles starting at tn * k_rot: the blocks that share an A panel
+    //  (neighbouring slots of one XCD) then ask L2 for the same lines a K-tile or more apart instead of in the same microsecond
+    const int rot = p.k_rot ? ((tile_of_round(0) % nbn) * p.k_rot) % KT : 0;
+    auto kti = [&](const Cur& c) { const int j = c.kt + rot; return (unsigned)(j >= KT ? j - KT : j); };
     Cur c1{0, 0, 0u, 0u};
     locate(c1);
     const Cur c0 = c1;
@@ -394,12 +404,12 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmArgs p, int n_tiles
     };
 
     // ---- prologue: the six half-tiles whose staging phase lies before the first compute phase ----
-    ld2(ra, sdst, vA, c0.sa, 128u * lda4);                                                        // A_0(0)
-    ldw(sdst + P8_WBASE, c0.sw, 0);                                                               // W_0(0)
-    ldw(sdst + P8_WBASE + P8_HALF, c0.sw, 1);                                                     // W_1(0)
-    ld2(ra, sdst + P8_HALF, vA, c0.sa + 64u * lda4, 128u * lda4);                                 // A_1(0)
-    ld2(ra, sdst + 2 * P8_HALF, vA, c1.sa + c1.kt * KA, 128u * lda4);                             // A_0(1)
-    ldw(sdst + P8_WBASE + 2 * P8_HALF, c1.sw + c1.kt * KW, 0);                                    // W_0(1)
+    ld2(ra, sdst, vA, c0.sa + kti(c0) * KA, 128u * lda4);                                         // A_0(0)
+    ldw(sdst + P8_WBASE, c0.sw + kti(c0) * KW, 0);                                                // W_0(0)
+    ldw(sdst + P8_WBASE + P8_HALF, c0.sw + kti(c0) * KW, 1);                                      // W_1(0)
+    ld2(ra, sdst + P8_HALF, vA, c0.sa + kti(c0) * KA + 64u * lda4, 128u * lda4);                  // A_1(0)
+    ld2(ra, sdst + 2 * P8_HALF, vA, c1.sa + kti(c1) * KA, 128u * lda4);                           // A_0(1)
+    ldw(sdst + P8_WBASE + 2 * P8_HALF, c1.sw + kti(c1) * KW, 0);                                  // W_0(1)
     p8_wait_vm<8>();
     p8_barrier();
     if (wr == 1) p8_barrier();                       // the two wave rows run one barrier apart from here on
@@ -416,8 +426,8 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmArgs p, int n_tiles
         constexpr int N2 = 8 + (VAR == P8_FIRST ? 4 * E : 0);
         constexpr int N4 = 8 + (VAR == P8_FIRST || VAR == P8_LAST ? 2 * E : 0);
         using Init = std::integral_constant<bool, VAR == P8_FIRST || VAR == P8_FIRST0>;
-        const unsigned a1 = c1.sa + c1.kt * KA, w1o = c1.sw + c1.kt * KW;
-        const unsigned a2 = c2.sa + c2.kt * KA, w2o = c2.sw + c2.kt * KW;
+        const unsigned a1 = c1.sa + kti(c1) * KA, w1o = c1.sw + kti(c1) * KW;
+        const unsigned a2 = c2.sa + kti(c2) * KA, w2o = c2.sw + kti(c2) * KW;
         // phase 1: quadrant (a0, w0)
         if (VAR == P8_FIRST) {               // (before the fragment reads: the strip's temporaries need their registers)
             epi(std::integral_constant<int, 2>{}, pm0);

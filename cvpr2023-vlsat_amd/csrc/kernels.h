@@ -36,6 +36,7 @@ struct GemmArgs {
     int ring_wide = 0;                          // experiment: bf16 ring kernel with 128 x 256 tiles where N allows (measured equal)
     int no_ring = 0;                            // debug: keep large bf16 launches on the two-stage 128 x 128 kernel
     int no_p8 = 0;                              // debug: large launches skip the 256 x 256 8-phase kernel (gemm_bf16_p8.hip)
+    int k_rot = 0;                              // A-B: the column tiles of a row panel walk their K-tiles rotated by tn * k_rot (8-phase kernel: siblings re-read the A panel out of step)
     int force_tile = 0;                         // experiment (tools/gemm_tile_sweep.py): 1 = 128x128, 2 = 128x64, 3 = 64x128, 4 = 64x64 tiles of gemm_f32_kernel, whatever the heuristic says
     int prefetch = -1;                          // bf16 LDS-direct pipe: slices of look-ahead of the A-panel prefetch (0 off, -1 default)
     int no_dma = 0;                             // debug: VGPR-staged fp32 operands instead of LDS-direct (vlsat_debug_option "gemm_dma")
@@ -83,6 +84,7 @@ struct FlashSplit {
     int rows = 0, heads = 0;
     int ablate = 0;              // timing experiments (garbage results): bit 0 no K/V loads after the first tile, bit 1 no LDS stores of them either
     int bq = 128;                // queries per block of the tile table handed in: FLASH_BQ, or FLASH_BQ_BIG (half rows, head dim 64, LDS-direct kernel only)
+    int asmv = 0;                // LDS-direct kernel at head dim 64: V fragments by inline-asm transpose reads (no vmcnt drain in front of the P.V product)
 };
 int launch_flash_attn(const float* Q, int ldq, const float* K, const float* V, int ldkv, float* O, int ldo,
                       const int4* tiles, int n_tiles, float scale_log2e, hipStream_t s, const FlashSplit* split = nullptr,

@@ -62,6 +62,7 @@ class VLSATModel:
         self._plans: "OrderedDict[tuple, _Plan]" = OrderedDict()
         self._ident: "OrderedDict[tuple, tuple]" = OrderedDict()     # (id(edge tensor), id(batch tensor)) -> plan key
         self._fc_verified = set()           # fc_sizes keys whose device edge list has been checked against the canonical graph
+        self.verify_fc_every_call = False   # re-check the fc_sizes claim on every call (debugging; costs a stream sync per call)
         self._debug_options = {}            # vlsat_debug_option settings applied to this handle (replayed by replicate())
         self.plan_stats = {"hits": 0, "identity_hits": 0, "builds": 0, "d2h_copies": 0}
         self.training = False
@@ -276,10 +277,12 @@ class VLSATModel:
         """Plan for this graph, from a content-keyed LRU cache.  In order of cost:
           1. ``fc_sizes`` given: the caller states that edge_indices IS the canonical fully-connected edge list of
              scenes with these object counts (source-major, ``synth.fc_edges`` order) -> key (sizes, P).  The claim is
-             CHECKED once per new key: host-side edge tensors against the canonical list on the host, device tensors (and
-             device batch_ids) by a kernel against the new plan's own tables (``vlsat_plan_check_graph``: one 4-byte
-             read-back when the plan is built; a wrongly ordered list would attribute every rel_cls row to the wrong
-             edge).  A key that is already cached reads nothing from the device;
+             checked for the FIRST tensor that arrives under a key only: host-side edge tensors against the canonical list
+             on the host, device tensors (and device batch_ids) by a kernel against the new plan's own tables
+             (``vlsat_plan_check_graph``: one 4-byte read-back when the plan is built; a wrongly ordered list would
+             attribute every rel_cls row to the wrong edge).  Later calls with the same sizes are TRUSTED -- a key that is
+             already cached reads nothing from the device -- unless ``self.verify_fc_every_call`` is set (a debugging aid:
+             every call with the hint then re-runs the check, host or device, at the price of a stream synchronisation);
           2. the same tensor OBJECTS as an earlier call, unmodified -> no copy either;
           3. edge_indices / batch_ids on the host (the reference's loader yields them there) -> hashed on the host;
           4. device tensors never seen before -> one D2H copy (a stream sync) to hash them.
@@ -298,6 +301,11 @@ class VLSATModel:
             if sum(sizes) != n or edge_indices.shape[1] != sum(k * (k - 1) for k in sizes):
                 raise L.VlsatError("fc_sizes does not match the node / edge counts")
             key = ("fc", sizes, p, self.batch_mode)
+            if self.verify_fc_every_call and key in self._plans:         # (debugging aid: the claim of an already trusted key, again)
+                if edge_indices.is_cuda or batch_ids.is_cuda:
+                    self._check_device_graph(self._plans[key], edge_indices, batch_ids)
+                elif not torch.equal(edge_indices.contiguous(), self._fc_host(sizes)[0]):
+                    raise L.VlsatError("fc_sizes: edge_indices is not the canonical fully-connected edge list of these scenes")
             if not edge_indices.is_cuda and key not in self._plans:      # free to verify on the host, once per key
                 if not torch.equal(edge_indices.contiguous(), self._fc_host(sizes)[0]):
                     raise L.VlsatError("fc_sizes: edge_indices is not the canonical fully-connected edge list of these scenes")

@@ -200,7 +200,7 @@ def test_random_graphs_vs_oracle(seed):
     _check(run_hip(cfg, b), run_oracle(cfg, b), TIGHT, f"random graph batch #{seed} ({len(scenes)} scenes, E={len(perm)})")
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16_mixed"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16_mixed", "bf16x3_attn1"])
 def test_two_stream_mode_is_bit_identical(precision):
     """Two-stream plans run the forward on up to three lanes (engine_forward.hip): the dependency-exact schedule of round 5
     ("sched" = 1: 3D chain / 2D edge chain / 2D node chain, coupled by one event per data-flow edge, the 3D chain up to a layer

@@ -578,7 +578,8 @@ def test_half_row_format_gemm_and_attention(lib):
 
 
 @pytest.mark.parametrize("N,K,resid,gather,relu_a,act,c_half", [(512, 512, 0, 0, 0, 1, 1), (1024, 256, 0, 0, 1, 0, 1), (512, 1024, 0, 0, 0, 0, 0),
-                                                                (256, 512, 1, 0, 0, 1, 0), (1024, 512, 0, 1, 1, 1, 1)])
+                                                                (256, 512, 1, 0, 0, 1, 0), (1024, 512, 0, 1, 1, 1, 1), (1024, 512, 0, 2, 1, 1, 1),
+                                                                (512, 256, 0, 3, 0, 0, 0), (1024, 512, 0, 4, 1, 1, 1)])
 def test_gemm_bf16_p8_kernel(lib, N, K, resid, gather, relu_a, act, c_half):
     """Half-row launches with M >= one full round of 256 x 256 tiles: the 8-phase kernel (gemm_bf16_p8.hip) takes the
     full rounds, the remaining row panels the older kernels.  Same k order per accumulator as the 128 x 128 kernel; the bias
@@ -596,8 +597,21 @@ def test_gemm_bf16_p8_kernel(lib, N, K, resid, gather, relu_a, act, c_half):
     Rh = _to_half_rows(R).to(DEV)
     NG = 777
     gbuf = torch.randn(NG, 2 * N, generator=g).to(DEV)
-    gi0 = torch.randint(0, NG, (M,), generator=g, dtype=torch.int32).to(DEV)
+    gi0 = torch.randint(0, NG, (M,), generator=g, dtype=torch.int32)
     gi1 = torch.randint(0, NG, (M,), generator=g, dtype=torch.int32).to(DEV)
+    # gather = 1: random indices; 2: source-major runs of 39 like the bench batch's edge list; 3: runs of 1..12; 4: runs of 39 with a
+    # few out-of-order rows
+    if gather >= 2:
+        lens = {2: lambda: 39, 3: lambda: int(torch.randint(1, 13, (1,), generator=g)), 4: lambda: 39}[gather]
+        rows, node = [], 0
+        while len(rows) < M:
+            rows += [node % NG] * lens()
+            node += 1
+        gi0 = torch.tensor(rows[:M], dtype=torch.int32)
+        if gather == 4:
+            hit = torch.randint(0, M, (M // 50,), generator=g)
+            gi0[hit] = torch.randint(0, NG, (len(hit),), generator=g, dtype=torch.int32)
+    gi0 = gi0.to(DEV)
     hi = torch.empty(N * K + 128, dtype=torch.int16, device=DEV)
     lo = torch.empty_like(hi)
     lib.check(l.vlsat_k_split_bf16(W.data_ptr(), N * K, hi.data_ptr(), lo.data_ptr(), lib.stream_ptr()))

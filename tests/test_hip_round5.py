@@ -45,6 +45,13 @@ def test_fc_sizes_with_a_device_edge_list_is_checked_not_trusted():
     plain = m(*args, d["edge_indices"], d["descriptor"], d["batch_ids"])
     for n, a, b, c in zip(NAMES, hinted, again, plain):
         assert torch.equal(a, b) and torch.equal(a, c), n
+    # a key that has been checked once is trusted afterwards: the same wrong list now passes unnoticed ...
+    m(*args, bad, d["descriptor"], d["batch_ids"], fc_sizes=sizes)
+    # ... unless the caller asks for the check on every call (debugging aid; one stream synchronisation per call)
+    m.verify_fc_every_call = True
+    with pytest.raises(L.VlsatError, match="not the canonical"):
+        m(*args, bad, d["descriptor"], d["batch_ids"], fc_sizes=sizes)
+    m(*args, d["edge_indices"], d["descriptor"], d["batch_ids"], fc_sizes=sizes)
     m.close()
 
 

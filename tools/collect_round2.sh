@@ -36,7 +36,7 @@ python tools/gemm_clock_probe.py --prec 3 > "$OUT/gemm_clock_bf16x3.txt" 2>&1
 python tools/gemm_clock_probe.py --prec 1 > "$OUT/gemm_clock_bf16.txt" 2>&1
 tools/forward_timeline.sh r02 40 > /dev/null 2>&1
 tools/forward_timeline.sh r02 40 bf16x3 > /dev/null 2>&1 && mv "$OUT/timeline_40.txt" "$OUT/timeline_40_bf16x3.txt"; tools/forward_timeline.sh r02 40 > /dev/null 2>&1
-python tools/graph_replay_probe.py 2>&1 | grep objects > "$OUT/graph_replay.txt"
+# (tools/graph_replay_probe.py and the hipGraph replay path it measured -- vlsat_forward_graph -- were removed in round 5: slower than eager)
 tools/bin/l2_fill_probe > "$OUT/l2_fill.txt" 2>&1
 tools/bin/lds_bw_probe > "$OUT/lds_bw.txt" 2>&1
 tools/bin/tr_read_probe > "$OUT/tr_read.txt" 2>&1

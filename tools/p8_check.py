@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--only", default="", help="substring of the shape names to run")
     ap.add_argument("--cold", type=int, default=1, help="cycle through this many copies of A and C (4: nothing a launch reads is in a cache)")
     ap.add_argument("--structured", action="store_true", help="gather indices of the bench batch instead of random ones")
+    ap.add_argument("--ab", action="store_true", help="round 6: K-tile rotation per column tile, A/B on the release library")
     ap.add_argument("--ablate", action="store_true", help="time the kernel with loads / MFMAs / fragment reads removed (first shape)")
     a = ap.parse_args()
     lib = L.load()
@@ -108,6 +109,8 @@ def main():
                 d = ((gv - rv).abs() > tol).nonzero()
                 print("   first bad (row, col):", d[:8].tolist(), " rows hit:", int(((gv - rv).abs() > tol).any(1).sum()), flush=True)
         variants = [("p8", fmt), ("ring", fmt | NO_P8)]
+        if a.ab:                                   # round 6 A/B, release library: K-tile rotation per column tile
+            variants = [("p8", fmt)] + [(f"k_rot={r}", fmt | (r << 22)) for r in (1, 2, 3)] + [("p8 again", fmt)]
         if a.ablate and name.startswith("kproj"):
             ab = lambda bits: ((bits & 3) << 8) | (((bits >> 2) & 63) << 13)
             variants += [("-load", fmt | ab(1)), ("-mfma", fmt | ab(2)), ("-read", fmt | ab(4)), ("-ld-mf", fmt | ab(3)), ("-mf-rd", fmt | ab(6)), ("none", fmt | ab(7)),
