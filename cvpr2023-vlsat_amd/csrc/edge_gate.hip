@@ -30,8 +30,11 @@ constexpr int GT_PITCH3 = 132;   // W3 rows: 128 + 4 pad
 
 // FUSED: the max aggregation runs inside the kernel (GateArgs::agg; gate_agg.h) and its wave buffers exist -- 63 KB of LDS per block,
 // two blocks per CU.  Exact fp32 keeps the separate aggregate launch by default, and that variant holds 51.7 KB: three per CU.
-template <bool FUSED>
-__global__ __launch_bounds__(256, 2) void edge_gate_kernel(GateArgs p) {
+// TWIN (round 6): the gates of gcn_3ds[l] and gcn_2ds[l] of a one-scene plan in ONE launch, selected by blockIdx.y (same edge list,
+// same grid; every block runs the single launch's code on its own problem: bit-identical results).
+template <bool FUSED, bool TWIN = false>
+__global__ __launch_bounds__(256, 2) void edge_gate_kernel(GateArgs pa, GateArgs pb) {
+    const GateArgs& p = (TWIN && blockIdx.y != 0) ? pb : pa;
     __shared__ __attribute__((aligned(16))) float sW0[128 * GT_PITCH];
     __shared__ __attribute__((aligned(16))) float sW3[32 * GT_PITCH3];
     __shared__ __attribute__((aligned(16))) char sAgg[FUSED ? 4 * AG_WAVE_BYTES : 16];      // wave buffers of the fused aggregation
@@ -198,8 +201,11 @@ int launch_edge_gate_generic(const GateArgs& a, int n_heads, int dk, int dox, hi
     return 0;
 }
 
-int launch_edge_gate(const GateArgs& a, hipStream_t s) {
+int launch_edge_gate(const GateArgs& a, hipStream_t s, const GateArgs* twin) {
     if (a.n_edges <= 0) return 0;
+    if (twin && (twin->n_edges != a.n_edges || !twin->agg != !a.agg || twin->row_map != a.row_map || twin->use_edge != a.use_edge ||
+                 !twin->prob != !a.prob || twin->grid_cap != a.grid_cap || twin->src != a.src || twin->dst != a.dst))
+        return fail(-1, "edge_gate: a twin launch needs two problems on the same edge list with the same options");
     if (a.agg && (!a.row_map || a.prob || (a.ld_agg & 3))) return fail(-1, "edge_gate: the fused aggregation needs the 32-edges-per-wave row map and no prob tap");
     if ((a.ld_node & 3) || (a.gq_off & 3) || (a.v_off & 3)) return fail(-1, "edge_gate: ld_node/gq_off/v_off must be multiples of 4");
     const int n_groups = a.row_map ? 2 * ((a.n_edges + 31) / 32) : (a.n_edges + 15) / 16;
@@ -207,8 +213,11 @@ int launch_edge_gate(const GateArgs& a, hipStream_t s) {
     // blocks per CU (51.7 KB of LDS each), 2 with the aggregation's wave buffers (63 KB) -- so there is no partial last wave of blocks
     const int cap = a.grid_cap > 0 ? a.grid_cap : (a.agg ? 512 : 768);
     const int grid = n_groups < cap ? n_groups : cap;
-    if (a.agg) hipLaunchKernelGGL(edge_gate_kernel<true>, dim3(grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(edge_gate_kernel<false>, dim3(grid), dim3(256), 0, s, a);
+    if (twin) {
+        if (a.agg) hipLaunchKernelGGL((edge_gate_kernel<true, true>), dim3(grid, 2), dim3(256), 0, s, a, *twin);
+        else hipLaunchKernelGGL((edge_gate_kernel<false, true>), dim3(grid, 2), dim3(256), 0, s, a, *twin);
+    } else if (a.agg) hipLaunchKernelGGL((edge_gate_kernel<true, false>), dim3(grid), dim3(256), 0, s, a, a);
+    else hipLaunchKernelGGL((edge_gate_kernel<false, false>), dim3(grid), dim3(256), 0, s, a, a);
     VLSAT_LAUNCH_CHECK("edge_gate");
     return 0;
 }

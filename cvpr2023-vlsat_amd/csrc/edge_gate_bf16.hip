@@ -24,8 +24,10 @@ constexpr int GB_P0 = 144;      // W0k plane row pitch (64 bf16 + 16 B)
 constexpr int GB_P3 = 264;      // W3 plane row pitch (128 bf16 + 8 B: the 32 rows of a ds_read_b64 land on 32 different bank pairs)
 
 // KS: format of kproj -- 0 fp32, 1 split-pair words, 2 half rows (bf16; TERMS = 1)
-template <int TERMS, int KS>
-__global__ __launch_bounds__(256, TERMS == 1 ? 4 : 2) void edge_gate_bf16_kernel(GateArgs p) {
+// TWIN (round 6): two gates on one edge list in one launch, selected by blockIdx.y (edge_gate.hip)
+template <int TERMS, int KS, bool TWIN = false>
+__global__ __launch_bounds__(256, TERMS == 1 ? 4 : 2) void edge_gate_bf16_kernel(GateArgs pa, GateArgs pb) {
+    const GateArgs& p = (TWIN && blockIdx.y != 0) ? pb : pa;
     constexpr int PL = TERMS == 1 ? 1 : 2;
     constexpr int W0B = 128 * GB_P0, W3B = 32 * GB_P3;
     __shared__ __attribute__((aligned(16))) char smem[PL * (W0B + W3B) + 4 * AG_WAVE_BYTES];     // + the fused aggregation's wave buffers (gate_agg.h)
@@ -185,8 +187,12 @@ __global__ __launch_bounds__(256, TERMS == 1 ? 4 : 2) void edge_gate_bf16_kernel
 
 }  // namespace
 
-int launch_edge_gate_bf16(const GateArgs& a, int terms, int kproj_split, hipStream_t s) {
+int launch_edge_gate_bf16(const GateArgs& a, int terms, int kproj_split, hipStream_t s, const GateArgs* twin) {
     if (a.n_edges <= 0) return 0;
+    if (twin && (twin->n_edges != a.n_edges || !twin->agg != !a.agg || twin->row_map != a.row_map || twin->use_edge != a.use_edge ||
+                 !twin->prob != !a.prob || twin->grid_cap != a.grid_cap || twin->src != a.src || twin->dst != a.dst))
+        return fail(-1, "edge_gate_bf16: a twin launch needs two problems on the same edge list with the same options");
+    const GateArgs& b = twin ? *twin : a;
     if ((a.ld_node & 3) || (a.gq_off & 3) || (a.v_off & 3)) return fail(-1, "edge_gate: ld_node/gq_off/v_off must be multiples of 4");
     if (terms != 1 && terms != 3) return fail(-1, "edge_gate_bf16: terms must be 1 or 3");
     if (a.agg && (!a.row_map || a.prob || (a.ld_agg & 3))) return fail(-1, "edge_gate_bf16: the fused aggregation needs the 32-edges-per-wave row map and no prob tap");
@@ -195,7 +201,8 @@ int launch_edge_gate_bf16(const GateArgs& a, int terms, int kproj_split, hipStre
     // 37 KB of LDS) and 1024 measured 0.7 % faster per step than 768 or 1280 with the aggregation fused in
     const int cap = a.grid_cap > 0 ? a.grid_cap : terms == 1 ? 1024 : 768;
     const int grid = n_groups < cap ? n_groups : cap;
-#define VLSAT_GB(T, K) hipLaunchKernelGGL((edge_gate_bf16_kernel<T, K>), dim3(grid), dim3(256), 0, s, a)
+#define VLSAT_GB(T, K) do { if (twin) hipLaunchKernelGGL((edge_gate_bf16_kernel<T, K, true>), dim3(grid, 2), dim3(256), 0, s, a, b); \
+                            else hipLaunchKernelGGL((edge_gate_bf16_kernel<T, K, false>), dim3(grid), dim3(256), 0, s, a, a); } while (0)
     if (kproj_split == 2 && terms != 1) return fail(-1, "edge_gate_bf16: half-row kproj needs terms = 1");
     if (terms == 3) { if (kproj_split) VLSAT_GB(3, 1); else VLSAT_GB(3, 0); }
     else            { if (kproj_split == 2) VLSAT_GB(1, 2); else if (kproj_split) VLSAT_GB(1, 1); else VLSAT_GB(1, 0); }

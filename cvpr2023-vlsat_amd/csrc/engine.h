@@ -95,14 +95,15 @@ struct vlsat_ctx {
     double acc_fl[vlsat::PC_COUNT] = {0};
     int debug_stop = -1;
     int gemm_no_dma = 0, gate_grid = 0, gate_row_map = 1, gate_heads_mfma = 1, flash_heads_bf16 = 1, gate_heads_bf16 = 1;      // vlsat_debug_option
-    int gemm_k_rot = 0;                      // vlsat_debug_option "gemm_k_rot": K-tile rotation per column tile of the 8-phase GEMM (A/B)
+    int pair_twins = 1;                      // one-scene plans (E <= pair_max_edges): the 3D / 2D twin stages as launches of two problems each (engine_forward.hip, "paired schedule"; vlsat_debug_option "pair_twins")
+    int pair_max_edges = 4096;               // ... and the plan size up to which that schedule is used ("pair_max_edges")
+    int gemm_k_rot = -1;                     // vlsat_debug_option "gemm_k_rot": K-tile rotation per column tile of the 8-phase GEMM; -1 (default) = 1 for half-row bf16 launches, 0 otherwise
     int gemm_no_p8 = 0;                      // vlsat_debug_option "gemm_p8": 0 keeps half-row launches off the 8-phase kernel
     int node_attn_split = 1024;              // node attention: sixteen lanes per query when the plan has fewer waves than this
     long config_epoch = 0;                   // bumped by every call that changes what a forward launches 
     int gemm_splitk = 1;                     // small GEMM launches take the split-K kernel (gemm_splitk.hip)
     float* sk_ws[3] = {nullptr, nullptr, nullptr};    // its workspace + counters, one set per lane: [0] launch stream, [1] / [2] the side streams
     unsigned* sk_cnt[3] = {nullptr, nullptr, nullptr};
-    int flash_asmv = 0;                      // debug option "flash_asmv": the edge attention's V fragments by inline-asm transpose reads (round 6 A/B)
     int flash_bq_big = 1;                    // 256-query tiles for plans whose scenes all have >= 4096 edges (debug option "flash_bq_big" 0: always 128)
     int flash_dma = 1;                       // half-row bf16 edge attention: K / V by LDS-direct loads, one tile ahead (0: register-staged, round 3; 3 | 4: rings of three / four tile buffers)
     int gate_fuse_agg = 1;                   // gate at the default head geometry, GCN_AGGR = max: aggregation fused into the gate kernel: 0 never, 1 the bf16 modes, 2 fp32 as well ("gate_fuse_agg")

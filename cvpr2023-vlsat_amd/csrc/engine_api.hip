@@ -64,7 +64,9 @@ int vlsat_debug_option(vlsat_handle h, const char* name, int32_t value) {
     else if (k == "flash_split") h->fa_split = value != 0;
     else if (k == "gemm_dma") h->gemm_no_dma = value == 0;
     else if (k == "gemm_p8") h->gemm_no_p8 = value == 0;
-    else if (k == "gemm_k_rot") h->gemm_k_rot = value < 0 ? 0 : value;
+    else if (k == "pair_twins") h->pair_twins = value != 0;
+    else if (k == "pair_max_edges") h->pair_max_edges = value < 0 ? 0 : value;
+    else if (k == "gemm_k_rot") h->gemm_k_rot = value < 0 ? -1 : value > 7 ? 7 : value;
     else if (k == "gate_row_map") h->gate_row_map = value != 0;
     else if (k == "prof_dual") h->prof_dual = value != 0;
     else if (k == "gate_heads_mfma") h->gate_heads_mfma = value < 0 ? 0 : value > 2 ? 2 : value;
@@ -78,7 +80,6 @@ int vlsat_debug_option(vlsat_handle h, const char* name, int32_t value) {
     else if (k == "gate_bf16") h->gate_bf16 = value != 0;
     else if (k == "flash_tr") h->flash_tr = value != 0;
     else if (k == "flash_bq_big") h->flash_bq_big = value != 0;
-    else if (k == "flash_asmv") h->flash_asmv = value != 0;
 #ifdef VLSAT_EXPERIMENTS
     else if (k == "gate_grid") h->gate_grid = value > 0 ? value : 0;
     else if (k == "gate_heads_bf16") h->gate_heads_bf16 = value != 0;

@@ -89,8 +89,9 @@ static void profile_close(vlsat_ctx* h, hipStream_t s) {
 // of the running plan) take prec_node, everything else (edge rows, point rows) prec_edge; the bf16 planes of the
 // weights were made when the mode was set (engine_weights.hip), so nothing is allocated or converted here.
 // prec_override >= 0: this launch's operand precision whatever the row class says (the edge attention's projections in mode 4)
-int gemm(vlsat_ctx* h, hipStream_t s, const GemmArgs& a0, int prec_override = -1) {
-    GemmArgs a = a0;
+// fills in what a launch of this handle needs besides the problem itself: operand precision and bf16 weight planes, debug switches,
+// the split-K workspace of lane `ws_lane`
+static int gemm_resolve(vlsat_ctx* h, int ws_lane, GemmArgs& a, int prec_override) {
     const bool edge_fmt = a.a_split || a.c_split || a.r_split;            // tensors in an edge format: an edge-row launch whatever M is
     const int prec = prec_override >= 0 ? prec_override : (a.M == h->cur_N && !edge_fmt) ? h->prec_node : h->prec_edge;
     if (prec) {
@@ -102,15 +103,37 @@ int gemm(vlsat_ctx* h, hipStream_t s, const GemmArgs& a0, int prec_override = -1
     }
     a.no_dma = h->gemm_no_dma;
     a.no_p8 = h->gemm_no_p8;
-    a.k_rot = h->gemm_k_rot;
+    a.k_rot = h->gemm_k_rot >= 0 ? h->gemm_k_rot : (a.prec == 1 && a.a_split == 2) ? 1 : 0;      // (round 6: +1 % per bf16_mixed step, nothing in the other modes)
     a.launches = &h->gemm_launches;
     if (h->gemm_splitk) {
-        const int w = prof_lane(h, s);             // (a split-K workspace per lane: launches of different lanes overlap)
-        a.sk_ws = h->sk_ws[w]; a.sk_ws_floats = SPLITK_WS_FLOATS;
-        a.sk_counters = h->sk_cnt[w]; a.sk_n_counters = SPLITK_COUNTERS;
+        a.sk_ws = h->sk_ws[ws_lane]; a.sk_ws_floats = SPLITK_WS_FLOATS;
+        a.sk_counters = h->sk_cnt[ws_lane]; a.sk_n_counters = SPLITK_COUNTERS;
     }
+    return 0;
+}
+int gemm(vlsat_ctx* h, hipStream_t s, const GemmArgs& a0, int prec_override = -1) {
+    GemmArgs a = a0;
+    RUN(gemm_resolve(h, prof_lane(h, s), a, prec_override));   // (a split-K workspace per lane: launches of different lanes overlap)
     Scope sc(h, s, PC_GEMM, gemm_flops(a));
     return launch_gemm(a, s);
+}
+// The 3D / 2D twins of a stage (same shape, same flags, different tensors and weights) on the caller's stream: ONE launch when the
+// problems are small enough for the single-round kernels (launch_gemm_pair), else one after the other -- the same kernels on the
+// same data either way, so the results do not depend on which it was.  The second problem takes lane 2's split-K workspace (the
+// paired schedule never runs the third lane).
+int gemm2(vlsat_ctx* h, hipStream_t s, const GemmArgs& a0, const GemmArgs& b0) {
+    GemmArgs a = a0, b = b0;
+    RUN(gemm_resolve(h, prof_lane(h, s), a, -1));
+    RUN(gemm_resolve(h, 2, b, -1));
+    {
+        Scope sc(h, s, PC_GEMM, gemm_flops(a) + gemm_flops(b));
+        const int r = launch_gemm_pair(a, b, s);
+        if (r <= 0) return r;
+    }
+    b.sk_ws = a.sk_ws; b.sk_counters = a.sk_counters;           // (one stream: the launches are ordered)
+    { Scope sc(h, s, PC_GEMM, gemm_flops(a)); RUN(launch_gemm(a, s)); }
+    Scope sc(h, s, PC_GEMM, gemm_flops(b));
+    return launch_gemm(b, s);
 }
 
 GemmArgs G(const float* A, int lda, const float* W, int K, float* C, int ldc, int M, int N, const float* bias,
@@ -259,6 +282,114 @@ int obj_head(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const float* x, const
     return 0;
 }
 
+// ---- the paired schedule of one-scene plans (round 6): gcn_3ds[l] and gcn_2ds[l], the two relation heads, the two object heads and
+// the two relation encoders as launches of TWO problems each (gemm2, twin gate / aggregate launches).  Stage by stage the same
+// kernels on the same operands as gcn_block / rel_head / obj_head above: bit-identical outputs.
+// Shipped gate kernels only (default head geometry, no probability tap); the caller checks.
+int gcn_block_pair(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const GcnW& w3, const GcnW& w2, float* x3, float* x2, float* e3, float* e2,
+                   int e3_relu_pending, int out_relu, const Scratch& sc3, const Scratch& sc2) {
+    const int N = (int)p->N, E = (int)p->E, D = h->D, A = h->A, LDX = ldx_of(h), NPC = npc_of(h);
+    const int S = split_fmt(h);
+    const bool gate16 = h->prec_edge && h->gate_bf16;
+    RUN(gemm2(h, s, G(x3, LDX, w3.wnode, D, sc3.NP, NPC, N, NPC, w3.bnode), G(x2, LDX, w2.wnode, D, sc2.NP, NPC, N, NPC, w2.bnode)));
+    auto e1_of = [&](const GcnW& w, float* e, int relu, const Scratch& sc) {
+        GemmArgs e1 = G(e, D, w.we1, D, sc.Hbig, 2 * D, E, 2 * D, nullptr, ACT_RELU);
+        e1.relu_a = relu;
+        e1.a_split = S; e1.c_split = S;
+        e1.g0 = sc.NP; e1.gi0 = p->d_src; e1.ldg0 = NPC;
+        e1.g1 = sc.NP + 2 * D; e1.gi1 = p->d_dst; e1.ldg1 = NPC;
+        return e1;
+    };
+    RUN(gemm2(h, s, e1_of(w3, e3, e3_relu_pending, sc3), e1_of(w2, e2, 0, sc2)));
+    if (h->d.use_gcn_edge) {
+        auto kp_of = [&](const GcnW& w, float* e, int relu, const Scratch& sc) {
+            GemmArgs kp = G(e, D, w.wpe, D, sc.KP, D, E, D, w.bpe);
+            kp.relu_a = relu;
+            kp.a_split = S;
+            kp.c_split = gate16 ? S : 0;
+            return kp;
+        };
+        RUN(gemm2(h, s, kp_of(w3, e3, e3_relu_pending, sc3), kp_of(w2, e2, 0, sc2)));
+    }
+    auto e2_of = [&](const GcnW& w, float* e, const Scratch& sc) {
+        GemmArgs g = G(sc.Hbig, 2 * D, w.we2, 2 * D, e, D, E, D, w.be2);
+        g.a_split = S; g.c_split = S;
+        return g;
+    };
+    RUN(gemm2(h, s, e2_of(w3, e3, sc3), e2_of(w2, e2, sc2)));
+    auto gate_of = [&](const GcnW& w, const Scratch& sc) {
+        GateArgs g{};
+        g.kproj = sc.KP; g.node = sc.NP; g.ld_node = NPC; g.gq_off = 4 * D; g.v_off = 6 * D;
+        g.src = p->d_src; g.dst = p->d_dst; g.w0k = w.w0k; g.w3 = w.w3; g.b3 = w.b3; g.gated = sc.G;
+        g.prob = nullptr; g.n_edges = E; g.use_edge = h->d.use_gcn_edge; g.grid_cap = h->gate_grid; g.row_map = h->gate_row_map;
+        return g;
+    };
+    GateArgs g3 = gate_of(w3, sc3), g2 = gate_of(w2, sc2);
+    const double dk = D / h->H, dox = A / h->H;
+    const bool fused_agg = (h->gate_fuse_agg == 2 || (h->gate_fuse_agg == 1 && gate16)) && h->d.gcn_aggr == 0 && h->gate_row_map && E > 0;
+    if (fused_agg) {
+        Scope scope(h, s, PC_AGGREGATE, 0);
+        RUN(launch_agg_init(p->d_rowptr, N, A, x3 + D, LDX, s, x2 + D));
+        g3.agg = x3 + D; g3.ld_agg = LDX;
+        g2.agg = x2 + D; g2.ld_agg = LDX;
+    }
+    {
+        Scope scope(h, s, PC_GATE, 2.0 * (double)E * h->H * (2.0 * dk * 2 * dk + 2.0 * 2 * dk * dox));
+        if (gate16) RUN(launch_edge_gate_bf16(g3, h->prec_edge == 3 ? 3 : 1, S, s, &g2));
+        else RUN(launch_edge_gate(g3, s, &g2));
+    }
+    if (!fused_agg) {
+        Scope scope(h, s, PC_AGGREGATE, 0);
+        RUN(launch_aggregate(sc3.G, A, p->d_rowptr, p->d_order, N, h->d.gcn_aggr, x3, LDX, D, s, sc2.G, x2));
+    }
+    RUN(gemm2(h, s, G(x3, LDX, w3.wp0, D + A, sc3.T768, D + A, N, D + A, w3.bp0, ACT_RELU), G(x2, LDX, w2.wp0, D + A, sc2.T768, D + A, N, D + A, w2.bp0, ACT_RELU)));
+    RUN(gemm2(h, s, G(sc3.T768, D + A, w3.wp2, D + A, x3, LDX, N, D, w3.bp2, out_relu ? ACT_RELU : ACT_NONE),
+              G(sc2.T768, D + A, w2.wp2, D + A, x2, LDX, N, D, w2.bp2, out_relu ? ACT_RELU : ACT_NONE)));
+    return 0;
+}
+
+int rel_head_pair(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const float* e3, int relu3, float* out3, const float* e2, float* out2,
+                  const Scratch& sc3, const Scratch& sc2) {
+    const int E = (int)p->E, D = h->D, R = h->d.n_rel_class;
+    const int S = split_fmt(h);
+    auto fc1 = [&](const RelHeadW& w, const float* e, int relu, const Scratch& sc) {
+        GemmArgs a = G(e, D, w.w1, D, sc.R1, 512, E, 512, w.b1, ACT_RELU);
+        a.relu_a = relu; a.a_split = S; a.c_split = S;
+        return a;
+    };
+    auto fc2 = [&](const RelHeadW& w, const Scratch& sc) {
+        GemmArgs b = G(sc.R1, 512, w.w2, 512, sc.R2, 256, E, 256, w.b2, ACT_RELU);
+        b.a_split = S; b.c_split = S;
+        return b;
+    };
+    auto fc3 = [&](const RelHeadW& w, const Scratch& sc, float* out) {
+        GemmArgs c = G(sc.R2, 256, w.w3, 256, out, R, E, R, w.b3, h->d.multi_rel_outputs ? ACT_SIGMOID : ACT_NONE);
+        c.a_split = S;
+        return c;
+    };
+    RUN(gemm2(h, s, fc1(h->rel3, e3, relu3, sc3), fc1(h->rel2, e2, 0, sc2)));
+    RUN(gemm2(h, s, fc2(h->rel3, sc3), fc2(h->rel2, sc2)));
+    RUN(gemm2(h, s, fc3(h->rel3, sc3, out3), fc3(h->rel2, sc2, out2)));
+    if (!h->d.multi_rel_outputs) {
+        Scope scope(h, s, PC_MISC, 0);
+        RUN(launch_softmax_rows(out3, R, E, R, out3, 1, s));
+        RUN(launch_softmax_rows(out2, R, E, R, out2, 1, s));
+    }
+    return 0;
+}
+
+int obj_head_pair(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, float* out3, float* out2, const Scratch& sc3, const Scratch& sc2) {
+    const int N = (int)p->N, D = h->D, C = h->d.n_obj_class;
+    {
+        Scope scope(h, s, PC_MISC, 0);
+        RUN(launch_row_invnorm(p->X3, ldx_of(h), N, D, std::exp(h->d.obj_logit_scale), sc3.rs, s, p->X2, sc2.rs));
+    }
+    GemmArgs a = G(p->X3, ldx_of(h), h->obj3_w, D, out3, C, N, C, h->obj3_b), b = G(p->X2, ldx_of(h), h->obj2_w, D, out2, C, N, C, h->obj2_b);
+    a.rowscale = sc3.rs;
+    b.rowscale = sc2.rs;
+    return gemm2(h, s, a, b);
+}
+
 int stn_encoder(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const StnW& w, const float* h1, int ldh, size_t R, int P,
                 const float* w2, const float* b2, const float* w3, const float* b3, int n_out, float** out_rows) {
     const size_t O = R / P;
@@ -367,10 +498,17 @@ static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const fl
     // another.  "sched" = 0: the fork / join schedule of round 4 (u = t; the lanes meet twice per layer).  The launches, their
     // operands and therefore the results are the same in both; not while stopping at a debug stage or for the training outputs.
     const bool dual = p->dual && do2d && (!h->prof || h->prof_dual) && stop < 0 && !tr;
+    // Paired schedule (round 6) for one-scene plans: a forward of a few thousand edges is ~114 launches of ~10 us that each leave most
+    // of the chip idle, and a loop with several scenes in flight is bound by the SUM of their durations.  The 3D / 2D twin stages
+    // (relation encoders, gcn_3ds | gcn_2ds, both head pairs) have the same shapes, so each pair becomes ONE launch of two problems
+    // on the caller's stream; the second lane keeps the only chain without a twin, the edge cross-attention of layer l, which runs
+    // under the node attentions of layer l + 1.  Same kernels on the same operands as the other schedules: bit-identical outputs.
+    const bool pair = dual && h->pair_twins && p->E > 0 && p->E <= h->pair_max_edges && !h->d.feature_transform && default_heads(h) &&
+                      !p->prob && !(h->gate_heads_mfma == 2 && !(h->prec_edge && h->gate_bf16)) && h->sched != 1;
     // (default: exact for the bf16 modes on plans that fill the chip by themselves.  One-scene plans keep two streams: with K replicas
     //  in flight on K host threads the third stream of every replica competes for the few hardware queues -- 551 vs 926-953 scenes/s at
     //  four in flight in bf16_mixed, profiles/r05_probes/val_loop_bf16_mixed_three_lanes.txt)
-    const bool exact = dual && (h->sched < 0 ? (h->prec_edge != 0 && p->E > 16384) : h->sched != 0);
+    const bool exact = dual && !pair && (h->sched < 0 ? (h->prec_edge != 0 && p->E > 16384) : h->sched != 0);
     hipStream_t t = s, u = s;
     size_t ev_i = 0;
     if (dual) {
@@ -412,11 +550,12 @@ static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const fl
         RUN(after(first, &e));
         return wait(then, e);
     };
-    auto fork = [&]() { return exact ? 0 : order(s, t); };               // (round-4 schedule only)
-    auto join = [&]() { return exact ? 0 : order(t, s); };
+    auto fork = [&]() { return (exact || pair) ? 0 : order(s, t); };     // (round-4 schedule only)
+    auto join = [&]() { return (exact || pair) ? 0 : order(t, s); };
     const Scratch sc3 = scratch_of(p, 0), sc2 = scratch_of(p, dual ? 1 : 0);
     const int S = split_fmt(h);            // edge tensors in the split-pair format (bf16 modes)
     if (exact) RUN(order(s, u));           // u starts where the forward starts (behind whatever the caller enqueued before it)
+    if (pair) RUN(order(s, t));            // (paired schedule: so does t -- the adapter, then the edge cross-attention of every layer)
 
     const bool ft = h->d.feature_transform != 0;
     if (!ft) {   // a-2 object encoder
@@ -456,9 +595,18 @@ static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const fl
         RUN(launch_edge_embed(desc, p->d_src, p->d_dst, E, h->re_w1cat, h->re_b1cat, p->H1, s));
     }
     hipEvent_t h1_ready = nullptr;
-    RUN(after(s, &h1_ready));
-    RUN(wait(t, h1_ready));                                                 // t: 2D relation encoder (old schedule: + adapter)
-    if (!ft) {
+    if (!pair) {
+        RUN(after(s, &h1_ready));
+        RUN(wait(t, h1_ready));                                             // t: 2D relation encoder (old schedule: + adapter)
+    }
+    if (pair) {                                                             // conv2 / conv3 of both relation encoders, two problems per launch
+        GemmArgs c2a = G(p->H1, 128, h->re3_w2, 64, sc3.H2, 128, E, 128, h->re3_b2, ACT_RELU), c2b = G(p->H1 + 64, 128, h->re2_w2, 64, sc2.H2, 128, E, 128, h->re2_b2, ACT_RELU);
+        c2a.c_split = S; c2b.c_split = S;
+        RUN(gemm2(h, s, c2a, c2b));
+        GemmArgs c3a = G(sc3.H2, 128, h->re3_w3, 128, p->E3, D, E, D, h->re3_b3, ACT_RELU), c3b = G(sc2.H2, 128, h->re2_w3, 128, p->E2, D, E, D, h->re2_b3, ACT_RELU);
+        c3a.a_split = S; c3a.c_split = S; c3b.a_split = S; c3b.c_split = S;
+        RUN(gemm2(h, s, c3a, c3b));
+    } else if (!ft) {
         for (int br = 0; br < (do2d ? 2 : 1); ++br) {          // conv2 / conv3 of rel_encoder_3d (on s) and rel_encoder_2d (on t)
             const Scratch& sc = br ? sc2 : sc3;
             GemmArgs c2 = G(p->H1 + 64 * br, 128, br ? h->re2_w2 : h->re3_w2, 64, sc.H2, 128, E, 128, br ? h->re2_b2 : h->re3_b2, ACT_RELU);
@@ -487,7 +635,7 @@ static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const fl
         RUN(gemm(h, u, a));
         if (tr && tr->mimic2d)             // the adapter's output before the MMG touches it (:312)
             RUN(launch_copy_rows(tr->mimic2d, 512, p->X2, (size_t)LDX, 512, (size_t)N, u));
-        if (exact) RUN(after(u, &x2_ready));
+        if (exact || pair) RUN(after(u, &x2_ready));
     }
     STAGE(4);
     {   // a-7 distance bias
@@ -497,6 +645,7 @@ static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const fl
     STAGE(5);
     int e3_pending_relu = 0;
     hipEvent_t flash_done[2] = {nullptr, nullptr};            // the edge attention that read KVe slot i has completed
+    hipEvent_t edge_done = nullptr;                           // (paired schedule) the edge cross-attention of the previous layer has written E2 and is done with E3
     for (int l = 0; l < L; ++l) {
         const int inter = (l < L - 1 || L == 1) ? 1 : 0;     // reference network_MMG.py:236
         const int base = 10 + 10 * l;
@@ -514,6 +663,7 @@ static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const fl
                 RUN(wait(u, x2_ready));
             } else {
                 RUN(join());                                  // X2 / E2 of the previous stage are complete
+                if (pair && l == 0) RUN(wait(s, x2_ready));   // (the adapter ran on t)
             }
             RUN(attn_block(h, p, exact ? u : s, h->cross_attn[l], p->X2, false, p->Q2n, kvx, p->On2));
             if (exact) {                                      // node side of gcn_2ds[l] on the same lane, then the edge lane may go on
@@ -522,6 +672,11 @@ static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const fl
             }
         }
         STAGE(base + 1);
+        if (pair) {                                           // :224-225 as launches of two problems each, behind the previous layer's edge attention
+            RUN(wait(s, edge_done));
+            RUN(gcn_block_pair(h, p, s, h->gcn3[l], h->gcn2[l], p->X3, p->X2, p->E3, p->E2, e3_pending_relu, inter, sc3, sc2));
+            RUN(order(s, t));                                 // t: this layer's edge cross-attention; s goes on with the next layer's node attentions
+        } else {
         RUN(fork());                                          // t: gcn_2ds + query projection; s: gcn_3ds + key/value projection
         RUN(gcn_block(h, p, s, h->gcn3[l], p->X3, p->E3, e3_pending_relu, inter, sc3)); // :224
         STAGE(base + 2);
@@ -529,6 +684,7 @@ static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const fl
             RUN(wait(t, np2_ready));
             RUN(gcn_block(h, p, t, h->gcn2[l], p->X2, p->E2, 0, inter, sc2, exact));      // :225
             if (exact) RUN(after(t, &x2_ready));
+        }
         }
         STAGE(base + 3);
         if (do2d) {   // :231 edge cross-attention: q = 2D edges, k = v = 3D edges (pre-activation)
@@ -547,16 +703,18 @@ static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const fl
             // that reads them: it waits for the reader of the slot's previous content only)
             const int slot = exact ? (l & 1) : 0;
             float* kve = slot ? p->KVe2 : p->KVe;
-            hipStream_t fs = exact ? t : s;                   // lane of the attention itself
+            hipStream_t fs = (exact || pair) ? t : s;         // lane of the attention itself
+            hipStream_t kvs = pair ? t : s;                   // ... and of its key | value projection (paired schedule: the whole chain on t)
             GemmArgs gq = G(p->E2, D, w.wq, D, p->Qe, D, E, D, w.bq);
             gq.a_split = S; gq.c_split = SA;
             if (SA) gq.c_scale = sc2e;                                 // the split-format attention takes Q pre-scaled
             RUN(gemm(h, t, gq, PA));
-            RUN(wait(s, flash_done[slot]));
+            if (!pair) RUN(wait(s, flash_done[slot]));
             GemmArgs gkv = G(p->E3, D, w.wkv, D, kve, 2 * D, E, 2 * D, w.bkv);
             gkv.a_split = S; gkv.c_split = SA;
-            RUN(gemm(h, s, gkv, PA));
-            if (exact) {
+            RUN(gemm(h, kvs, gkv, PA));
+            if (pair) {
+            } else if (exact) {
                 hipEvent_t kve_ready;
                 RUN(after(s, &kve_ready));
                 RUN(wait(t, kve_ready));
@@ -567,7 +725,6 @@ static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const fl
                 Scope sc(h, fs, PC_FLASH, p->flash_flops);
                 FlashSplit sp;
                 sp.ablate = h->flash_ablate;
-                sp.asmv = h->flash_asmv;
                 sp.parts = p->fa_parts; sp.krange = p->d_krange; sp.o_part = p->fa_opart; sp.m_part = p->fa_m;
                 sp.l_part = p->fa_l; sp.part_stride = (size_t)E * D; sp.rows = E; sp.heads = h->H;
                 if (dh != 32 && dh != 64 && dh != 128)   // any other head dim: VALU attention over the scenes' edge ranges (no bias)
@@ -595,8 +752,11 @@ static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const fl
             if (!ln_resid) { o.resid = p->E2; o.ldr = D; o.r_split = S; }
             o.a_split = SA;
             RUN(gemm(h, fs, o, PA));
-            Scope sc(h, fs, PC_LAYERNORM, 0);
-            RUN(launch_layernorm_to(pre_ln, D, p->E2, D, E, D, w.lng, w.lnb, inter, S, fs, ln_resid ? p->E2 : nullptr, D, S));
+            {
+                Scope sc(h, fs, PC_LAYERNORM, 0);
+                RUN(launch_layernorm_to(pre_ln, D, p->E2, D, E, D, w.lng, w.lnb, inter, S, fs, ln_resid ? p->E2 : nullptr, D, S));
+            }
+            if (pair) RUN(after(t, &edge_done));
         }
         e3_pending_relu = inter;
         STAGE(base + 4);
@@ -617,6 +777,11 @@ static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const fl
         RUN(gemm(h, s, e2));
     }
     // a-15 relation heads, a-16 object heads
+    if (pair) {                                               // both head pairs as launches of two problems each, behind the last edge attention
+        RUN(wait(s, edge_done));
+        RUN(rel_head_pair(h, p, s, p->E3, e3_pending_relu, rel3d, p->E2, rel2d, sc3, sc2));
+        RUN(obj_head_pair(h, p, s, obj3d, obj2d, sc3, sc2));
+    } else {
     RUN(fork());                                              // t: the 2D heads
     if (E > 0) {
         RUN(rel_head(h, p, s, h->rel3, p->E3, e3_pending_relu, rel3d, sc3));
@@ -626,6 +791,7 @@ static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const fl
     if (do2d) {
         RUN(wait(u, x2_ready));
         RUN(obj_head(h, p, u, p->X2, h->obj2_w, h->obj2_b, obj2d, sc2));
+    }
     }
     if (dual) {                                               // every lane ends joined into the caller's stream
         profile_close(h, t);

@@ -128,11 +128,13 @@ __device__ __forceinline__ void planes_of(const f32x4& x, bf16x4& hi, bf16x4& lo
 // whose last, partly filled query tile is a negligible share: round 5, +4 % at cfg 5)
 // ABL (experiments build only, compile-time so that the shipped code generation is what gets timed; results are GARBAGE): 4 no exponentials,
 // 8 no maximum, 16 no cross-half exchanges, 32 no P.V MFMAs, 64 no Q.K MFMAs, 256 no barrier per tile
-// ASMV (round 6; LDS-direct kernel at head dim 64 with compile-time buffer slots): the V fragments by INLINE-ASM transpose reads with a
-// hand-written lgkmcnt wait.  Through the builtin (no alias information) hipcc drains vmcnt in front of the first transpose read of
-// an iteration, i.e. every wave waits for the NEXT tile's LDS-direct loads where its P.V product starts; the asm reads are invisible
-// to that bookkeeping, so the look-ahead covers the whole iteration.
-template <int TERMS, bool TR, int IO, int PVT = 3, int FB_D = 64, int RING = 0, int BQW = 4, int ABL = 0, bool ASMV = false>
+// (round 6, measured and dropped: the V fragments by inline-asm ds_read_b64_tr_b16 with hand-counted lgkmcnt waits, two register sets a
+//  16-key chunk apart -- through the builtin, which carries no alias information, hipcc drains vmcnt in front of the first transpose read
+//  of an iteration, i.e. a wave waits for the NEXT tile's LDS-direct loads where its P.V product starts.  Bit-identical, 120 VGPRs, still
+//  four blocks per CU, no vmcnt wait left inside the iteration: 9844-9894 vs 9822-9870 scenes/s in the cfg 3 step (+0.2 %), 80.4-81.0 vs
+//  80.7-81.7 at cfg 5 (-0.7...-1.2 %): with K / V resident in L2 the loads have landed by then, and the fixed read order costs more than
+//  the compiler's.  profiles/r06_probes/krot_asmv_step_ab.txt)
+template <int TERMS, bool TR, int IO, int PVT = 3, int FB_D = 64, int RING = 0, int BQW = 4, int ABL = 0>
 __global__ __launch_bounds__(64 * BQW, 2) void flash_attn_bf16_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
     float* __restrict__ O, int ldq, int ldkv, int ldo, const int4* __restrict__ tiles, int n_tiles,
@@ -292,9 +294,6 @@ __global__ __launch_bounds__(64 * BQW, 2) void flash_attn_bf16_kernel(
     // One key tile.  SLOT: the tile's LDS buffer as a compile-time constant where the loop below can provide it (two-buffer
     // configurations: the loop is unrolled by two, so every LDS address of the iteration is lane constant + immediate -- the
     // run-time slot cost ~40 VALU address instructions per tile in a kernel that is VALU-bound, round 5), else -1 = `ring`.
-    static_assert(!ASMV || (RING == 2 && FB_D == 64 && TERMS == 1 && TR), "asm V reads: the two-buffer LDS-direct kernel at head dim 64");
-    const unsigned lds0 = (unsigned)(uintptr_t)((char __attribute__((address_space(3)))*)smem);
-    const unsigned vlane = lds0 + (unsigned)(KBYTES + ((lane >> 4) & 1) * FB_VSUB + (4 * hi + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8);
     int ring = 0;                                          // (DMA) buffer of tile kt
     auto tile_step = [&](int kt, auto slotc) __attribute__((always_inline)) {
         constexpr int SLOT = decltype(slotc)::value;
@@ -399,43 +398,6 @@ __global__ __launch_bounds__(64 * BQW, 2) void flash_attn_bf16_kernel(
                     for (int r = 0; r < 16; ++r) o[b][r] *= alpha;
             }
             // ---- O^T[d][query] += sum_key V[key][d] * P[key][query] ----
-            if constexpr (ASMV && SLOT >= 0) {
-                // (macro, not a loop: the ds offsets are immediates; operands are locals -- hipcc rejects asm operands that name
-                //  captured variables inside a generic lambda)
-                const unsigned vl = vlane;
-                constexpr int OFF = SLOT * BUF;
-                static_assert(OFF + 3 * 512 + 2 * FB_VSUB + 256 < 65536, "ds offset field");
-                // two register sets: the reads of chunk J + 2 are issued behind the MFMAs of chunk J, the wait in front of chunk J lets the
-                // four reads of chunk J + 1 stay in flight
-                s16x4 xa0, xa1, xa2, xa3, xb0, xb1, xb2, xb3;
-#define FB_V_READ(J, S)                                                                                                                    \
-                asm volatile("ds_read_b64_tr_b16 %0, %4 offset:%5\n\tds_read_b64_tr_b16 %1, %4 offset:%6\n\t"                              \
-                             "ds_read_b64_tr_b16 %2, %4 offset:%7\n\tds_read_b64_tr_b16 %3, %4 offset:%8"                                  \
-                             : "=&v"(x##S##0), "=&v"(x##S##1), "=&v"(x##S##2), "=&v"(x##S##3)                                              \
-                             : "v"(vl), "n"(OFF + (J) * 512), "n"(OFF + (J) * 512 + 256), "n"(OFF + (J) * 512 + 2 * FB_VSUB),              \
-                               "n"(OFF + (J) * 512 + 2 * FB_VSUB + 256))
-#define FB_PV_USE(J, S, N)                                                                                                                 \
-                {                                                                                                                          \
-                    f32x4 p0, p1;                                                                                                          \
-                    for (int c = 0; c < 4; ++c) { p0[c] = s[(J) >> 1][8 * ((J) & 1) + c]; p1[c] = s[(J) >> 1][8 * ((J) & 1) + 4 + c]; }    \
-                    const bf16x8 ph = __builtin_shufflevector(__builtin_convertvector(p0, bf16x4), __builtin_convertvector(p1, bf16x4), 0, 1, 2, 3, 4, 5, 6, 7); \
-                    asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(x##S##0), "+v"(x##S##1), "+v"(x##S##2), "+v"(x##S##3));                 \
-                    const bf16x8 v0 = __builtin_shufflevector(__builtin_bit_cast(bf16x4, x##S##0), __builtin_bit_cast(bf16x4, x##S##1), 0, 1, 2, 3, 4, 5, 6, 7); \
-                    const bf16x8 v1 = __builtin_shufflevector(__builtin_bit_cast(bf16x4, x##S##2), __builtin_bit_cast(bf16x4, x##S##3), 0, 1, 2, 3, 4, 5, 6, 7); \
-                    o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, ph, o[0], 0, 0, 0);                                                 \
-                    o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, ph, o[1], 0, 0, 0);                                                 \
-                }
-                FB_V_READ(0, a);
-                FB_V_READ(1, b);
-                FB_PV_USE(0, a, 4)
-                FB_V_READ(2, a);
-                FB_PV_USE(1, b, 4)
-                FB_V_READ(3, b);
-                FB_PV_USE(2, a, 4)
-                FB_PV_USE(3, b, 0)
-#undef FB_V_READ
-#undef FB_PV_USE
-            } else
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int kb = j >> 1, half = j & 1;
@@ -573,7 +535,7 @@ int launch_flash_attn_bf16(const float* Q, int ldq, const float* K, const float*
         if (!sp.krange || !sp.o_part || !sp.m_part || !sp.l_part || sp.heads * FB_D > ldo)
             return fail(-1, "flash_attn: incomplete split-key workspace");
     }
-    if (split) { sp.ablate = split->ablate; sp.bq = split->bq; sp.rows = split->rows; sp.asmv = split->asmv; }
+    if (split) { sp.ablate = split->ablate; sp.bq = split->bq; sp.rows = split->rows; }
     if (sp.bq != FLASH_BQ && !(sp.bq == FLASH_BQ_BIG && FB_D == 64 && io_split == 2 && use_tr == 1 && sp.parts <= 1 && sp.rows > 0 &&
                                (size_t)sp.rows * (size_t)ldkv * 4 < (1ull << 32)))
         return fail(-1, "flash_attn_bf16: 256-query tiles are built for half rows, head dim 64, the LDS-direct kernel, no key split");
@@ -612,12 +574,8 @@ int launch_flash_attn_bf16(const float* Q, int ldq, const float* K, const float*
         VLSAT_FA_ABL(4) VLSAT_FA_ABL(8) VLSAT_FA_ABL(16) VLSAT_FA_ABL(28) VLSAT_FA_ABL(32) VLSAT_FA_ABL(64) VLSAT_FA_ABL(96) VLSAT_FA_ABL(256) VLSAT_FA_ABL(124) VLSAT_FA_ABL(380)
 #undef VLSAT_FA_ABL
 #endif
-        else if (use_tr != 2 && sp.bq == FLASH_BQ_BIG && sp.asmv)
-            hipLaunchKernelGGL((flash_attn_bf16_kernel<1, true, 2, 3, 64, 2, 8, 0, true>), dim3(n_tiles), dim3(512), 0, s, Q, K, V, O, ldq, ldkv, ldo, tiles, n_tiles, scale_log2e, sp);
         else if (use_tr != 2 && sp.bq == FLASH_BQ_BIG)
             hipLaunchKernelGGL((flash_attn_bf16_kernel<1, true, 2, 3, 64, 2, 8>), dim3(n_tiles), dim3(512), 0, s, Q, K, V, O, ldq, ldkv, ldo, tiles, n_tiles, scale_log2e, sp);
-        else if (use_tr != 2 && sp.asmv)
-            hipLaunchKernelGGL((flash_attn_bf16_kernel<1, true, 2, 3, 64, 2, 4, 0, true>), dim3(n_tiles), dim3(256), 0, s, Q, K, V, O, ldq, ldkv, ldo, tiles, n_tiles, scale_log2e, sp);
         else if (use_tr != 2)       // (use_tr = 2: the register-staged kernel of round 3, for A/B -- "flash_dma" 0)
             hipLaunchKernelGGL((flash_attn_bf16_kernel<1, true, 2, 3, 64, 2>), dim3(n_tiles), dim3(256), 0, s, Q, K, V, O, ldq, ldkv, ldo, tiles, n_tiles, scale_log2e, sp);
         else

@@ -43,8 +43,10 @@ namespace vlsat {
 // PREC: 0 = exact fp32 (PipeF32), 1 / 3 = bf16 / split-bf16 operands (PipeBF16, gemm_core.h).
 // KSL: k-slices (of 32) moved per pipeline step.  2 for small single-round problems, which are bound
 //      by the global-load round trip per step, not by MFMA issue: half the steps, twice the bytes in flight.
-template <int BM, int BN, int ADD, int PREC, int KSL>
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p, int n_tiles, int nbn) {
+// TWIN: two problems of one shape in one launch, selected by blockIdx.y (see gemm_splitk.hip; single-round 64 x 64 launches only).
+template <int BM, int BN, int ADD, int PREC, int KSL, bool TWIN = false>
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs pa, GemmArgs pb, int n_tiles, int nbn) {
+    const GemmArgs& p = (TWIN && blockIdx.y != 0) ? pb : pa;
     constexpr int TM = BM / 64, TN = BN / 64;
     using Pipe = typename PipeSel<BM, BN, PREC>::type;
     constexpr int SLICE = Pipe::STAGE_BYTES;
@@ -179,7 +181,7 @@ static int launch_t(const GemmArgs& a, int n_tiles, int grid, hipStream_t s) {
     const int nbn = (a.N + BN - 1) / BN;
     const int add = (a.resid ? 1 : 0) | (a.g0 ? 2 : 0) | (a.g1 ? 4 : 0);
 #define VLSAT_GEMM_CASE(ADD, PREC) \
-    case (PREC) * 8 + (ADD): hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, ADD, PREC, KSL>), dim3(grid), dim3(256), 0, s, a, n_tiles, nbn); break;
+    case (PREC) * 8 + (ADD): hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, ADD, PREC, KSL>), dim3(grid), dim3(256), 0, s, a, a, n_tiles, nbn); break;
     // exact fp32 launches without ReLU-on-A take the LDS-direct staging pipe (internal precision code 4) when
     // the operands are addressable with 32-bit byte offsets and the additive mode is one the forward uses
     int prec = a.prec;
@@ -245,8 +247,78 @@ static int run_tiled(const GemmArgs& a, hipStream_t s, int slot_mult2 = 2) {
     return launch_gemm(tail_of(a, (int)(main_panels * BM)), s);   // strictly fewer rows: terminates
 }
 
+static bool g_clock_probe_on();
+// ---- two problems, one launch (one-scene plans, round 6) ----
+static bool twin_shapes(const GemmArgs& a, const GemmArgs& b) {
+    return a.M == b.M && a.N == b.N && a.K == b.K && a.lda == b.lda && a.ldw == b.ldw && a.ldc == b.ldc && a.ldr == b.ldr &&
+           a.ldg0 == b.ldg0 && a.ldg1 == b.ldg1 && a.act == b.act && a.prec == b.prec && a.a_split == b.a_split && a.r_split == b.r_split &&
+           a.c_split == b.c_split && a.c_scale == b.c_scale && a.resid_scale == b.resid_scale && !a.bias == !b.bias && !a.resid == !b.resid &&
+           !a.g0 == !b.g0 && !a.g1 == !b.g1 && !a.rowscale == !b.rowscale && a.no_dma == b.no_dma && a.no_ring == b.no_ring &&
+           a.no_p8 == b.no_p8 && a.k_rot == b.k_rot && !a.force_tile && !b.force_tile && !a.ablate && !b.ablate && a.prefetch == b.prefetch;
+}
+// single round of 64 x 64 tiles, two k-slices per step (what run_tiled<64, 64> launches for T <= G), grid.y = 2
+static int launch_t_twin(const GemmArgs& a, const GemmArgs& b, int n_tiles, int grid, hipStream_t s) {
+    const int nbn = (a.N + 63) / 64;
+    const int add = (a.resid ? 1 : 0) | (a.g0 ? 2 : 0) | (a.g1 ? 4 : 0);
+#define VLSAT_GEMM_CASE(ADD, PREC) \
+    case (PREC) * 8 + (ADD): hipLaunchKernelGGL((gemm_f32_kernel<64, 64, ADD, PREC, 2, true>), dim3(grid, 2), dim3(256), 0, s, a, b, n_tiles, nbn); break;
+    int prec = a.prec;
+    const bool dma_ok = !a.no_dma && (add == 0 || add == 1 || add == 6) &&
+                        ((size_t)a.M + 256) * a.lda * 4 < (1ull << 32) && ((size_t)a.N + 256) * a.ldw * 4 < (1ull << 32);
+    if (prec == 0 && (a.a_split || a.r_split || a.c_split || a.c_scale != 1.f)) return 1;
+    if (prec == 0 && dma_ok && !(a.relu_a || b.relu_a)) prec = 4;     // (ReLU-on-A of either problem: the VGPR-staged pipe for both -- same products)
+    if (a.a_split == 2 && !(prec == 1 && dma_ok)) return 1;
+    if ((prec == 1 || prec == 3) && dma_ok) prec += a.a_split == 2 ? 12 : a.a_split ? 8 : 4;
+    else if (a.a_split) return 1;
+    switch (prec * 8 + add) {
+        VLSAT_GEMM_CASE(0, 13) VLSAT_GEMM_CASE(1, 13) VLSAT_GEMM_CASE(6, 13)
+        VLSAT_GEMM_CASE(0, 9) VLSAT_GEMM_CASE(1, 9) VLSAT_GEMM_CASE(6, 9)
+        VLSAT_GEMM_CASE(0, 11) VLSAT_GEMM_CASE(1, 11) VLSAT_GEMM_CASE(6, 11)
+        VLSAT_GEMM_CASE(0, 4) VLSAT_GEMM_CASE(1, 4) VLSAT_GEMM_CASE(6, 4)
+        VLSAT_GEMM_CASE(0, 5) VLSAT_GEMM_CASE(1, 5) VLSAT_GEMM_CASE(6, 5)
+        VLSAT_GEMM_CASE(0, 7) VLSAT_GEMM_CASE(1, 7) VLSAT_GEMM_CASE(6, 7)
+        VLSAT_GEMM_CASE(0, 0) VLSAT_GEMM_CASE(1, 0) VLSAT_GEMM_CASE(6, 0)
+        default: return 1;
+    }
+#undef VLSAT_GEMM_CASE
+    if (a.launches) ++*a.launches;
+    VLSAT_LAUNCH_CHECK("gemm_f32 (pair)");
+    return 0;
+}
+
+int launch_gemm_pair(const GemmArgs& a, const GemmArgs& b, hipStream_t s) {
+    // anything launch_gemm would refuse or treat specially stays with launch_gemm (the caller falls back to two launches)
+    if (!a.A || !a.W || !a.C || !b.A || !b.W || !b.C || a.M <= 0 || a.N <= 0 || a.K <= 0 || a.K % BK || !twin_shapes(a, b)) return 1;
+    if ((a.lda & 3) || (a.ldw & 3) || (a.prec != 0 && a.prec != 1 && a.prec != 3)) return 1;
+    if (a.prec && (!a.Whi || !b.Whi || (a.prec == 3 && (!a.Wlo || !b.Wlo)) || (a.ldw & 7))) return 1;
+    if (a.rowscale && (a.resid || a.g0 || a.g1)) return 1;
+    for (const GemmArgs* q : {&a, &b})
+        if ((reinterpret_cast<uintptr_t>(q->A) & 15) || (reinterpret_cast<uintptr_t>(q->W) & 15)) return 1;
+    if (g_clock_probe_on()) return 1;
+    const int G = slots();
+    if (a.sk_ws && b.sk_ws) {
+        const int r = launch_gemm_splitk(a, G, s, &b);
+        if (r <= 0) return r;
+    }
+    // Mirror of launch_gemm's cascade for a problem this small: only the case that ends in ONE round of 64 x 64 tiles with two
+    // k-slices per step is paired; everything else (8-phase partial rounds, ring kernel, wider tiles, several rounds) is not.
+    const long T = (long)((a.M + 63) / 64) * ((a.N + 63) / 64);
+    if (T > G || a.K % (2 * BK)) return 1;
+    if (a.N % 256 == 0 && a.K % 128 == 0 && !a.no_dma && !a.no_ring && !a.no_p8 && !a.rowscale) {           // 8-phase partial round?
+        const bool p8_fmt = (a.prec == 1 && a.a_split == 2) || (a.prec == 3 && a.a_split == 1) || (a.prec == 0 && !a.a_split && !a.c_split && !a.r_split);
+        const long panels = (a.M + 255) / 256, nbn = a.N / 256, part_min = a.prec == 1 ? 32 : (G / 2 * 5) / 8;
+        if (p8_fmt && panels * nbn >= part_min) return 1;
+    }
+    if ((a.prec == 1 || a.prec == 3) && !a.no_dma && !a.no_ring && a.N > 64 && !a.rowscale && (long)((a.M + 255) / 256) * ((a.N + 127) / 128) >= G / 2) return 1;   // ring kernel
+    auto blocks = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
+    if (a.prec == 3 && !a.a_split && a.N >= 1024 && a.N <= 2048 && blocks(64, 128) <= G && blocks(64, 128) >= G / 2) return 1;
+    if ((a.N > 64 && blocks(128, 128) >= G) || (a.N <= 64 && blocks(128, 64) >= G) || (a.N > 64 && blocks(64, 128) >= G)) return 1;
+    return launch_t_twin(a, b, (int)T, (int)((T + 7) / 8) * 8, s);
+}
+
 static long long* g_clock_probe = nullptr;       // debug only (vlsat_debug_gemm_clock_probe): process-wide on purpose
 void gemm_set_clock_probe(long long* buf) { g_clock_probe = buf; }
+static bool g_clock_probe_on() { return g_clock_probe != nullptr; }
 
 int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
     GemmArgs a = a_in;

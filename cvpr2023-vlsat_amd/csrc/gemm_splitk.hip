@@ -21,9 +21,18 @@ namespace {
 
 constexpr int SK_MAXS = 4;                   // k-slices (of 32) a block holds in LDS at once
 
-template <int PREC>
-__global__ __launch_bounds__(256, 2) void gemm_splitk_kernel(GemmArgs p, int n_tiles, int nbn, int ks, int slices, float* __restrict__ ws,
-                                                             unsigned* __restrict__ counters) {
+// TWIN (round 6, one-scene plans): ONE launch for two problems of the same shape, flags and launch geometry -- the 3D / 2D twins of a
+// GraphEdgeAttenNetwork block, of the relation encoders and of the heads -- selected by blockIdx.y, each with its own workspace
+// and counters.  Every block runs exactly the code of the single launch on its own problem: the results are bit-identical to two
+// launches; what goes away is one kernel's worth of start-up, drain and queue time per pair (a one-scene forward is ~114 such
+// launches of ~10 us each, and a loop with several scenes in flight is bound by the SUM of their durations).
+template <int PREC, bool TWIN = false>
+__global__ __launch_bounds__(256, 2) void gemm_splitk_kernel(GemmArgs pa, GemmArgs pb, int n_tiles, int nbn, int ks, int slices, float* __restrict__ wsa,
+                                                             unsigned* __restrict__ cnta, float* __restrict__ wsb, unsigned* __restrict__ cntb) {
+    const bool second = TWIN && blockIdx.y != 0;
+    const GemmArgs& p = second ? pb : pa;
+    float* __restrict__ ws = second ? wsb : wsa;
+    unsigned* __restrict__ counters = second ? cntb : cnta;
     using Pipe = typename PipeSel<64, 64, PREC>::type;
     constexpr int SLICE = Pipe::STAGE_BYTES;
     __shared__ __attribute__((aligned(16))) char smem[SK_MAXS * SLICE];
@@ -101,8 +110,11 @@ __global__ __launch_bounds__(256, 2) void gemm_splitk_kernel(GemmArgs p, int n_t
 
 // Decides whether the launch is one of the small ones this kernel is for and, if so, runs it.  Returns 0 = launched,
 // 1 = not applicable (the caller falls through to the persistent kernel), < 0 = error.
-int launch_gemm_splitk(const GemmArgs& a, int slots, hipStream_t s) {
+// twin: a second problem of the same shape and flags (gemm_f32.hip launch_gemm_pair has checked that) for the same launch; every
+// decision below is taken from `a` exactly as for a single launch, so each problem is computed as it would be alone.
+int launch_gemm_splitk(const GemmArgs& a, int slots, hipStream_t s, const GemmArgs* twin) {
     if (!a.sk_ws || !a.sk_counters) return 1;
+    if (twin && (!twin->sk_ws || !twin->sk_counters || twin->sk_ws == a.sk_ws || twin->sk_counters == a.sk_counters)) return 1;
     const long nbm = (a.M + 63) / 64, nbn = (a.N + 63) / 64, T = nbm * nbn;
     const int total = a.K / BK;                                      // k-slices
     if (total < 4 || T > slots / 2) return 1;                        // at least two parts of >= 2 slices, and room for them
@@ -113,15 +125,21 @@ int launch_gemm_splitk(const GemmArgs& a, int slots, hipStream_t s) {
     const int slices = (total + ks - 1) / ks;
     ks = (total + slices - 1) / slices;                              // no empty parts
     if ((size_t)T * ks * 4096 > a.sk_ws_floats || (size_t)T > a.sk_n_counters) return 1;
+    if (twin && ((size_t)T * ks * 4096 > twin->sk_ws_floats || (size_t)T > twin->sk_n_counters)) return 1;
     int prec = a.prec;
+    const bool relu_a = a.relu_a || (twin && twin->relu_a);          // (a pair takes the staging pipe that can apply ReLU to A if either needs it: same products)
     const bool dma_ok = !a.no_dma && ((size_t)a.M + 256) * a.lda * 4 < (1ull << 32) && ((size_t)a.N + 256) * a.ldw * 4 < (1ull << 32);
-    if (prec == 0 && dma_ok && !a.relu_a) prec = 4;
+    if (prec == 0 && dma_ok && !relu_a) prec = 4;
     if (a.a_split == 2 && !(prec == 1 && dma_ok)) return 1;
     if ((prec == 1 || prec == 3) && dma_ok) prec += a.a_split == 2 ? 12 : a.a_split ? 8 : 4;
     else if (a.a_split) return 1;
     const int grid = (int)((T + 7) / 8) * 8 * ks;
+    const GemmArgs& b = twin ? *twin : a;
 #define VLSAT_SK_CASE(PREC) \
-    case PREC: hipLaunchKernelGGL((gemm_splitk_kernel<PREC>), dim3(grid), dim3(256), 0, s, a, (int)T, (int)nbn, ks, slices, a.sk_ws, a.sk_counters); break;
+    case PREC: \
+        if (twin) hipLaunchKernelGGL((gemm_splitk_kernel<PREC, true>), dim3(grid, 2), dim3(256), 0, s, a, b, (int)T, (int)nbn, ks, slices, a.sk_ws, a.sk_counters, b.sk_ws, b.sk_counters); \
+        else hipLaunchKernelGGL((gemm_splitk_kernel<PREC, false>), dim3(grid), dim3(256), 0, s, a, a, (int)T, (int)nbn, ks, slices, a.sk_ws, a.sk_counters, a.sk_ws, a.sk_counters); \
+        break;
     switch (prec) {
         VLSAT_SK_CASE(0) VLSAT_SK_CASE(1) VLSAT_SK_CASE(3) VLSAT_SK_CASE(4) VLSAT_SK_CASE(5) VLSAT_SK_CASE(7)
         VLSAT_SK_CASE(9) VLSAT_SK_CASE(11) VLSAT_SK_CASE(13)

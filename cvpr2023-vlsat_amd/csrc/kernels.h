@@ -48,7 +48,11 @@ struct GemmArgs {
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
 // small launches: k range cut over several CUs, deterministic in-kernel reduction; 1 = not applicable, 0 = launched
-int launch_gemm_splitk(const GemmArgs& a, int slots, hipStream_t s);
+int launch_gemm_splitk(const GemmArgs& a, int slots, hipStream_t s, const GemmArgs* twin = nullptr);
+// two problems of the same shape and flags in ONE launch (round 6: the 3D / 2D twins of a one-scene forward): 0 = launched,
+// 1 = not pairable (different shapes / flags, or a launch the single-round small-tile kernels would not take): the caller
+// launches them one after the other; results are bit-identical either way
+int launch_gemm_pair(const GemmArgs& a, const GemmArgs& b, hipStream_t s);
 constexpr size_t SPLITK_WS_FLOATS = (size_t)768 * 4096;    // room for 768 partial 64 x 64 tiles (12 MB)
 constexpr size_t SPLITK_COUNTERS = 512;
 // bf16 modes, full rounds of large-M launches: 3-stage LDS ring, 256 x 128 tiles, one 8-wave block per CU
@@ -84,7 +88,6 @@ struct FlashSplit {
     int rows = 0, heads = 0;
     int ablate = 0;              // timing experiments (garbage results): bit 0 no K/V loads after the first tile, bit 1 no LDS stores of them either
     int bq = 128;                // queries per block of the tile table handed in: FLASH_BQ, or FLASH_BQ_BIG (half rows, head dim 64, LDS-direct kernel only)
-    int asmv = 0;                // LDS-direct kernel at head dim 64: V fragments by inline-asm transpose reads (no vmcnt drain in front of the P.V product)
 };
 int launch_flash_attn(const float* Q, int ldq, const float* K, const float* V, int ldkv, float* O, int ldo,
                       const int4* tiles, int n_tiles, float scale_log2e, hipStream_t s, const FlashSplit* split = nullptr,
@@ -128,7 +131,7 @@ int launch_layernorm(float* x, int ld, int rows, int dim, const float* gamma, co
 int launch_layernorm_to(const float* x, int ld, float* y, int ldy, int rows, int dim, const float* gamma, const float* beta,
                         int relu, int out_split, hipStream_t s, const float* resid = nullptr, int ldr = 0, int r_split = 0);
 // rowscale[m] = scale / ||x[m,:]||_2  (dim == 512)
-int launch_row_invnorm(const float* x, int ld, int rows, int dim, float scale, float* out, hipStream_t s);
+int launch_row_invnorm(const float* x, int ld, int rows, int dim, float scale, float* out, hipStream_t s, const float* x2 = nullptr, float* out2 = nullptr);
 
 // ---- MODEL.feature_transform glue (stn.hip): conv1 as point rows, max over an object's rows, per-object 64x64 ----
 int launch_pts_conv1_rows(const float* pts, int n_obj, int P, int cin, const float* w1, const float* b1, float* rows,
@@ -161,9 +164,9 @@ struct GateArgs {
     int ld_agg = 0;
     int row_map = 1;         // rows of a wave: 1 = 32 edges of one head, 0 = 4 edges x 8 heads (vlsat_debug_option "gate_row_map")
 };
-int launch_edge_gate(const GateArgs& a, hipStream_t s);
+int launch_edge_gate(const GateArgs& a, hipStream_t s, const GateArgs* twin = nullptr);     // twin: a second gate on the same edge list in the same launch (one-scene plans)
 // agg[n, 0:n_ch] = rowptr[n+1] > rowptr[n] ? -inf : 0   (start values of the fused max aggregation)
-int launch_agg_init(const int32_t* rowptr, int n_nodes, int n_ch, float* agg, int ld_agg, hipStream_t s);
+int launch_agg_init(const int32_t* rowptr, int n_nodes, int n_ch, float* agg, int ld_agg, hipStream_t s, float* agg2 = nullptr);
 // p[0:n] = 0 with a kernel of the library (16-byte stores when n and p allow): the forward path does not use hipMemsetAsync
 int launch_zero_f32(float* p, size_t n, hipStream_t s);
 // dst[r, 0:cols] = src[r, 0:cols], r < rows (pitches in floats; 16-byte accesses when sizes and pointers allow)
@@ -178,12 +181,12 @@ bool edge_gate_bf16_heads_supports(int dk, int dox, int terms);
 int launch_edge_gate_bf16_heads(const GateArgs& a, int n_heads, int dk, int dox, int terms, int kproj_split, hipStream_t s);
 // the same on the bf16 matrix cores (edge_gate_bf16.hip): terms = 3 split-bf16 | 1 single-rounded; kproj_split = 1: kproj is
 // in the split-pair format of the bf16 modes (common.h pack_split)
-int launch_edge_gate_bf16(const GateArgs& a, int terms, int kproj_split, hipStream_t s);
+int launch_edge_gate_bf16(const GateArgs& a, int terms, int kproj_split, hipStream_t s, const GateArgs* twin = nullptr);
 
 // ---- scatter aggregation by source node over a CSR (rowptr[N+1], order[E]) ----
 // out[n, col0 + c] = reduce_{k in rowptr[n]..rowptr[n+1]} gated[order[k], c]; empty -> 0
 int launch_aggregate(const float* gated, int n_ch, const int32_t* rowptr, const int32_t* order,
-                     int n_nodes, int aggr, float* out, int ldo, int col0, hipStream_t s);
+                     int n_nodes, int aggr, float* out, int ldo, int col0, hipStream_t s, const float* gated2 = nullptr, float* out2 = nullptr);   // gated2 / out2: a twin problem on the same graph in the same launch
 
 // w[i] -> bf16 hi[i] + bf16 lo[i] (split-bf16 GEMM weights, one-time)
 int launch_split_bf16(const float* w, size_t n, uint16_t* hi, uint16_t* lo, hipStream_t s);

@@ -159,7 +159,8 @@ int launch_layernorm_to(const float* x, int ld, float* y, int ldy, int rows, int
 
 // rowscale[m] = scale / ||x[m, 0:512]||_2   (object heads: reference SGFN_MMG/model.py:327-330)
 __global__ __launch_bounds__(256) void row_invnorm512_kernel(const float* __restrict__ x, int ld, int rows,
-                                                             float scale, float* __restrict__ out) {
+                                                             float scale, float* __restrict__ out, const float* __restrict__ x2, float* __restrict__ out2) {
+    if (blockIdx.y != 0) { x = x2; out = out2; }                  // (the twin problem of a paired launch)
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -172,10 +173,11 @@ __global__ __launch_bounds__(256) void row_invnorm512_kernel(const float* __rest
     s = wave_sum(s);
     if (lane == 0) out[row] = scale / sqrtf(s);
 }
-int launch_row_invnorm(const float* x, int ld, int rows, int dim, float scale, float* out, hipStream_t s) {
+int launch_row_invnorm(const float* x, int ld, int rows, int dim, float scale, float* out, hipStream_t s, const float* x2, float* out2) {
     if (rows <= 0) return 0;
     if (dim != 512 || (ld & 3)) return fail(-1, "row_invnorm: dim must be 512 and ld a multiple of 4");
-    hipLaunchKernelGGL(row_invnorm512_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, ld, rows, scale, out);
+    if (!x2 != !out2) return fail(-1, "row_invnorm: a twin launch needs both the second input and the second output");
+    hipLaunchKernelGGL(row_invnorm512_kernel, dim3((rows + 3) / 4, x2 ? 2 : 1), dim3(256), 0, s, x, ld, rows, scale, out, x2, out2);
     VLSAT_LAUNCH_CHECK("row_invnorm512");
     return 0;
 }
@@ -184,10 +186,13 @@ int launch_row_invnorm(const float* x, int ld, int rows, int dim, float scale, f
 // Aggre_Index (reference network_util.py:64-73; aggr from MODEL.GCN_AGGR, flow target_to_source
 // => reduce over the edges whose SOURCE is n).  CSR over sources, one block per node, one
 // thread per channel: deterministic, no atomics; empty segment -> 0 (torch_scatter semantics).
+// (blockIdx.y = 1: the twin problem of a paired launch -- gated2 / out2, same graph: round 6, one-scene plans)
 __global__ __launch_bounds__(256) void aggregate_kernel(const float* __restrict__ gated, int n_ch,
                                                         const int32_t* __restrict__ rowptr,
                                                         const int32_t* __restrict__ order, int aggr,
-                                                        float* __restrict__ out, int ldo, int col0) {
+                                                        float* __restrict__ out, int ldo, int col0,
+                                                        const float* __restrict__ gated2, float* __restrict__ out2) {
+    if (blockIdx.y != 0) { gated = gated2; out = out2; }
     const int n = blockIdx.x;
     const int b = rowptr[n], e = rowptr[n + 1];
     for (int c = threadIdx.x; c < n_ch; c += 256) {          // (DIM_ATTEN = 512: two channels per thread)
@@ -206,17 +211,18 @@ __global__ __launch_bounds__(256) void aggregate_kernel(const float* __restrict_
 }
 // start values of the aggregation fused into the gate kernel (edge_gate_bf16.hip): -inf where a maximum will arrive, 0 for
 // nodes without out-edges (torch_scatter's empty segment)
-__global__ __launch_bounds__(256) void agg_init_kernel(const int32_t* __restrict__ rowptr, int n_nodes, int n_ch, float* __restrict__ agg, int ld) {
+__global__ __launch_bounds__(256) void agg_init_kernel(const int32_t* __restrict__ rowptr, int n_nodes, int n_ch, float* __restrict__ agg, int ld, float* __restrict__ agg2) {
+    if (blockIdx.y != 0) agg = agg2;
     const int i = blockIdx.x * 256 + threadIdx.x, n = i / (n_ch / 4), c4 = (i % (n_ch / 4)) * 4;
     if (n >= n_nodes) return;
     const float v = rowptr[n + 1] > rowptr[n] ? -INFINITY : 0.f;
     *reinterpret_cast<f32x4*>(agg + (size_t)n * ld + c4) = f32x4{v, v, v, v};
 }
-int launch_agg_init(const int32_t* rowptr, int n_nodes, int n_ch, float* agg, int ld_agg, hipStream_t s) {
+int launch_agg_init(const int32_t* rowptr, int n_nodes, int n_ch, float* agg, int ld_agg, hipStream_t s, float* agg2) {
     if (n_nodes <= 0) return 0;
     if ((n_ch & 3) || (ld_agg & 3)) return fail(-1, "agg_init: channel count and pitch must be multiples of 4");
     const long n4 = (long)n_nodes * (n_ch / 4);
-    hipLaunchKernelGGL(agg_init_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, rowptr, n_nodes, n_ch, agg, ld_agg);
+    hipLaunchKernelGGL(agg_init_kernel, dim3((unsigned)((n4 + 255) / 256), agg2 ? 2 : 1), dim3(256), 0, s, rowptr, n_nodes, n_ch, agg, ld_agg, agg2);
     VLSAT_LAUNCH_CHECK("agg_init");
     return 0;
 }
@@ -268,10 +274,11 @@ int launch_copy_rows(float* dst, size_t dst_ld, const float* src, size_t src_ld,
 }
 
 int launch_aggregate(const float* gated, int n_ch, const int32_t* rowptr, const int32_t* order, int n_nodes,
-                     int aggr, float* out, int ldo, int col0, hipStream_t s) {
+                     int aggr, float* out, int ldo, int col0, hipStream_t s, const float* gated2, float* out2) {
     if (n_nodes <= 0) return 0;
-    hipLaunchKernelGGL(aggregate_kernel, dim3(n_nodes), dim3(256), 0, s, gated, n_ch, rowptr, order, aggr, out, ldo,
-                       col0);
+    if (!gated2 != !out2) return fail(-1, "aggregate: a twin launch needs both the second input and the second output");
+    hipLaunchKernelGGL(aggregate_kernel, dim3(n_nodes, gated2 ? 2 : 1), dim3(256), 0, s, gated, n_ch, rowptr, order, aggr, out, ldo,
+                       col0, gated2, out2);
     VLSAT_LAUNCH_CHECK("aggregate");
     return 0;
 }
