@@ -43,6 +43,8 @@ int vlsat_set_edge_attention_scope(vlsat_handle h, int32_t scope) {
 //                       mode (-1, default: exact in the bf16 modes, fork / join in exact fp32)
 //   "flash_split" 0|1   split-key edge attention for plans that cannot fill the chip (plans created afterwards)
 //   "prof_dual"   0|1   per-class profiling keeps the multi-stream execution (1, default) or serialises on the launch stream
+//   "pair_twins" 0|1 / "pair_max_edges" n   paired schedule of one-scene plans (engine_forward.hip): twin stages as launches of two problems
+//   "gemm_k_rot" -1|0..7   K-tile rotation per column tile of the 8-phase GEMM (-1: 1 for half-row bf16 launches, else 0)
 //   "gemm_p8" / "gemm_dma" / "gemm_splitk" 0|1   GEMM kernel selection: 256 x 256 8-phase kernel for large launches, LDS-direct staging of
 //                       fp32 operands, split-K kernel for small launches (0: the older kernels; parity-tested both ways)
 //   "split_fmt" / "flash_bf16" / "flash_tr" / "pointnet_bf16" / "gate_bf16" / "ln_resid" 0|1   bf16 modes: edge tensors between matrix

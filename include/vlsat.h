@@ -391,7 +391,13 @@ int vlsat_debug_gemm_clock_probe(int64_t* buf);
  *                         the bf16 modes on plans of more than 16 384 edges, fork / join otherwise.  Bit-identical results;
  *   "flash_split" 0|1     split-key edge attention for plans that cannot fill the chip (plans created afterwards);
  *   "prof_dual" 0|1       per-class profiling keeps the multi-stream execution (1, default) or serialises on the launch stream;
+ *   "pair_twins" 0|1, "pair_max_edges" n   plans of at most n edges (default 4096: one scene per call) run the 3D / 2D twin stages --
+ *                         relation encoders, gcn_3ds | gcn_2ds, both head pairs -- as launches of two problems each, the edge cross-attention
+ *                         of layer l on the second stream under the node attentions of layer l + 1 (round 6).  Bit-identical results;
  *   "gemm_p8", "gemm_dma", "gemm_splitk" 0|1          GEMM kernel selection (0: the older kernels);
+ *   "gemm_k_rot" -1|0..7  8-phase GEMM: column tile tn of a row panel walks its K-tiles starting at tn * r (the blocks that share an A
+ *                         panel ask L2 for its lines out of step); -1 = default: 1 for half-row bf16 launches, 0 otherwise.  Rotates an
+ *                         fp32 summation order: inside every mode's tolerance (tests/test_hip_round6.py), not bit-identical;
  *   "split_fmt", "flash_bf16", "flash_tr", "pointnet_bf16", "gate_bf16", "ln_resid" 0|1   bf16 modes: tensor formats and kernels (0: the
  *                         fp32 forms) -- every one parity-tested both ways (tests/test_hip_forward.py);
  *   "flash_bq_big" 0|1    half-row edge attention, plans whose scenes all have >= 4096 edges: 256 queries per block (default) or 128;

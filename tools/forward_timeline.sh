@@ -1,10 +1,10 @@
 #!/bin/bash
 # Kernel-by-kernel timeline of ONE one-scene forward under rocprofv3 --kernel-trace:
-#   tools/forward_timeline.sh <tag> <objects> [fp32|bf16x3|bf16_mixed|bf16] [points]
+#   tools/forward_timeline.sh <tag> <objects> [fp32|bf16x3|bf16_mixed|bf16] [points] [debug option NAME=VALUE] [output suffix]
 # writes gpurun_out/<tag>/timeline_<objects>.txt: every kernel of the last of 6 identical calls with its start offset,
 # duration and the gap to the previous kernel's end on the same stream view (two-stream plans overlap: start offsets tell).
 set -u
-TAG=$1; N=$2; PREC=${3:-fp32}; P=${4:-256}
+TAG=$1; N=$2; PREC=${3:-fp32}; P=${4:-256}; OPT=${5:-}; SUF=${6:-}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -16,6 +16,9 @@ from vlsat_amd import VLSATConfig, synth
 from vlsat_amd.model import VLSATModel
 cfg = VLSATConfig(N_LAYERS=3)
 m = VLSATModel(cfg, "cuda:0").load_state(synth.make_weights(cfg)).eval().set_gemm_precision("$PREC")
+opt = "$OPT"
+if opt:
+    m.debug_option(opt.split("=")[0], int(opt.split("=")[1]))
 b = synth.collate([synth.make_scene($N, $P, 1)])
 d = {k: torch.from_numpy(v).to("cuda:0") for k, v in b.items()}
 for i in range(6):
@@ -24,9 +27,9 @@ for i in range(6):
 PY
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace -d "$OUT/kt_$N" -o one -- python /tmp/_one_scene.py > "$OUT/kt_$N.log" 2>&1
-python - "$OUT" "$N" "$PREC" <<'PY'
+python - "$OUT" "$N" "$PREC$OPT" "$SUF" <<'PY'
 import sqlite3, sys, glob
-out, n, prec = sys.argv[1:4]
+out, n, prec, suf = sys.argv[1:5]
 db = glob.glob(f"{out}/kt_{n}/**/*.db", recursive=True)[0]
 c = sqlite3.connect(db)
 rows = [(s, e, nm) for s, e, nm in c.execute("select start, end, name from kernels order by start") if "vlsat::" in nm]
@@ -46,7 +49,7 @@ for s, e, nm in last:
     k = nm.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].replace("vlsat::", "")
     lines.append(f"{(s - t0) / 1e3:9.1f} us  +{(e - s) / 1e3:7.1f} us  gap {(s - prev_end) / 1e3:6.1f}  {k}")
     prev_end = max(prev_end, e)
-open(f"{out}/timeline_{n}.txt", "w").write("\n".join(lines) + "\n")
+open(f"{out}/timeline_{n}{suf}.txt", "w").write("\n".join(lines) + "\n")
 print(lines[0])
 PY
 rm -rf "$OUT/kt_$N"
