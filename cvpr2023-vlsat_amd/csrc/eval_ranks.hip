@@ -59,27 +59,44 @@ __device__ inline void finish_edge(int* r, int n, int32_t* out, int stride_pad) 
     for (int i = 0; i < stride_pad; ++i) out[i] = i < n ? r[i] - i : 0;
 }
 
+// 32 lanes per edge (lane = relation class, R <= 32; coalesced reads of the edge's scores and labels), 8 edges per block.
+// rank of gt class k = min(#{q : p[q] > p[k]}, topk) + 1; an edge without gt relation gets ONE rank from #{q : p[q] >= thr}
+// (eva_utils_acc.py:55-61).  The edge's ranks are then sorted ascending and each loses its position (:73-77) -- by counting, the
+// ranks being few: position of rank_k = #{gt j : rank_j < rank_k, or equal and j < k}.
 __global__ __launch_bounds__(256) void rel_rank_kernel(const float* __restrict__ rel, const int64_t* __restrict__ gt_rel,
                                                        int n_edges, int R, int topk, float thr,
                                                        int32_t* __restrict__ out, int32_t* __restrict__ cnt) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ int s_sorted[8][32];
+    const int tid = threadIdx.x, k = tid & 31, base = tid & 32;
+    const int e = blockIdx.x * 8 + (tid >> 5);
     if (e >= n_edges) return;
-    const float* p = rel + (size_t)e * R;
-    const int64_t* g = gt_rel + (size_t)e * R;
-    int r[32], n = 0;
-    for (int k = 0; k < R; ++k)
-        if (g[k] == 1) {
-            int c = 0;
-            for (int q = 0; q < R; ++q) c += p[q] > p[k];
-            r[n++] = min(c, topk) + 1;
-        }
-    if (n == 0) {
-        int ge = 0;
-        for (int q = 0; q < R; ++q) ge += p[q] >= thr;
-        r[n++] = ge == R ? topk + 1 : ge + 1;
+    const bool in = k < R;
+    const float v = in ? rel[(size_t)e * R + k] : -INFINITY;
+    const bool is_gt = in && gt_rel[(size_t)e * R + k] == 1;
+    const unsigned gts = (unsigned)(__ballot(is_gt) >> base);
+    const unsigned ge = (unsigned)(__ballot(in && v >= thr) >> base);
+    int c = 0;
+    for (int q = 0; q < R; ++q) c += __shfl(v, base + q) > v;
+    int rank = min(c, topk) + 1;
+    int32_t* o = out + (size_t)e * R;
+    if (gts == 0) {                                           // no gt relation: one rank
+        const int g = __popc(ge);
+        if (in) o[k] = k == 0 ? (g == R ? topk + 1 : g + 1) : 0;
+        if (k == 0) cnt[e] = 1;
+        return;
     }
-    finish_edge(r, n, out + (size_t)e * R, R);
-    cnt[e] = n;
+    const int n = __popc(gts);
+    int pos = 0;
+    for (unsigned m = gts; m; m &= m - 1) {
+        const int j = __ffs(m) - 1;
+        const int rj = __shfl(rank, base + j);
+        pos += rj < rank || (rj == rank && j < k);
+    }
+    // the sorted list through LDS: gt lane k owns slot `pos` (equal ranks hold distinct positions), lane i then writes slot i of the row
+    if (is_gt) s_sorted[tid >> 5][pos] = rank - pos;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // (one wave: its LDS writes are complete before its reads issue)
+    if (in) o[k] = k < n ? s_sorted[tid >> 5][k] : 0;
+    if (k == 0) cnt[e] = n;
 }
 
 // ---- triplet ranks by counting a STAIRCASE, not the outer product ---------------------------------------------------------------
@@ -414,7 +431,7 @@ int launch_eval_ranks(const float* obj_logits, const float* obj_probs, const flo
     if (E > 0) {
         if (!sorted_probs) return fail(-1, "eval_ranks: null scratch (vlsat_eval_ranks_scratch_floats)");
         const int K = eval_ranks_sorted_k(C, topk_tri);
-        hipLaunchKernelGGL(rel_rank_kernel, dim3((E + 255) / 256), dim3(256), 0, s, rel, gt_rel, E, R, topk_rel, thr, rel_rank, cnt);
+        hipLaunchKernelGGL(rel_rank_kernel, dim3((E + 7) / 8), dim3(256), 0, s, rel, gt_rel, E, R, topk_rel, thr, rel_rank, cnt);
         VLSAT_LAUNCH_CHECK("rel_rank");
         hipLaunchKernelGGL(sort_probs_kernel, dim3((N + 3) / 4), dim3(256), (size_t)4 * C * sizeof(float), s, obj_probs, N, C, K, sorted_probs);
         VLSAT_LAUNCH_CHECK("sort_probs");

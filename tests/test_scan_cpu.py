@@ -145,3 +145,83 @@ def test_name_lists_of_the_reference_subset_have_the_survey_sizes():
     relations = S.read_name_list(os.path.join(here, "3dssg_relations.txt"))
     assert len(classes) == 160 and len(set(classes)) == 160
     assert len(relations) in (26, 27)
+
+
+def test_read_ply_round_trips_random_vertex_tables(tmp_path):
+    """Property test (hypothesis): any vertex table with the 3RScan label-mesh properties in any order, extra scalar properties of any
+    PLY type, ASCII or binary, with or without an element in front -- read_ply returns exactly the written xyz / colours / normals /
+    instance ids (values are parsed into their declared type, so a float32 written in decimal comes back as that float32)."""
+    from hypothesis import given, settings, strategies as st, HealthCheck
+    types = {"float": ("<f4", "f"), "double": ("<f8", "d"), "uchar": ("u1", "B"), "ushort": ("<u2", "H"), "int": ("<i4", "i"), "short": ("<i2", "h")}
+
+    @settings(max_examples=40, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+    @given(st.integers(0, 2 ** 31 - 1), st.integers(1, 60), st.booleans(), st.booleans(), st.booleans(), st.booleans(), st.sampled_from(["objectId", "label"]),
+           st.lists(st.sampled_from(sorted(types)), min_size=0, max_size=3))
+    def run(seed, n, binary, lead, with_rgb, with_normals, label_name, extra):
+        g = np.random.default_rng(seed)
+        cols = [("x", "float"), ("y", "float"), ("z", "float")]
+        if with_rgb:
+            cols += [("red", "uchar"), ("green", "uchar"), ("blue", "uchar")]
+        if with_normals:
+            cols += [("nx", "float"), ("ny", "float"), ("nz", "float")]
+        cols += [(label_name, "ushort")] + [(f"extra{i}", t) for i, t in enumerate(extra)]
+        order = g.permutation(len(cols))
+        cols = [cols[i] for i in order]
+        rec = np.zeros(n, dtype=[(c, types[t][0]) for c, t in cols])
+        for c, t in cols:
+            kind = np.dtype(types[t][0]).kind
+            rec[c] = g.normal(size=n) * 3 if kind == "f" else g.integers(0, 200 if t != "short" else 100, n)
+        head = ["ply", "format %s 1.0" % ("binary_little_endian" if binary else "ascii")]
+        if lead:
+            head += ["element camera 1", "property float fx"]
+        head += ["element vertex %d" % n] + ["property %s %s" % (t, c) for c, t in cols] + ["element face 0", "property list uchar int vertex_indices", "end_header"]
+        p = str(tmp_path / f"h_{seed}_{n}.ply")
+        with open(p, "wb") as f:
+            f.write(("\n".join(head) + "\n").encode())
+            if lead:
+                f.write(struct.pack("<f", 1.0) if binary else b"1.0\n")
+            if binary:
+                f.write(rec.tobytes())
+            else:
+                for r in rec:
+                    f.write((" ".join(("%.9g" % float(r[c])) if np.dtype(types[t][0]).kind == "f" and t == "float" else repr(float(r[c])) if t == "double" else str(int(r[c])) for c, t in cols) + "\n").encode())
+        m = S.read_ply(p)
+        assert np.array_equal(m["points"], np.stack([rec["x"], rec["y"], rec["z"]], 1).astype(np.float64))
+        assert np.array_equal(m["instances"], rec[label_name].astype(np.int64))
+        if with_rgb:
+            assert np.array_equal(m["colors"], np.stack([rec["red"], rec["green"], rec["blue"]], 1))
+        else:
+            assert m["colors"] is None
+        if with_normals:
+            assert np.array_equal(m["normals"], np.stack([rec["nx"], rec["ny"], rec["nz"]], 1).astype(np.float64))
+        else:
+            assert m["normals"] is None
+    run()
+
+
+def test_edge_list_and_ground_truth_agree_with_the_restatement_on_random_scans():
+    """Property test: random object maps (any key order, instances without points, points without annotation), random relationship
+    lists (duplicates, unknown instances, several labels per pair) -- scan.py's vectorised functions equal the oracle's loop-by-loop
+    restatement of data_preparation (which tests/test_scan_golden_cpu.py pins to the reference itself), in all four switch settings."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.integers(0, 2 ** 31 - 1), st.booleans(), st.booleans())
+    def run(seed, multi, all_edge):
+        g = np.random.default_rng(seed)
+        ids = [int(i) for i in g.permutation(np.arange(1, 30))[: int(g.integers(1, 12))]]
+        objs = {i: ["bed", "chair", "floor"][int(g.integers(0, 3))] for i in ids}
+        with_points = [i for i in ids if g.random() < 0.8] + [int(g.integers(40, 50))]
+        inst = g.choice(np.array([0] + with_points), 300)
+        names = ["none", "left", "right", "on"] if not multi else ["left", "right", "on"]
+        pool = ids + [99]
+        rel = [[int(g.choice(pool)), int(g.choice(pool)), 0, str(g.choice(names[(0 if multi else 1):]))] for _ in range(int(g.integers(0, 25)))]
+        nodes = S.scene_nodes(inst, objs)
+        if not nodes:
+            return
+        edges = S.edge_list(nodes, rel, all_edge)
+        gt_class, gt_rel = S.ground_truth(nodes, edges, objs, ["bed", "chair", "floor"], rel, names, multi)
+        r_nodes, r_edges, r_class, r_rel = PO.scene_labels(inst, objs, ["bed", "chair", "floor"], rel, names, multi, all_edge)
+        assert nodes == r_nodes and np.array_equal(edges, r_edges) and np.array_equal(gt_class, r_class)
+        assert gt_rel.dtype == r_rel.dtype and gt_rel.shape == r_rel.shape and np.array_equal(gt_rel, r_rel)
+    run()
