@@ -71,6 +71,8 @@ python tools/eval_synth.py > "$OUT/eval_synth.txt" 2>&1
 python tools/stress_scan.py > "$OUT/stress_scan.txt" 2>&1
 python tools/fuzz_forward.py --iters 120 > "$OUT/fuzz_forward.txt" 2>&1
 python tools/soak_forward.py > "$OUT/soak_forward.txt" 2>&1
+python tools/replica_race_probe.py --scenes 120 --passes 3 > "$OUT/replica_race_fp32.txt" 2>&1
+python tools/replica_race_probe.py --scenes 120 --passes 3 --gemm-precision bf16_mixed > "$OUT/replica_race_bf16_mixed.txt" 2>&1
 python -m pytest tests -q -m gpu -rf 2>&1 | grep -E "^FAILED|passed|failed|error" | tail -12 > "$OUT/tests_gpu.log"
 fi
 du -sh "$OUT"; ls "$OUT"

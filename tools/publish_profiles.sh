@@ -22,11 +22,14 @@ cp $S/prof_cfg3_mixed/kernel_stats.md $D/${R}_cfg3_bf16_mixed_kernel_stats.md; c
 for hd in 4 16; do [ -d $S/prof_heads$hd ] && { cp $S/prof_heads$hd/kernel_stats.md $D/${R}_heads${hd}_kernel_stats.md; cp $S/prof_heads$hd/pmc.md $D/${R}_heads${hd}_pmc.md; }; done
 for m in fp32 bf16x3 bf16_mixed; do [ -f $S/latency_$m.txt ] && grep -v amdgpu.ids $S/latency_$m.txt > $D/${R}_latency_$m.txt; done
 for f in gemm_fp32 gemm_fp32_no_p8 gemm_bf16_half gemm_bf16_half_cold gemm_p8_ablation gemm_p8_ablation_cold gemm_p8_gather_ablation heads switch_scan fuzz_forward gemm_bf16x3 gemm_bf16x3_no_p8 eval_synth \
-         gemm_tile_sweep val_loop_fp32 val_loop_bf16_mixed val_loop_fp32_n40 stress_scan soak_forward; do
+         gemm_tile_sweep val_loop_fp32 val_loop_bf16_mixed val_loop_fp32_n40 stress_scan soak_forward replica_race_fp32 replica_race_bf16_mixed latency_fp32_unpaired \
+         timeline_20 timeline_20_unpaired timeline_40 timeline_40_unpaired metrics_bench; do
   [ -f $S/$f.txt ] && grep -v amdgpu.ids $S/$f.txt > $P/$f.txt
 done
 for l in launches_fp32 launches_bf16_mixed; do [ -f $S/$l/launches.txt ] && cp $S/$l/launches.txt $P/$l.txt; done
 cp $S/tests_gpu.log $D/${R}_tests_gpu.txt
+[ -f $S/eval_kernel_stats.md ] && cp $S/eval_kernel_stats.md $D/${R}_eval_kernel_stats.md
+[ -f $S/eval_pmc.md ] && cp $S/eval_pmc.md $D/${R}_eval_pmc.md
 ls $D $P
 # stamp the published summaries with the commit they were published from (the GPU box has no .git; the digests of sources and
 # library in `collected_on` were taken there)
