@@ -217,7 +217,7 @@ int vlsat_plan_create(vlsat_handle h, const int64_t* bid, const int64_t* edges, 
     if (h->edge_scope == 0 && p->fa_parts <= 1 && E > 0 && E * (int64_t)(2 * D) * 4 < (int64_t)1 << 32) {
         int64_t min_t = INT64_MAX;
         for (int s = 0; s < p->S; ++s) { const int64_t T = p->edge_ptr[s + 1] - p->edge_ptr[s]; if (T > 0) min_t = std::min(min_t, T); }
-        if (min_t >= 4096 && min_t != INT64_MAX)
+        if (min_t >= h->flash_bq_big_min && min_t != INT64_MAX)
             for (int s = 0; s < p->S; ++s) {
                 const int64_t T = p->edge_ptr[s + 1] - p->edge_ptr[s];
                 for (int hh = 0; hh < H; ++hh)

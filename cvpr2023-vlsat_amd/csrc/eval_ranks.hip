@@ -431,6 +431,8 @@ int launch_eval_ranks(const float* obj_logits, const float* obj_probs, const flo
     if (E > 0) {
         if (!sorted_probs) return fail(-1, "eval_ranks: null scratch (vlsat_eval_ranks_scratch_floats)");
         const int K = eval_ranks_sorted_k(C, topk_tri);
+        if ((size_t)16 * K * sizeof(float) + 256 * sizeof(int) > 65536)      // (8 edges x 2 sorted rows of K floats per block; process_val's topk is 101)
+            return fail(-1, "eval_ranks: min(n_obj_class, topk_triplet) must be at most 1008");
         hipLaunchKernelGGL(rel_rank_kernel, dim3((E + 7) / 8), dim3(256), 0, s, rel, gt_rel, E, R, topk_rel, thr, rel_rank, cnt);
         VLSAT_LAUNCH_CHECK("rel_rank");
         hipLaunchKernelGGL(sort_probs_kernel, dim3((N + 3) / 4), dim3(256), (size_t)4 * C * sizeof(float), s, obj_probs, N, C, K, sorted_probs);

@@ -140,7 +140,7 @@ class VLSATModel:
         (timing ablations and the like) exist in the experiments build only (``build.py --experiments``)."""
         L.check(self._lib.vlsat_debug_option(self._h, name.encode(), int(value)))
         self._debug_options[name] = int(value)
-        if name in ("dual_stream", "flash_split"):
+        if name in ("dual_stream", "flash_split", "flash_bq_big_min"):
             self._drop_plans()
         self._drop_replicas()                   # (replicas built before this call run another kernel configuration)
         return self

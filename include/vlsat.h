@@ -401,6 +401,8 @@ int vlsat_debug_gemm_clock_probe(int64_t* buf);
  *   "split_fmt", "flash_bf16", "flash_tr", "pointnet_bf16", "gate_bf16", "ln_resid" 0|1   bf16 modes: tensor formats and kernels (0: the
  *                         fp32 forms) -- every one parity-tested both ways (tests/test_hip_forward.py);
  *   "flash_bq_big" 0|1    half-row edge attention, plans whose scenes all have >= 4096 edges: 256 queries per block (default) or 128;
+ *   "flash_bq_big_min" n  ... that bound (plans created afterwards).  At the bench batch (1560 edges per scene) 256-query tiles are 1 %
+ *                         slower per step than 128-query ones (profiles/r06_probes/ab_flash_bq_big_min.txt): the default stays 4096;
  *   "flash_pv_terms" 3|2  split-bf16 edge attention: MFMAs per P.V product;  "gate_fuse_agg" 0|1|2: max aggregation inside the gate
  *                         kernel (never / bf16 modes / fp32 too);  "gate_row_map" 0|1, "gate_heads_mfma" 0|1|2: gate kernel variants.
  * Lab switches ("gate_grid", "gate_heads_bf16", "flash_heads_bf16", "node_attn_split", "half_fmt", "flash_dma", "flash_ablate" -- the
