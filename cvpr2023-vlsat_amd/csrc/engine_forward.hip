@@ -108,6 +108,7 @@ static int gemm_resolve(vlsat_ctx* h, int ws_lane, GemmArgs& a, int prec_overrid
     if (h->gemm_splitk) {
         a.sk_ws = h->sk_ws[ws_lane]; a.sk_ws_floats = SPLITK_WS_FLOATS;
         a.sk_counters = h->sk_cnt[ws_lane]; a.sk_n_counters = SPLITK_COUNTERS;
+        a.sk_max_tiles = h->gemm_splitk_max_tiles;
     }
     return 0;
 }

@@ -117,7 +117,7 @@ int launch_gemm_splitk(const GemmArgs& a, int slots, hipStream_t s, const GemmAr
     if (twin && (!twin->sk_ws || !twin->sk_counters || twin->sk_ws == a.sk_ws || twin->sk_counters == a.sk_counters)) return 1;
     const long nbm = (a.M + 63) / 64, nbn = (a.N + 63) / 64, T = nbm * nbn;
     const int total = a.K / BK;                                      // k-slices
-    if (total < 4 || T > slots / 2) return 1;                        // at least two parts of >= 2 slices, and room for them
+    if (total < 4 || T > slots / 2 || (a.sk_max_tiles > 0 && T > a.sk_max_tiles)) return 1;      // at least two parts of >= 2 slices, and room for them
     // as many parts as fill the resident slots once, each at least two slices (64 of K) long
     int ks = (int)std::min<long>(total / 2, std::max<long>(1, slots / T));
     ks = std::min(ks, 16);

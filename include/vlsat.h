@@ -395,6 +395,7 @@ int vlsat_debug_gemm_clock_probe(int64_t* buf);
  *                         relation encoders, gcn_3ds | gcn_2ds, both head pairs -- as launches of two problems each, the edge cross-attention
  *                         of layer l on the second stream under the node attentions of layer l + 1 (round 6).  Bit-identical results;
  *   "gemm_p8", "gemm_dma", "gemm_splitk" 0|1          GEMM kernel selection (0: the older kernels);
+ *   "gemm_splitk_max_tiles" n   the split-K kernel takes launches of at most n 64 x 64 output tiles (default 64; 0: half the resident slots);
  *   "gemm_k_rot" -1|0..7  8-phase GEMM: column tile tn of a row panel walks its K-tiles starting at tn * r (the blocks that share an A
  *                         panel ask L2 for its lines out of step); -1 = default: 1 for half-row bf16 launches, 0 otherwise.  Rotates an
  *                         fp32 summation order: inside every mode's tolerance (tests/test_hip_round6.py), not bit-identical;

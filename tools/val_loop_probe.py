@@ -30,11 +30,14 @@ def main():
     ap.add_argument("--gemm-precision", default="fp32", choices=["fp32", "bf16x3", "bf16_mixed"])
     ap.add_argument("--workers", default="1,2,4,6,8")
     ap.add_argument("--merge", default="4,8,16", help="also: K workers each collating B consecutive one-scene batches into one call (evaluate.merge_batches)")
+    ap.add_argument("--debug-option", action="append", default=[], metavar="NAME=VALUE", help="vlsat_debug_option of the model (replicas inherit it)")
     ap.add_argument("--no-hint", action="store_true", help="do not pass fc_sizes: the plan cache hashes the (device) edge list, one read-back per new graph")
     a = ap.parse_args()
     dev = "cuda:0"
     cfg = VLSATConfig(N_LAYERS=a.layers)
     model = VLSATModel(cfg, dev).load_state(synth.make_weights(cfg)).eval().set_gemm_precision(a.gemm_precision)
+    for kv in a.debug_option:
+        model.debug_option(kv.split("=")[0], int(kv.split("=")[1]))
     rng = np.random.default_rng(5)
     lo, hi = ([int(x) for x in a.objects.split(",")] * 2)[:2]
     sizes = rng.integers(lo, hi + 1, a.scenes)
