@@ -101,6 +101,7 @@ struct vlsat_ctx {
     int gemm_no_p8 = 0;                      // vlsat_debug_option "gemm_p8": 0 keeps half-row launches off the 8-phase kernel
     int node_attn_split = 1024;              // node attention: sixteen lanes per query when the plan has fewer waves than this
     long config_epoch = 0;                   // bumped by every call that changes what a forward launches 
+    int gemm_p8_part_min = 0;                // "gemm_p8_part_min": remainder tiles from which the 8-phase kernel takes them as balanced rounds (0: built-in)
     int gemm_splitk_max_tiles = 64;          // ... for launches of at most this many 64 x 64 tiles ("gemm_splitk_max_tiles"; 0: half the resident slots = the rule of
                                              // rounds 2-5, 256).  Round 6, interleaved A/B (profiles/r06_probes/ab_splitk_max_tiles*.txt): with 64 the remainder launches of the
                                              // big GEMMs (192-384 tiles) and the edge rows of a one-scene plan stay on the single-round kernel -- batch step +0.8 % bf16_mixed,

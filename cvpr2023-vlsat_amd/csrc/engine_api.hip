@@ -73,6 +73,7 @@ int vlsat_debug_option(vlsat_handle h, const char* name, int32_t value) {
     else if (k == "prof_dual") h->prof_dual = value != 0;
     else if (k == "gate_heads_mfma") h->gate_heads_mfma = value < 0 ? 0 : value > 2 ? 2 : value;
     else if (k == "gemm_splitk") h->gemm_splitk = value != 0;
+    else if (k == "gemm_p8_part_min") h->gemm_p8_part_min = value < 0 ? 0 : value;
     else if (k == "gemm_splitk_max_tiles") h->gemm_splitk_max_tiles = value < 0 ? 0 : value;
     else if (k == "split_fmt") h->split_fmt = value != 0;
     else if (k == "ln_resid") h->ln_resid = value != 0;

@@ -103,6 +103,7 @@ static int gemm_resolve(vlsat_ctx* h, int ws_lane, GemmArgs& a, int prec_overrid
     }
     a.no_dma = h->gemm_no_dma;
     a.no_p8 = h->gemm_no_p8;
+    a.p8_part_min = h->gemm_p8_part_min;
     a.k_rot = h->gemm_k_rot >= 0 ? h->gemm_k_rot : (a.prec == 1 && a.a_split == 2) ? 1 : 0;      // (round 6: +1 % per bf16_mixed step, nothing in the other modes)
     a.launches = &h->gemm_launches;
     if (h->gemm_splitk) {

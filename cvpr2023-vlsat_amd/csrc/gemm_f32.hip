@@ -306,7 +306,7 @@ int launch_gemm_pair(const GemmArgs& a, const GemmArgs& b, hipStream_t s) {
     if (T > G || a.K % (2 * BK)) return 1;
     if (a.N % 256 == 0 && a.K % 128 == 0 && !a.no_dma && !a.no_ring && !a.no_p8 && !a.rowscale) {           // 8-phase partial round?
         const bool p8_fmt = (a.prec == 1 && a.a_split == 2) || (a.prec == 3 && a.a_split == 1) || (a.prec == 0 && !a.a_split && !a.c_split && !a.r_split);
-        const long panels = (a.M + 255) / 256, nbn = a.N / 256, part_min = a.prec == 1 ? 32 : (G / 2 * 5) / 8;
+        const long panels = (a.M + 255) / 256, nbn = a.N / 256, part_min = a.p8_part_min > 0 ? a.p8_part_min : a.prec == 1 ? 32 : (G / 2 * 5) / 8;
         if (p8_fmt && panels * nbn >= part_min) return 1;
     }
     if ((a.prec == 1 || a.prec == 3) && !a.no_dma && !a.no_ring && a.N > 64 && !a.rowscale && (long)((a.M + 255) / 256) * ((a.N + 127) / 128) >= G / 2) return 1;   // ring kernel
@@ -357,13 +357,20 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
         // (single-rounding bf16: a tile is 17-30 us against 8 + 0.4-0.7 us per tile-equivalent on the small kernels -- from 32 tiles on
         //  the partial round wins; the cfg 5 scene's 7 032 remainder rows = 54 tiles took 27.7 us per launch on 64 x 64 tiles, as long
         //  as the full round in front of them: profiles/r05_cfg5_bf16_mixed_kernel_stats_serial.md)
-        const long part_min = a.prec == 1 ? 32 : (G1 * 5) / 8;          // tiles from which a partial round beats the small kernels
+        const long part_min = a.p8_part_min > 0 ? a.p8_part_min : a.prec == 1 ? 32 : (G1 * 5) / 8;          // tiles from which a partial round beats the small kernels
+        // ... and from which the REMAINDER behind full rounds rides along as one more (balanced) round instead of a tail launch.  Round 6,
+        // interleaved A/B at the bench batch (profiles/r06_probes/ab_p8_part_min_*.txt): single-rounding bf16 from 12 tiles on (the
+        // 12 / 24 remainder tiles of every N = 512 / 1024 launch: bf16_mixed 10127-10139 -> 10518-10565 scenes/s, +4 % -- a fourth
+        // round on 208 of the 256 CUs costs what the tail launch cost, but it is one dependent launch less per GEMM and leaves 48 CUs
+        // to the other lanes); split-bf16 from 24 on (+1.2 %; with 12 only +0.5 %: its tiles are three times as long); exact fp32
+        // keeps 5/8 of a round (24: -1.7 %, 12: -10 %: a tile is 131 us there)
+        const long rem_min = a.p8_part_min > 0 ? a.p8_part_min : a.prec == 1 ? 12 : a.prec == 3 ? 24 : (G1 * 5) / 8;
         if (main_panels == 0 && panels * nbn >= part_min) main_panels = panels;
         // Full rounds followed by a remainder that would be a partial round of its own (the cfg 5 scene: 312 tiles = 1.2 rounds at
         // N = 512, 624 = 2.4 at N = 1024): ONE launch of rounds + 1 BALANCED rounds on T / (rounds + 1) blocks instead of a full and a
         // partial launch -- the same number of tile times, one launch skeleton less, and the CUs it leaves out are free for the other
         // lanes' kernels (round 5: kproj 41.7 -> 30.1 us, nn_edge.2 64.7 -> 48.6 at E = 39 800; cfg 5 step +3 %)
-        if (rounds >= 1 && main_panels > 0 && main_panels < panels && (panels - main_panels) * nbn >= part_min) {
+        if (rounds >= 1 && main_panels > 0 && main_panels < panels && (panels - main_panels) * nbn >= rem_min) {
             const long step = 8 * nbn, g2 = ((panels * nbn + rounds) / (rounds + 1) + step - 1) / step * step;
             if (g2 <= G1) {
                 const int r = launch_gemm_p8(a, (int)(panels * nbn), (int)g2, s);

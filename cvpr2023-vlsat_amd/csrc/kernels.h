@@ -36,6 +36,7 @@ struct GemmArgs {
     int ring_wide = 0;                          // experiment: bf16 ring kernel with 128 x 256 tiles where N allows (measured equal)
     int no_ring = 0;                            // debug: keep large bf16 launches on the two-stage 128 x 128 kernel
     int no_p8 = 0;                              // debug: large launches skip the 256 x 256 8-phase kernel (gemm_bf16_p8.hip)
+    int p8_part_min = 0;                        // 8-phase kernel: tiles from which a remainder rides along as balanced rounds / a partial round (0: the built-in bound, 32 in bf16, 5/8 of a round otherwise)
     int sk_max_tiles = 0;                       // split-K kernel only for launches of at most this many 64 x 64 tiles (0: half the resident slots, the rule of rounds 2-5)
     int k_rot = 0;                              // A-B: the column tiles of a row panel walk their K-tiles rotated by tn * k_rot (8-phase kernel: siblings re-read the A panel out of step)
     int force_tile = 0;                         // experiment (tools/gemm_tile_sweep.py): 1 = 128x128, 2 = 128x64, 3 = 64x128, 4 = 64x64 tiles of gemm_f32_kernel, whatever the heuristic says

@@ -396,6 +396,9 @@ int vlsat_debug_gemm_clock_probe(int64_t* buf);
  *                         of layer l on the second stream under the node attentions of layer l + 1 (round 6).  Bit-identical results;
  *   "gemm_p8", "gemm_dma", "gemm_splitk" 0|1          GEMM kernel selection (0: the older kernels);
  *   "gemm_splitk_max_tiles" n   the split-K kernel takes launches of at most n 64 x 64 output tiles (default 64; 0: half the resident slots);
+ *   "gemm_p8_part_min" n   8-phase GEMM: remainder tiles (behind full rounds of 256 x 256 tiles) from which the launch takes them along as one
+ *                         more, balanced round instead of leaving them to a tail launch; 0 = default by precision: 12 single-rounding bf16,
+ *                         24 split-bf16, 5/8 of a round exact fp32 (profiles/r06_probes/ab_p8_part_min_*.txt);
  *   "gemm_k_rot" -1|0..7  8-phase GEMM: column tile tn of a row panel walks its K-tiles starting at tn * r (the blocks that share an A
  *                         panel ask L2 for its lines out of step); -1 = default: 1 for half-row bf16 launches, 0 otherwise.  Rotates an
  *                         fp32 summation order: inside every mode's tolerance (tests/test_hip_round6.py), not bit-identical;
