@@ -247,6 +247,34 @@ def timed_run(model, d, n_scenes, steps, warmup, prof, dev):
             "classes": classes, "out": out, "metrics": metrics}
 
 
+def two_in_flight(model, d, n_scenes, steps, warmup, dev):
+    """The same steps with TWO of them in flight: step i on handle i % 2 (the model and one replica: own plans and scratch) on
+    its own caller stream, so the end of a step -- where only the 2D edge lane still has work (profiles/r06_probes/lanes_bf16_mixed.txt)
+    -- runs under the start of the next.  Every step is a complete forward + checksums of its own; reported NEXT to `value`, never as it."""
+    models = [model] + model.replicas(1)
+    streams = [torch.cuda.Stream(device=dev) for _ in models]
+
+    def run(k):
+        outs = [None, None]
+        for i in range(k):
+            with torch.cuda.stream(streams[i % 2]):
+                out = models[i % 2](d["obj_points"], d["obj_2d_feats"], d["edge_indices"], d["descriptor"], d["batch_ids"])
+                outs[i % 2] = (out, vdist.scene_metrics(out, n_scenes))
+        return outs
+
+    torch.cuda.synchronize()                      # the inputs were produced on the caller's stream
+    run(2 * max(2, warmup))                      # (the replica's plan and scratch are built in its first step)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    outs = run(steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    same = all(torch.equal(a, b) for a, b in zip(outs[0][0], outs[1][0]))
+    return {"what": "two steps in flight: step i on handle i % 2 (model + one replica), each on its own stream; every step a complete forward + checksums",
+            "value": round(n_scenes * steps / dt, 2), "unit": "scenes/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
+            "outputs_of_both_handles_bit_identical": bool(same)}
+
+
 def eval_leg(model, scenes, d, n_obj, dev):
     """Untimed: the step AFTER the path on this rank's batch with seeded synthetic labels -- forward +
     GPU ranking + the additive counts vector (len(evaluate.fields()) = 361 counts), all-reduced once (evaluate.validation) -- so the line carries real evaluation
@@ -440,11 +468,13 @@ def main():
             if ref is not None:
                 e = {k: float((g.cpu() - x).abs().max()) for k, g, x in zip(names, r["out"], ref)}
                 e["scenes_checked"] = f"{n_scenes}/{n_scenes}"
-            ev_mode = None
+            ev_mode, pipelined = None, None
+            if mode in ("bf16x3", "bf16_mixed"):
+                pipelined = two_in_flight(model, d, n_scenes, args.steps, args.warmup, dev)
             if mode == "bf16_mixed":             # the step after the path behind the fastest forward (there the ranking weighs most)
                 ev = eval_leg(model, list(scenes), d, args.objects, dev)
                 ev_mode = {k: ev[k] for k in ("what", "ms_forward_plus_ranking", "scenes_per_s_per_gpu", "reference_compatible_rank_lists")}
-            extra.append({"workload": f"BASELINE configs[2]: 64 scenes x 40 objects x 256 pts, L=3, {mode}", "dtype": MODE_DTYPE[mode], "evaluation": ev_mode,
+            extra.append({"workload": f"BASELINE configs[2]: 64 scenes x 40 objects x 256 pts, L=3, {mode}", "dtype": MODE_DTYPE[mode], "evaluation": ev_mode, "two_steps_in_flight": pipelined,
                           "timing": "value: steps without events on the shipped schedule; roofline: the same steps profiled on one stream",
                           "tolerance": 1e-2, "value": round(v, 2), "unit": "scenes/s", "ms_per_step": round(r["dt"] / args.steps * 1e3, 3),
                           "median_ms_per_step": round(r["median_ms"], 3), "steps": args.steps, "max_abs_err_vs_cpu_oracle": e,
