@@ -97,6 +97,7 @@ struct vlsat_ctx {
     int gemm_no_dma = 0, gate_grid = 0, gate_row_map = 1, gate_heads_mfma = 1, flash_heads_bf16 = 1, gate_heads_bf16 = 1;      // vlsat_debug_option
     int pair_twins = 1;                      // one-scene plans (E <= pair_max_edges): the 3D / 2D twin stages as launches of two problems each (engine_forward.hip, "paired schedule"; vlsat_debug_option "pair_twins")
     int pair_max_edges = 4096;               // ... and the plan size up to which that schedule is used ("pair_max_edges")
+    int gather_f16 = -1;                     // vlsat_debug_option "gather_f16": [P_i | P_j] of the node-side projection as fp16 half rows; -1 (default) = on in the single-rounding modes (prec_edge 1), 0 / 1
     int gemm_k_rot = -1;                     // vlsat_debug_option "gemm_k_rot": K-tile rotation per column tile of the 8-phase GEMM; -1 (default) = 1 for half-row bf16 launches, 0 otherwise
     int gemm_no_p8 = 0;                      // vlsat_debug_option "gemm_p8": 0 keeps half-row launches off the 8-phase kernel
     int node_attn_split = 1024;              // node attention: sixteen lanes per query when the plan has fewer waves than this
@@ -195,6 +196,9 @@ struct Scratch { float *NP, *Hbig, *KP, *G, *T768, *R1, *R2, *rs, *H2; };
 // projection buffer [P_i 1024 | P_j 1024 | Gq H*(2 d_k) = 1024 | value A]
 inline int ldx_of(const vlsat_ctx* h) { return h->D + h->A; }
 inline int npc_of(const vlsat_ctx* h) { return 6 * h->D + h->A; }
+// [P_i | P_j] as fp16 half rows (written by gcn_node_project, gathered by nn_edge.0): the single-rounding modes unless "gather_f16" says otherwise;
+// never in the exact-fp32 mode and never when the node rows run in fp32
+inline bool gather_f16_on(const vlsat_ctx* h) { return h->prec_edge != 0 && h->prec_node != 0 && (h->gather_f16 >= 0 ? h->gather_f16 != 0 : h->prec_edge == 1); }
 inline bool default_heads(const vlsat_ctx* h) { return h->H == 8 && h->A == 256; }
 // a plan whose workspace would exceed this with the second scratch set of the two-stream mode runs on one stream
 constexpr size_t DUAL_WS_BUDGET = size_t(48) << 30;

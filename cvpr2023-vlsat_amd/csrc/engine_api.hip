@@ -44,6 +44,7 @@ int vlsat_set_edge_attention_scope(vlsat_handle h, int32_t scope) {
 //   "flash_split" 0|1   split-key edge attention for plans that cannot fill the chip (plans created afterwards)
 //   "prof_dual"   0|1   per-class profiling keeps the multi-stream execution (1, default) or serialises on the launch stream
 //   "pair_twins" 0|1 / "pair_max_edges" n   paired schedule of one-scene plans (engine_forward.hip): twin stages as launches of two problems
+//   "gather_f16" -1|0|1    [P_i | P_j] of the node-side projection as fp16 half rows (-1: on in the single-rounding modes)
 //   "gemm_k_rot" -1|0..7   K-tile rotation per column tile of the 8-phase GEMM (-1: 1 for half-row bf16 launches, else 0)
 //   "gemm_p8" / "gemm_dma" / "gemm_splitk" 0|1   GEMM kernel selection: 256 x 256 8-phase kernel for large launches, LDS-direct staging of
 //                       fp32 operands, split-K kernel for small launches (0: the older kernels; parity-tested both ways)
@@ -68,6 +69,7 @@ int vlsat_debug_option(vlsat_handle h, const char* name, int32_t value) {
     else if (k == "gemm_p8") h->gemm_no_p8 = value == 0;
     else if (k == "pair_twins") h->pair_twins = value != 0;
     else if (k == "pair_max_edges") h->pair_max_edges = value < 0 ? 0 : value;
+    else if (k == "gather_f16") h->gather_f16 = value < 0 ? -1 : value != 0;
     else if (k == "gemm_k_rot") h->gemm_k_rot = value < 0 ? -1 : value > 7 ? 7 : value;
     else if (k == "gate_row_map") h->gate_row_map = value != 0;
     else if (k == "prof_dual") h->prof_dual = value != 0;
@@ -156,7 +158,10 @@ int vlsat_k_gemm_planes(const float* A, int32_t lda, const float* W, const uint1
     a.prec = prec; a.Whi = Whi; a.Wlo = Wlo; a.no_dma = no_dma; a.prefetch = prefetch;
     const int code = (fmt >> 5) & 1 ? 2 : 1;   // (bit 5: the flagged operands are half rows instead of split pairs)
     a.a_split = (fmt & 1) * code; a.r_split = ((fmt >> 1) & 1) * code; a.c_split = ((fmt >> 2) & 1) * code; a.c_scale = c_scale;
-    // (bit 3: free; bit 4: no ring kernel -- benchmarking)
+    // (bit 3: g0 / g1 are fp16 half rows; bits 25..28: that many times 256 leading columns of C are written as fp16 half rows -- GemmArgs::g_f16,
+    //  c_f16_cols; bit 4: no ring kernel -- benchmarking)
+    a.g_f16 = (fmt >> 3) & 1;
+    a.c_f16_cols = ((fmt >> 25) & 15) * 256;
     a.no_ring = (fmt >> 4) & 1;
     a.no_p8 = (fmt >> 12) & 1;                 // (bit 12: half-row launches skip the 256 x 256 8-phase kernel)
     a.k_rot = (fmt >> 22) & 7;                 // (bits 22..24: K-tile rotation per column tile of the 8-phase kernel -- A/B)

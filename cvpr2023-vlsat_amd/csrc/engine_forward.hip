@@ -183,7 +183,9 @@ int kv_project(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const AttnW& w, con
 // node side of a GraphEdgeAttenNetwork block: NP [N, 6D + A] = [P_i | P_j | Gq | value]
 int gcn_node_project(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const GcnW& w, const float* x, const Scratch& sc) {
     const int N = (int)p->N, D = h->D, NPC = npc_of(h);
-    return gemm(h, s, G(x, ldx_of(h), w.wnode, D, sc.NP, NPC, N, NPC, w.bnode));
+    GemmArgs np = G(x, ldx_of(h), w.wnode, D, sc.NP, NPC, N, NPC, w.bnode);
+    if (gather_f16_on(h)) np.c_f16_cols = 4 * D;                 // [P_i | P_j] as fp16 half rows (what nn_edge.0 gathers per edge: half the bytes)
+    return gemm(h, s, np);
 }
 
 // node_done: sc.NP has already been filled by gcn_node_project (on another lane; the caller has ordered this lane behind it)
@@ -199,7 +201,8 @@ int gcn_block(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const GcnW& w, float
     e1.relu_a = e_relu_pending;
     e1.a_split = S; e1.c_split = S;
     e1.g0 = sc.NP; e1.gi0 = p->d_src; e1.ldg0 = NPC;
-    e1.g1 = sc.NP + 2 * D; e1.gi1 = p->d_dst; e1.ldg1 = NPC;
+    e1.g_f16 = gather_f16_on(h);
+    e1.g1 = sc.NP + (e1.g_f16 ? D : 2 * D); e1.gi1 = p->d_dst; e1.ldg1 = NPC;       // (fp16 half rows: P_j starts at byte 2 * 2D of the row)
     RUN(gemm(h, s, e1));
     if (h->d.use_gcn_edge) {              // proj_edge feeds only the gate MLP (reference network_MMG.py:98-102)
         GemmArgs kp = G(e, D, w.wpe, D, sc.KP, D, E, D, w.bpe);
@@ -293,13 +296,18 @@ int gcn_block_pair(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const GcnW& w3,
     const int N = (int)p->N, E = (int)p->E, D = h->D, A = h->A, LDX = ldx_of(h), NPC = npc_of(h);
     const int S = split_fmt(h);
     const bool gate16 = h->prec_edge && h->gate_bf16;
-    RUN(gemm2(h, s, G(x3, LDX, w3.wnode, D, sc3.NP, NPC, N, NPC, w3.bnode), G(x2, LDX, w2.wnode, D, sc2.NP, NPC, N, NPC, w2.bnode)));
+    {
+        GemmArgs n3 = G(x3, LDX, w3.wnode, D, sc3.NP, NPC, N, NPC, w3.bnode), n2 = G(x2, LDX, w2.wnode, D, sc2.NP, NPC, N, NPC, w2.bnode);
+        if (gather_f16_on(h)) n3.c_f16_cols = n2.c_f16_cols = 4 * D;
+        RUN(gemm2(h, s, n3, n2));
+    }
     auto e1_of = [&](const GcnW& w, float* e, int relu, const Scratch& sc) {
         GemmArgs e1 = G(e, D, w.we1, D, sc.Hbig, 2 * D, E, 2 * D, nullptr, ACT_RELU);
         e1.relu_a = relu;
         e1.a_split = S; e1.c_split = S;
         e1.g0 = sc.NP; e1.gi0 = p->d_src; e1.ldg0 = NPC;
-        e1.g1 = sc.NP + 2 * D; e1.gi1 = p->d_dst; e1.ldg1 = NPC;
+        e1.g_f16 = gather_f16_on(h);
+        e1.g1 = sc.NP + (e1.g_f16 ? D : 2 * D); e1.gi1 = p->d_dst; e1.ldg1 = NPC;
         return e1;
     };
     RUN(gemm2(h, s, e1_of(w3, e3, e3_relu_pending, sc3), e1_of(w2, e2, 0, sc2)));

@@ -75,6 +75,28 @@ __device__ __forceinline__ void tile_init(const GemmArgs& p, int m0, int n0, int
     const int li = lv & 31, hi = lv >> 5;
     const bool vec = n0 + (wn * TN + TN) * 32 <= p.N && ((ldr | ldg0 | ldg1) & 3) == 0 &&
                      (!(ADD & 1) || aligned16(p.resid)) && (!(ADD & 2) || aligned16(p.g0)) && (!(ADD & 4) || aligned16(p.g1));
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    if (!(ADD & 1) && !PLAIN && p.g_f16) {       // fp16 half-row tables (GemmArgs::g_f16; the launcher admits them for N % 256 == 0 only: every tile's columns are inside N): 8 bytes per lane and load
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            int m = m0 + (wm * TM + tm) * 32 + li;
+            m = m < p.M ? m : p.M - 1;
+            const _Float16* g0row = (ADD & 2) ? reinterpret_cast<const _Float16*>(p.g0 + (size_t)p.gi0[m] * ldg0) : nullptr;
+            const _Float16* g1row = (ADD & 4) ? reinterpret_cast<const _Float16*>(p.g1 + (size_t)p.gi1[m] * ldg1) : nullptr;
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int col = n0 + (wn * TN + tn) * 32 + 8 * g + 4 * hi;
+                    f32x4 x = {0.f, 0.f, 0.f, 0.f};
+                    if (ADD & 2) x = __builtin_convertvector(*reinterpret_cast<const f16x4*>(g0row + col), f32x4);
+                    if (ADD & 4) x += __builtin_convertvector(*reinterpret_cast<const f16x4*>(g1row + col), f32x4);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[tm][tn][4 * g + c] = x[c];
+                }
+        }
+        return;
+    }
     if (vec) {
         with_format((ADD & 1) && !PLAIN ? p.r_split : 0, [&](auto fmt) {
 #pragma unroll
@@ -128,6 +150,7 @@ __device__ __forceinline__ void tile_init(const GemmArgs& p, int m0, int n0, int
 template <int TM, int TN, bool PLAIN = false>
 __device__ __forceinline__ void tile_epilogue(const GemmArgs& p, int m0, int n0, int BM, int BN, int wm, int wn, int lane,
                                               f32x16 (&acc)[TM][TN]) {
+    const bool c_f16 = !PLAIN && p.c_f16_cols > 0 && n0 + BN <= p.c_f16_cols;      // this block tile's columns are fp16 half rows (GemmArgs::c_f16_cols)
     const int c_split = PLAIN ? 0 : p.c_split;
     int ldc = p.ldc, lv = lane;
     asm volatile("" : "+s"(ldc), "+v"(lv));                          // see tile_init: no LICM of the store offsets
@@ -194,6 +217,30 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& p, int m0, int n0,
                 for (int r = 0; r < 16; ++r) acc[tm][tn][r] *= p.c_scale;
     }
     const bool interior = m0 + BM <= p.M && cols_in && (ldc & 3) == 0 && aligned16(p.C);
+    if (c_f16) {
+        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const int m = m0 + (wm * TM + tm) * 32 + li;
+            _Float16* crow = reinterpret_cast<_Float16*>(p.C + (size_t)(m < p.M ? m : 0) * ldc);
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int col = n0 + (wn * TN + tn) * 32 + 8 * g + 4 * hi;
+                    f32x4 v;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] = fminf(fmaxf(acc[tm][tn][4 * g + c], -65504.f), 65504.f);
+                    const f16x4 hv = __builtin_convertvector(v, f16x4);
+                    if (interior) *reinterpret_cast<f16x4*>(crow + col) = hv;
+                    else if (m < p.M) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) if (col + c < p.N) crow[col + c] = hv[c];
+                    }
+                }
+        }
+        return;
+    }
     if (interior) {
         with_format(c_split, [&](auto fmt) {
             constexpr int FMT = decltype(fmt)::value;

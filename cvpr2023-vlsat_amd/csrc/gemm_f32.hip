@@ -254,7 +254,7 @@ static bool twin_shapes(const GemmArgs& a, const GemmArgs& b) {
            a.ldg0 == b.ldg0 && a.ldg1 == b.ldg1 && a.act == b.act && a.prec == b.prec && a.a_split == b.a_split && a.r_split == b.r_split &&
            a.c_split == b.c_split && a.c_scale == b.c_scale && a.resid_scale == b.resid_scale && !a.bias == !b.bias && !a.resid == !b.resid &&
            !a.g0 == !b.g0 && !a.g1 == !b.g1 && !a.rowscale == !b.rowscale && a.no_dma == b.no_dma && a.no_ring == b.no_ring &&
-           a.no_p8 == b.no_p8 && a.k_rot == b.k_rot && !a.force_tile && !b.force_tile && !a.ablate && !b.ablate && a.prefetch == b.prefetch;
+           a.no_p8 == b.no_p8 && a.k_rot == b.k_rot && a.c_f16_cols == b.c_f16_cols && a.g_f16 == b.g_f16 && !a.force_tile && !b.force_tile && !a.ablate && !b.ablate && a.prefetch == b.prefetch;
 }
 // single round of 64 x 64 tiles, two k-slices per step (what run_tiled<64, 64> launches for T <= G), grid.y = 2
 static int launch_t_twin(const GemmArgs& a, const GemmArgs& b, int n_tiles, int grid, hipStream_t s) {
@@ -304,7 +304,7 @@ int launch_gemm_pair(const GemmArgs& a, const GemmArgs& b, hipStream_t s) {
     // k-slices per step is paired; everything else (8-phase partial rounds, ring kernel, wider tiles, several rounds) is not.
     const long T = (long)((a.M + 63) / 64) * ((a.N + 63) / 64);
     if (T > G || a.K % (2 * BK)) return 1;
-    if (a.N % 256 == 0 && a.K % 128 == 0 && !a.no_dma && !a.no_ring && !a.no_p8 && !a.rowscale) {           // 8-phase partial round?
+    if (a.N % 256 == 0 && a.K % 128 == 0 && !a.no_dma && !a.no_ring && !a.no_p8 && !a.rowscale && !a.c_f16_cols) {           // 8-phase partial round?
         const bool p8_fmt = (a.prec == 1 && a.a_split == 2) || (a.prec == 3 && a.a_split == 1) || (a.prec == 0 && !a.a_split && !a.c_split && !a.r_split);
         const long panels = (a.M + 255) / 256, nbn = a.N / 256, part_min = a.p8_part_min > 0 ? a.p8_part_min : a.prec == 1 ? 32 : (G / 2 * 5) / 8;
         if (p8_fmt && panels * nbn >= part_min) return 1;
@@ -333,6 +333,10 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
         return fail(-1, "gemm: rowscale cannot be combined with resid/g0/g1 (additive operands are accumulator inits)");
     if ((reinterpret_cast<uintptr_t>(a.A) & 15) || (reinterpret_cast<uintptr_t>(a.W) & 15))
         return fail(-1, "gemm: A/W must be 16-byte aligned");
+    if ((a.c_f16_cols || a.g_f16) && a.prec == 0) return fail(-1, "gemm: fp16 half-row columns / tables belong to the bf16 modes (the exact-fp32 kernels read and write fp32)");
+    if (a.c_f16_cols && (a.c_f16_cols % 256 || a.c_f16_cols > a.N || a.c_split)) return fail(-1, "gemm: c_f16_cols must be a multiple of 256 within N of an fp32 output");
+    if (a.g_f16 && (a.resid || !(a.g0 || a.g1) || a.N % 256 || ((a.ldg0 | a.ldg1) & 1) || ((reinterpret_cast<uintptr_t>(a.g0) | reinterpret_cast<uintptr_t>(a.g1)) & 7)))
+        return fail(-1, "gemm: g_f16 needs gathered rows, no residual, N % 256 == 0 and 8-byte aligned tables");
     const int G = slots();
     auto blocks = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
     if (a.sk_ws && !a.clock_probe) {                  // small launch: k range spread over otherwise idle CUs
@@ -342,7 +346,7 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
     // Large M; exact fp32, single-rounding bf16 with half-row operands or split-bf16 with split-pair operands: the full rounds of 256 x 256 tiles go to the 8-phase
     // kernel (gemm_bf16_p8.hip: one 8-wave block per CU), the remaining row panels to the kernels below
     if (((a.prec == 1 && a.a_split == 2) || (a.prec == 3 && a.a_split == 1) || (a.prec == 0 && !a.a_split && !a.c_split && !a.r_split)) && !a.no_dma && !a.no_ring &&
-        !a.no_p8 && !a.rowscale && !a.clock_probe && a.N % 256 == 0 && a.K % 128 == 0 &&
+        !a.no_p8 && !a.rowscale && !a.clock_probe && !a.c_f16_cols && a.N % 256 == 0 && a.K % 128 == 0 &&
         ((size_t)a.M + 256) * a.lda * 4 < (1ull << 32) && ((size_t)a.M + 256) * a.ldc * 4 < (1ull << 32) &&
         ((size_t)a.N + 256) * a.ldw * 4 < (1ull << 32)) {
         const int G1 = G / 2;

@@ -39,6 +39,10 @@ struct GemmArgs {
     int p8_part_min = 0;                        // 8-phase kernel: tiles from which a remainder rides along as balanced rounds / a partial round (0: the built-in bound, 32 in bf16, 5/8 of a round otherwise)
     int sk_max_tiles = 0;                       // split-K kernel only for launches of at most this many 64 x 64 tiles (0: half the resident slots, the rule of rounds 2-5)
     int k_rot = 0;                              // A-B: the column tiles of a row panel walk their K-tiles rotated by tn * k_rot (8-phase kernel: siblings re-read the A panel out of step)
+    // fp16 additive tables (round 6; the single-rounding modes): the first c_f16_cols columns of C (a multiple of the block tile's width) are
+    // stored as fp16 HALF ROWS (element n at byte 2 n of the fp32-pitched row, values clamped to +-65504) -- what the node-side projection
+    // writes for [P_i | P_j]; g_f16: g0 / g1 are such half rows (launches without a residual).  Halves the bytes nn_edge.0 gathers per edge.
+    int c_f16_cols = 0, g_f16 = 0;
     int force_tile = 0;                         // experiment (tools/gemm_tile_sweep.py): 1 = 128x128, 2 = 128x64, 3 = 64x128, 4 = 64x64 tiles of gemm_f32_kernel, whatever the heuristic says
     int prefetch = -1;                          // bf16 LDS-direct pipe: slices of look-ahead of the A-panel prefetch (0 off, -1 default)
     int no_dma = 0;                             // debug: VGPR-staged fp32 operands instead of LDS-direct (vlsat_debug_option "gemm_dma")

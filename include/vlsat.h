@@ -190,7 +190,9 @@ int vlsat_k_split_bf16(const float* w, size_t n, uint16_t* hi, uint16_t* lo, voi
  * look-ahead of the A-panel prefetch (0 = off, -1 = default).  fmt: bit 0 = A, bit 1 = resid, bit 2 = C are in the
  * split-pair format of the split-bf16 mode (one 32-bit word per element: bf16 hi = rne(x) in the upper half, bf16 lo =
  * rne(x - hi) in the lower half) or, with bit 5 set, in the half-row format of the single-rounding modes (bf16 values
- * at byte 2 * column of the fp32-pitched row; prec 1 only); bits 4 / 6 / 7 are benchmarking switches (
+ * at byte 2 * column of the fp32-pitched row; prec 1 only); bit 3: g0 / g1 are FP16 half rows (fp16 values at byte 2 * column of the
+ * fp32-pitched table row; no residual, N % 256 == 0), bits 25..28: k = that many times 256 leading columns of C are written as fp16 half
+ * rows, clamped to +-65504 (the node-side projection's [P_i | P_j], which nn_edge.0 gathers per edge); bits 4 / 6 / 7 are benchmarking switches (
  * no ring kernel, small launches on the split-K kernel, ring kernel with 128 x 256 tiles; bits 10 / 11: its
  * 32-wide k slices / single fragment set in the half-row mode) and bits 8 / 9 timing
  * ablations (no operand loads / no MFMAs: garbage results); c_scale multiplies C
@@ -402,6 +404,10 @@ int vlsat_debug_gemm_clock_probe(int64_t* buf);
  *   "gemm_k_rot" -1|0..7  8-phase GEMM: column tile tn of a row panel walks its K-tiles starting at tn * r (the blocks that share an A
  *                         panel ask L2 for its lines out of step); -1 = default: 1 for half-row bf16 launches, 0 otherwise.  Rotates an
  *                         fp32 summation order: inside every mode's tolerance (tests/test_hip_round6.py), not bit-identical;
+ *   "gather_f16" -1|0|1   the node-side tables [P_i | P_j] that nn_edge.0 adds per edge (reference network_MMG.py:59-60,92: cat[x_i, e, x_j] as
+ *                         three partial products) as fp16 half rows instead of fp32: half the gathered bytes, 2^-12 relative rounding of two
+ *                         summands in front of a ReLU whose output is rounded to bf16 anyway; -1 = default: on in the single-rounding modes
+ *                         (bf16_mixed, bf16), off in the split-bf16 ones, never in fp32;
  *   "split_fmt", "flash_bf16", "flash_tr", "pointnet_bf16", "gate_bf16", "ln_resid" 0|1   bf16 modes: tensor formats and kernels (0: the
  *                         fp32 forms) -- every one parity-tested both ways (tests/test_hip_forward.py);
  *   "flash_bq_big" 0|1    half-row edge attention, plans whose scenes all have >= 4096 edges: 256 queries per block (default) or 128;

@@ -646,6 +646,80 @@ def test_gemm_bf16_p8_kernel(lib, N, K, resid, gather, relu_a, act, c_half):
     assert float((got.double() - ref).abs().max()) <= tol
 
 
+@pytest.mark.parametrize("M", [300, 2560, 256 * 128 + 256 * 9 + 77])
+def test_gemm_fp16_half_row_tables(lib, M):
+    """The node-side tables of nn_edge.0 as fp16 half rows (round 6; GemmArgs::c_f16_cols / g_f16, fmt bits 25..28 / 3 of
+    vlsat_k_gemm_planes; reference network_MMG.py:59-60,92 -- cat[x_i, e, x_j] . W^T as three partial products).
+    Producer: a split-bf16 launch on fp32 rows writes its first 512 of 1024 columns as fp16 (element n at byte 2 n of the row), the rest as
+    fp32 -- checked against the same launch with an fp32 output, rounded to fp16 on the host (bit for bit) -- on the 64 x 64 / 64 x 128
+    kernels, the split-K kernel (M = 300, fmt bit 6) and the ring kernel.  Consumer: a half-row launch that gathers [P_i | P_j] from such
+    a table must equal, BIT FOR BIT, the launch that gathers the same (fp16-representable) values from an fp32 table -- 8-phase kernel
+    with a ragged last panel, the older kernels (M = 2560, 300)."""
+    l = lib.load()
+    g = torch.Generator().manual_seed(M)
+    K, N = 512, 1024
+    hi = torch.empty(N * K + 128, dtype=torch.int16, device=DEV)
+    lo = torch.empty_like(hi)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    lib.check(l.vlsat_k_split_bf16(W.data_ptr(), N * K, hi.data_ptr(), lo.data_ptr(), lib.stream_ptr()))
+    # ---- producer ----
+    Mp = min(M, 2560)
+    X = torch.randn(Mp, K, generator=g).to(DEV)
+
+    def produce(f):
+        C = torch.full((Mp, N), float("nan"), device=DEV)
+        lib.check(l.vlsat_k_gemm_planes(X.data_ptr(), K, W.data_ptr(), hi.data_ptr(), lo.data_ptr(), K, C.data_ptr(), N, Mp, N, K, b.data_ptr(),
+                                        0, 0, 0.0, 0, 0, 0, 0, 0, 0, 0, 0, 3, 0, -1, f, 1.0, lib.stream_ptr()))
+        _sync()
+        return C.cpu()
+    for extra in (0, 64, 16):                                  # default cascade / small launches on the split-K kernel / no ring kernel
+        plain, mixed = produce(extra), produce(extra | (2 << 25))
+        as16 = mixed.view(torch.float16).view(Mp, 2 * N)
+        assert torch.equal(as16[:, :512], plain[:, :512].clamp(-65504, 65504).half()), extra
+        assert torch.equal(mixed[:, 512:], plain[:, 512:]), extra
+        assert bool(torch.isnan(mixed[:, 256:512]).all())       # bytes 1024..2047 of a row belong to nobody
+    # ---- consumer ----
+    NG, Nc = 777, 512
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16).float()
+    Ah = _to_half_rows(A).to(DEV)
+    tab16 = (torch.randn(NG, 2 * Nc, generator=g) * 3).half()
+    tab32 = tab16.float().to(DEV)                               # [P_i | P_j] as fp32, pitch 2 Nc floats
+    buf = torch.zeros(NG, 2 * Nc + 64)                          # the same values as half rows of a row with another pitch
+    buf.view(torch.float16).view(NG, 2 * (2 * Nc + 64))[:, :2 * Nc] = tab16
+    buf = buf.to(DEV)
+    rows, node = [], 0
+    while len(rows) < M:
+        rows += [node % NG] * 39
+        node += 1
+    gi0 = torch.tensor(rows[:M], dtype=torch.int32).to(DEV)
+    gi1 = torch.randint(0, NG, (M,), generator=g, dtype=torch.int32).to(DEV)
+    hic = hi[:Nc * K + 128]
+    Wc = W[:Nc].contiguous()
+    lib.check(l.vlsat_k_split_bf16(Wc.data_ptr(), Nc * K, hic.data_ptr(), lo.data_ptr(), lib.stream_ptr()))
+
+    def consume(f16, f):
+        C = torch.full((M, Nc), float("nan"), device=DEV)
+        t, ld, off = (buf, 2 * Nc + 64, 2 * Nc) if f16 else (tab32, 2 * Nc, 4 * Nc)     # P_j: Nc halfs / Nc floats into the row
+        lib.check(l.vlsat_k_gemm_planes(Ah.data_ptr(), K, Wc.data_ptr(), hic.data_ptr(), lo.data_ptr(), K, C.data_ptr(), Nc, M, Nc, K, 0,
+                                        0, 0, 0.0, t.data_ptr(), gi0.data_ptr(), ld, t.data_ptr() + off, gi1.data_ptr(), ld,
+                                        1, 1, 1, 0, -1, f | (8 if f16 else 0), 1.0, lib.stream_ptr()))
+        _sync()
+        return _from_half_rows(C.cpu(), Nc)
+    base = 32 | 1 | 4
+    for extra in (0, 16 | (1 << 12)):                           # the shipped cascade (8-phase kernel for the large M) / the older kernels only
+        a, c = consume(True, base | extra), consume(False, base | extra)
+        assert torch.isfinite(a).all() and torch.equal(a, c), extra
+    ref = torch.relu(torch.relu(A).double() @ Wc.cpu().to(torch.bfloat16).double().t() + tab16.double()[gi0.cpu().long(), :Nc] + tab16.double()[gi1.cpu().long(), Nc:])
+    assert float((a.double() - ref).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
+    # misuse is refused: fp16 tables next to a residual
+    C = torch.empty(M, Nc, device=DEV)
+    r = l.vlsat_k_gemm_planes(Ah.data_ptr(), K, Wc.data_ptr(), hic.data_ptr(), lo.data_ptr(), K, C.data_ptr(), Nc, M, Nc, K, 0, C.data_ptr(), Nc, 1.0,
+                              buf.data_ptr(), gi0.data_ptr(), 2 * Nc + 64, buf.data_ptr() + 2 * Nc, gi1.data_ptr(), 2 * Nc + 64, 0, 0, 1, 0, -1, base | 8, 1.0,
+                              lib.stream_ptr())
+    assert r != 0
+
+
 @pytest.mark.parametrize("tail", [5, 90])          # remainder panels: 5 -> small kernels; 90 (+ 33 rows) -> a partial 8-phase round WITH the ragged last panel
 @pytest.mark.parametrize("N,K,resid,gather,relu_a,act", [(512, 512, 0, 0, 0, 1), (1024, 128, 0, 0, 1, 0), (512, 1024, 1, 0, 0, 0), (1024, 512, 0, 1, 0, 1)])
 def test_gemm_f32_p8_kernel_is_bit_identical(lib, N, K, resid, gather, relu_a, act, tail):

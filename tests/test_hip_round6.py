@@ -118,3 +118,34 @@ def test_paired_schedule_through_the_evaluation_loop():
         got = EV.validation(m, items, device=DEV, workers=k)
         assert got == ref, [q for q in ref if got[q] != ref[q]]
     m.close()
+
+
+def test_fp16_node_tables_of_nn_edge_0():
+    """"gather_f16": [P_i | P_j] of the node-side projection (the x_i and x_j parts of nn_edge's first Linear, reference
+    network_MMG.py:59-60,92, hoisted to node rows) stored as fp16 half rows and gathered per edge by nn_edge.0 -- default in the
+    single-rounding modes, off in the split-bf16 ones, never in fp32.  Against the CPU oracle on a batch that takes the 8-phase kernel
+    (E = 68 640) and on one-scene plans (the paired schedule's twin launches): bf16_mixed stays inside 1e-2 with and without, the two differ
+    (the switch reaches the kernels) by less than the tolerance; bf16x3's default equals "off" bit for bit and its forced "on" stays inside
+    1e-3; fp32 ignores the switch bit for bit."""
+    from oracle import vlsat_oracle as O
+    cfg = VLSATConfig(N_LAYERS=2)
+    w = synth.make_weights(cfg)
+    cases = [_batch(44, 40, 32, seed0=4500), _batch(1, 26, 32, seed0=4501), _batch(1, 1, 32, seed0=4502)]
+    for b, d in cases:
+        c = {k: torch.from_numpy(v) for k, v in b.items()}
+        ref = O.forward(O.to_torch(w), cfg, c["obj_points"], c["obj_2d_feats"], c["edge_indices"], c["descriptor"], c["batch_ids"])
+        outs = {}
+        for precision, tol in (("bf16_mixed", 1e-2), ("bf16x3", 1e-3), ("fp32", 1e-3)):
+            for v in (-1, 0, 1):
+                m = VLSATModel(cfg, DEV).load_state(w).eval().set_gemm_precision(precision).debug_option("gather_f16", v)
+                outs[precision, v] = _run(m, d)
+                m.close()
+                for n, g, x in zip(NAMES, outs[precision, v], ref):
+                    assert g.numel() == 0 or float((g.cpu() - x).abs().max()) < tol, (precision, v, n)      # (one object: no relation rows)
+        same = lambda a, b_: all(torch.equal(x, y) for x, y in zip(a, b_))
+        assert same(outs["bf16_mixed", -1], outs["bf16_mixed", 1]) and same(outs["bf16x3", -1], outs["bf16x3", 0])
+        assert same(outs["fp32", 1], outs["fp32", 0]) and same(outs["fp32", -1], outs["fp32", 0])
+        if d["edge_indices"].shape[1]:
+            assert not same(outs["bf16_mixed", 0], outs["bf16_mixed", 1]) and not same(outs["bf16x3", 0], outs["bf16x3", 1])
+            diff = max(float((x - y).abs().max()) for x, y in zip(outs["bf16_mixed", 0], outs["bf16_mixed", 1]))
+            assert diff < 1e-2, diff               # (two realisations of the mode's rounding noise: each inside 1e-2 of the oracle above)
