@@ -98,6 +98,7 @@ struct vlsat_ctx {
     int pair_twins = 1;                      // one-scene plans (E <= pair_max_edges): the 3D / 2D twin stages as launches of two problems each (engine_forward.hip, "paired schedule"; vlsat_debug_option "pair_twins")
     int pair_max_edges = 4096;               // ... and the plan size up to which that schedule is used ("pair_max_edges")
     int gather_f16 = -1;                     // vlsat_debug_option "gather_f16": [P_i | P_j] of the node-side projection as fp16 half rows; -1 (default) = on in the single-rounding modes (prec_edge 1), 0 / 1
+    int outproj_f16 = -1;                    // vlsat_debug_option "outproj_f16": the out-projection of a single-rounded edge attention writes fp16 half rows for its LayerNorm; -1 (default) = on, 0 / 1
     int gemm_k_rot = -1;                     // vlsat_debug_option "gemm_k_rot": K-tile rotation per column tile of the 8-phase GEMM; -1 (default) = 1 for half-row bf16 launches, 0 otherwise
     int gemm_no_p8 = 0;                      // vlsat_debug_option "gemm_p8": 0 keeps half-row launches off the 8-phase kernel
     int node_attn_split = 1024;              // node attention: sixteen lanes per query when the plan has fewer waves than this

@@ -45,6 +45,7 @@ int vlsat_set_edge_attention_scope(vlsat_handle h, int32_t scope) {
 //   "prof_dual"   0|1   per-class profiling keeps the multi-stream execution (1, default) or serialises on the launch stream
 //   "pair_twins" 0|1 / "pair_max_edges" n   paired schedule of one-scene plans (engine_forward.hip): twin stages as launches of two problems
 //   "gather_f16" -1|0|1    [P_i | P_j] of the node-side projection as fp16 half rows (-1: on in the single-rounding modes)
+//   "outproj_f16" -1|0|1   out-projection of the single-rounded edge attention -> LayerNorm as fp16 half rows instead of fp32 (-1: on)
 //   "gemm_k_rot" -1|0..7   K-tile rotation per column tile of the 8-phase GEMM (-1: 1 for half-row bf16 launches, else 0)
 //   "gemm_p8" / "gemm_dma" / "gemm_splitk" 0|1   GEMM kernel selection: 256 x 256 8-phase kernel for large launches, LDS-direct staging of
 //                       fp32 operands, split-K kernel for small launches (0: the older kernels; parity-tested both ways)
@@ -70,6 +71,7 @@ int vlsat_debug_option(vlsat_handle h, const char* name, int32_t value) {
     else if (k == "pair_twins") h->pair_twins = value != 0;
     else if (k == "pair_max_edges") h->pair_max_edges = value < 0 ? 0 : value;
     else if (k == "gather_f16") h->gather_f16 = value < 0 ? -1 : value != 0;
+    else if (k == "outproj_f16") h->outproj_f16 = value < 0 ? -1 : value != 0;
     else if (k == "gemm_k_rot") h->gemm_k_rot = value < 0 ? -1 : value > 7 ? 7 : value;
     else if (k == "gate_row_map") h->gate_row_map = value != 0;
     else if (k == "prof_dual") h->prof_dual = value != 0;

@@ -761,10 +761,14 @@ static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const fl
             GemmArgs o = G(p->Oe, D, w.wo, D, pre_ln, D, E, D, w.bo);
             if (!ln_resid) { o.resid = p->E2; o.ldr = D; o.r_split = S; }
             o.a_split = SA;
+            // single-rounded attention (half-row O): pre_ln has one reader, the LayerNorm below -- fp16 half rows instead of fp32 (2^-12 in
+            // front of a normalisation whose output is rounded to bf16 / split pairs: not visible in the mode's error; half the bytes both ways)
+            const bool o16 = ln_resid && SA == 2 && h->outproj_f16 != 0 && D % 256 == 0;
+            if (o16) o.c_f16_cols = D;
             RUN(gemm(h, fs, o, PA));
             {
                 Scope sc(h, fs, PC_LAYERNORM, 0);
-                RUN(launch_layernorm_to(pre_ln, D, p->E2, D, E, D, w.lng, w.lnb, inter, S, fs, ln_resid ? p->E2 : nullptr, D, S));
+                RUN(launch_layernorm_to(pre_ln, D, p->E2, D, E, D, w.lng, w.lnb, inter, S, fs, ln_resid ? p->E2 : nullptr, D, S, o16 ? 1 : 0));
             }
             if (pair) RUN(after(t, &edge_done));
         }

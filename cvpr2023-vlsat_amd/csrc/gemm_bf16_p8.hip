@@ -55,7 +55,8 @@ constexpr int P8_TBASE = 8 * P8_HALF;         // wave-private transposition buff
 // (ABL bit 4: no barrier after the MFMA clusters, bit 5: no barrier in the K loop at all -- timing experiments)
 enum { P8_MID = 0, P8_LAST = 1, P8_FIRST = 2, P8_SECOND = 3, P8_FIRST0 = 4 };   // FIRST0: first K-tile of a tile without strips of a previous one
 
-// CF: storage format of C (0 fp32, 2 half rows).  ABL (timing experiments, results are garbage): bit 0 no LDS-direct
+// CF: storage format of C (0 fp32, 2 half rows of bf16, 3 half rows of FP16 clamped to +-65504 -- the out-projection of the single-rounded edge
+// attention, whose only reader is the LayerNorm: round 6).  ABL (timing experiments, results are garbage): bit 0 no LDS-direct
 // loads after the prologue, bit 1 no MFMAs, bit 2 no fragment reads, bit 3 no epilogue stores
 // F32: exact-fp32 operands (A fp32 rows, W fp32 [N,K], v_mfma_f32_32x32x2_f32, K-tiles of 32): the same LDS image -- 128-byte
 // rows, a lane's fragment is the 16-byte chunk 2 ks + hi = four consecutive k (gemm_core.h, K-permutation trick) -- so
@@ -75,14 +76,15 @@ enum { P8_MID = 0, P8_LAST = 1, P8_FIRST = 2, P8_SECOND = 3, P8_FIRST0 = 4 };   
 template <int MODE, int ADD, bool RELU, int CF, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmArgs p, int n_tiles, int nbn) {
     constexpr bool F32 = MODE == 1, X3 = MODE == 2, WORDS = MODE != 0;      // WORDS: 4-byte A elements, K-tiles of 32
-    static_assert(MODE == 0 ? (CF == 0 || CF == 2) : F32 ? CF == 0 : (CF == 0 || CF == 1), "output format of the mode");
+    static_assert(MODE == 0 ? (CF == 0 || CF == 2 || CF == 3) : F32 ? CF == 0 : (CF == 0 || CF == 1), "output format of the mode");
     __shared__ __attribute__((aligned(16))) char smem[10 * P8_HALF];
     typedef short s16x8 __attribute__((ext_vector_type(8)));
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     constexpr bool SPREAD = ADD == 0;             // epilogue strips 2 / 3 inside the next tile's first K-tile
     // (ABL bits 8, 9, gathered-row launches: 256 = the init loads in a row-contiguous lane pattern, 512 = no init loads)
-    constexpr int E = CF == 2 ? 4 : 8;            // buffer stores per epilogue strip and lane
+    constexpr bool HALF = CF >= 2;                // two bytes per element of C
+    constexpr int E = HALF ? 4 : 8;            // buffer stores per epilogue strip and lane
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -302,7 +304,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmArgs p, int n_tiles
     // (half rows: a lane writes 8 bytes; rows li and li + 8 of a 16-lane write group name the same chunk, so the upper eight
     //  rows take the chunk's OTHER half -- 32 distinct banks per group instead of a 2-way conflict (PMC, round 3: 10-12 % of the
     //  LDS cycles of the half-row launches) -- and the reader swaps the halves back for those rows, a register renaming)
-    const int t_wr = li * 128 + (CF == 2 ? (hi ^ ((li >> 3) & 1)) * 8 : 0), t_x = (li & 7) << 4;
+    const int t_wr = li * 128 + (HALF ? (hi ^ ((li >> 3) & 1)) * 8 : 0), t_x = (li & 7) << 4;
     const int t_rd = (lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 3) & 7)) << 4);
     const unsigned ldc4 = (unsigned)p.ldc * 4u;
     const unsigned vst = (unsigned)(lane >> 3) * ldc4 + (unsigned)(lane & 7) * 16u;
@@ -320,7 +322,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmArgs p, int n_tiles
         typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         typedef short s16x2 __attribute__((ext_vector_type(2)));
-        const unsigned srow = (unsigned)(m0 + wr * 128 + TM * 32) * ldc4 + (unsigned)(n0 + wc * 64) * (CF == 2 ? 2u : 4u);
+        const unsigned srow = (unsigned)(m0 + wr * 128 + TM * 32) * ldc4 + (unsigned)(n0 + wc * 64) * (HALF ? 2u : 4u);
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn) {
 #pragma unroll
@@ -332,12 +334,21 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmArgs p, int n_tiles
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         if (ACTV == 2) v[c] = fmaxf(v[c], act_lo) * cs;      // (branch-free: ReLU or max with -inf)
-                        else if (ACTV == 1 && CF != 2) v[c] = relu1(v[c]);
+                        else if (ACTV == 1 && !HALF) v[c] = relu1(v[c]);
                     }
                 }
-                if (CF == 2) {
-                    s16x2 w0 = __builtin_bit_cast(s16x2, __builtin_convertvector((f32x2{v[0], v[1]}), bf16x2));
-                    s16x2 w1 = __builtin_bit_cast(s16x2, __builtin_convertvector((f32x2{v[2], v[3]}), bf16x2));
+                if (HALF) {
+                    s16x2 w0, w1;
+                    if (CF == 3) {
+                        typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) v[c] = __builtin_amdgcn_fmed3f(v[c], -65504.f, 65504.f);
+                        w0 = __builtin_bit_cast(s16x2, __builtin_convertvector((f32x2{v[0], v[1]}), f16x2));
+                        w1 = __builtin_bit_cast(s16x2, __builtin_convertvector((f32x2{v[2], v[3]}), f16x2));
+                    } else {
+                        w0 = __builtin_bit_cast(s16x2, __builtin_convertvector((f32x2{v[0], v[1]}), bf16x2));
+                        w1 = __builtin_bit_cast(s16x2, __builtin_convertvector((f32x2{v[2], v[3]}), bf16x2));
+                    }
                     if (ACTV == 1) {          // ReLU after the rounding: the same values (rounding keeps the sign; -0 becomes +0)
                         w0 = __builtin_elementwise_max(w0, s16x2{0, 0});
                         w1 = __builtin_elementwise_max(w1, s16x2{0, 0});
@@ -350,14 +361,14 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmArgs p, int n_tiles
                     *reinterpret_cast<f32x4*>(tbuf + t_wr + (((2 * g + hi) << 4) ^ t_x)) = v;
                 }
             }
-            if (CF != 2 || tn == 1) {          // the buffer holds 32 rows x 128 bytes: both n-tiles (bf16) or one (fp32)
+            if (!HALF || tn == 1) {          // the buffer holds 32 rows x 128 bytes: both n-tiles (bf16) or one (fp32)
                 u32x4 rj[4];                   // (all four reads in flight before the first store waits for its data)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) rj[j] = *reinterpret_cast<const u32x4*>(tbuf + t_rd + j * 1024);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     u32x4 r = rj[j];
-                    if (CF == 2 && (j & 1)) r = u32x4{rj[j][2], rj[j][3], rj[j][0], rj[j][1]};      // rows 8 j + (lane >> 3): halves stored swapped
+                    if (HALF && (j & 1)) r = u32x4{rj[j][2], rj[j][3], rj[j][0], rj[j][1]};      // rows 8 j + (lane >> 3): halves stored swapped
                     if (WORDS) {               // lane: row 8j + (l >> 3), columns tn*32 + 4 (l & 7) .. +3
                         f32x4 x = __builtin_bit_cast(f32x4, r) + biasr[tn];
 #pragma unroll
@@ -383,7 +394,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmArgs p, int n_tiles
                         }
                     }
                     if (!(ABL & 8)) {
-                        __builtin_amdgcn_raw_buffer_store_b128(r, rc, vst, srow + (unsigned)(8 * j) * ldc4 + (CF == 2 ? 0u : (unsigned)tn * 128u), 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(r, rc, vst, srow + (unsigned)(8 * j) * ldc4 + (HALF ? 0u : (unsigned)tn * 128u), 0);
                         // A 128-bit buffer store reads its data registers a few cycles after issue; hipcc pads a following VALU
                         // write of them ONLY when the store has no SGPR soffset (LLVM's hazard rule assumes the register form is
                         // safe) -- on gfx950 it is not: split-pair epilogues, whose pack code reuses the registers at once, stored
@@ -565,6 +576,8 @@ int launch_gemm_p8(const GemmArgs& a, int n_tiles, int grid, hipStream_t s) {
     if (grid % 8 || (grid / 8) % nbn) return 1;      // the kernel keeps one column tile per block (bias registers)
 #define VLSAT_P8(MODE, ADD, RELU, CF) hipLaunchKernelGGL((gemm_p8_kernel<MODE, ADD, RELU, CF>), dim3(grid), dim3(512), 0, s, a, n_tiles, nbn)
 #define VLSAT_P8_ABL(X) hipLaunchKernelGGL((gemm_p8_kernel<0, 0, false, 2, X>), dim3(grid), dim3(512), 0, s, a, n_tiles, nbn)
+    const bool c16 = a.c_f16_cols > 0;            // (the whole output as fp16 half rows: half-row launches without additive operands only)
+    if (c16 && (a.c_f16_cols != a.N || f32 || x3 || add || a.c_split || a.relu_a)) return 1;
     const int key = add * 4 + (a.relu_a ? 2 : 0) + (a.c_split ? 1 : 0);
     if (f32) {
         switch (key) {
@@ -609,7 +622,7 @@ int launch_gemm_p8(const GemmArgs& a, int n_tiles, int grid, hipStream_t s) {
 #endif
     } else {
         switch (key) {
-            case 0: VLSAT_P8(0, 0, false, 0); break;
+            case 0: if (c16) VLSAT_P8(0, 0, false, 3); else VLSAT_P8(0, 0, false, 0); break;
             case 1: VLSAT_P8(0, 0, false, 2); break;
             case 2: VLSAT_P8(0, 0, true, 0); break;
             case 3: VLSAT_P8(0, 0, true, 2); break;

@@ -304,7 +304,7 @@ int launch_gemm_pair(const GemmArgs& a, const GemmArgs& b, hipStream_t s) {
     // k-slices per step is paired; everything else (8-phase partial rounds, ring kernel, wider tiles, several rounds) is not.
     const long T = (long)((a.M + 63) / 64) * ((a.N + 63) / 64);
     if (T > G || a.K % (2 * BK)) return 1;
-    if (a.N % 256 == 0 && a.K % 128 == 0 && !a.no_dma && !a.no_ring && !a.no_p8 && !a.rowscale && !a.c_f16_cols) {           // 8-phase partial round?
+    if (a.N % 256 == 0 && a.K % 128 == 0 && !a.no_dma && !a.no_ring && !a.no_p8 && !a.rowscale && (!a.c_f16_cols || a.c_f16_cols == a.N)) {           // 8-phase partial round?
         const bool p8_fmt = (a.prec == 1 && a.a_split == 2) || (a.prec == 3 && a.a_split == 1) || (a.prec == 0 && !a.a_split && !a.c_split && !a.r_split);
         const long panels = (a.M + 255) / 256, nbn = a.N / 256, part_min = a.p8_part_min > 0 ? a.p8_part_min : a.prec == 1 ? 32 : (G / 2 * 5) / 8;
         if (p8_fmt && panels * nbn >= part_min) return 1;
@@ -346,7 +346,7 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
     // Large M; exact fp32, single-rounding bf16 with half-row operands or split-bf16 with split-pair operands: the full rounds of 256 x 256 tiles go to the 8-phase
     // kernel (gemm_bf16_p8.hip: one 8-wave block per CU), the remaining row panels to the kernels below
     if (((a.prec == 1 && a.a_split == 2) || (a.prec == 3 && a.a_split == 1) || (a.prec == 0 && !a.a_split && !a.c_split && !a.r_split)) && !a.no_dma && !a.no_ring &&
-        !a.no_p8 && !a.rowscale && !a.clock_probe && !a.c_f16_cols && a.N % 256 == 0 && a.K % 128 == 0 &&
+        !a.no_p8 && !a.rowscale && !a.clock_probe && (!a.c_f16_cols || (a.c_f16_cols == a.N && a.prec == 1 && !a.resid && !a.g0 && !a.g1 && !a.relu_a)) && a.N % 256 == 0 && a.K % 128 == 0 &&
         ((size_t)a.M + 256) * a.lda * 4 < (1ull << 32) && ((size_t)a.M + 256) * a.ldc * 4 < (1ull << 32) &&
         ((size_t)a.N + 256) * a.ldw * 4 < (1ull << 32)) {
         const int G1 = G / 2;

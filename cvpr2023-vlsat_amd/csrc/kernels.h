@@ -135,7 +135,8 @@ int launch_layernorm(float* x, int ld, int rows, int dim, const float* gamma, co
                      hipStream_t s);
 // out of place; out_split = 1 writes the split-pair format of the bf16 modes (common.h pack_split)
 int launch_layernorm_to(const float* x, int ld, float* y, int ldy, int rows, int dim, const float* gamma, const float* beta,
-                        int relu, int out_split, hipStream_t s, const float* resid = nullptr, int ldr = 0, int r_split = 0);
+                        int relu, int out_split, hipStream_t s, const float* resid = nullptr, int ldr = 0, int r_split = 0, int x_f16 = 0);
+// (x_f16: the rows of x are fp16 half rows -- what the out-projection of the single-rounded edge attention writes, GemmArgs::c_f16_cols == N)
 // rowscale[m] = scale / ||x[m,:]||_2  (dim == 512)
 int launch_row_invnorm(const float* x, int ld, int rows, int dim, float scale, float* out, hipStream_t s, const float* x2 = nullptr, float* out2 = nullptr);
 

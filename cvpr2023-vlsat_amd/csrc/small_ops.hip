@@ -86,13 +86,20 @@ int launch_desc_tail(const float* desc, int n_nodes, float* x, int ldx, int col0
 __global__ __launch_bounds__(256) void layernorm512_kernel(const float* __restrict__ x, int ld, float* __restrict__ y, int ldy,
                                                            int rows, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, int relu, int out_split,
-                                                           const float* __restrict__ resid, int ldr, int r_split) {
+                                                           const float* __restrict__ resid, int ldr, int r_split, int x_f16) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float* p = x + (size_t)row * ld;
-    f32x4 a = *reinterpret_cast<const f32x4*>(p + 4 * lane);
-    f32x4 b = *reinterpret_cast<const f32x4*>(p + 256 + 4 * lane);
+    f32x4 a, b;
+    if (x_f16) {                                           // fp16 half rows: element n at byte 2 n
+        typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+        a = __builtin_convertvector(reinterpret_cast<const f16x4_t*>(p)[lane], f32x4);
+        b = __builtin_convertvector(reinterpret_cast<const f16x4_t*>(p)[64 + lane], f32x4);
+    } else {
+        a = *reinterpret_cast<const f32x4*>(p + 4 * lane);
+        b = *reinterpret_cast<const f32x4*>(p + 256 + 4 * lane);
+    }
     if (resid) {
         const float* r = resid + (size_t)row * ldr;
         f32x4 ra, rb;
@@ -147,12 +154,12 @@ int launch_layernorm(float* x, int ld, int rows, int dim, const float* gamma, co
     return launch_layernorm_to(x, ld, x, ld, rows, dim, gamma, beta, relu, 0, s);
 }
 int launch_layernorm_to(const float* x, int ld, float* y, int ldy, int rows, int dim, const float* gamma, const float* beta,
-                        int relu, int out_split, hipStream_t s, const float* resid, int ldr, int r_split) {
+                        int relu, int out_split, hipStream_t s, const float* resid, int ldr, int r_split, int x_f16) {
     if (rows <= 0) return 0;
     if (dim != 512 || (ld & 3) || (ldy & 3) || (resid && ((ldr & 3) || r_split > 2)))
         return fail(-1, "layernorm: dim must be 512, ld a multiple of 4, residual fp32, split pairs or half rows");
     hipLaunchKernelGGL(layernorm512_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, ld, y, ldy, rows, gamma, beta, relu, out_split,
-                       resid, ldr, r_split);
+                       resid, ldr, r_split, x_f16);
     VLSAT_LAUNCH_CHECK("layernorm512");
     return 0;
 }

@@ -408,6 +408,8 @@ int vlsat_debug_gemm_clock_probe(int64_t* buf);
  *                         three partial products) as fp16 half rows instead of fp32: half the gathered bytes, 2^-12 relative rounding of two
  *                         summands in front of a ReLU whose output is rounded to bf16 anyway; -1 = default: on in the single-rounding modes
  *                         (bf16_mixed, bf16), off in the split-bf16 ones, never in fp32;
+ *   "outproj_f16" -1|0|1  the out-projection of a single-rounded edge attention (bf16_mixed, bf16, bf16x3_attn1) hands its rows to the
+ *                         LayerNorm as fp16 half rows instead of fp32 (-1 = default: on);
  *   "split_fmt", "flash_bf16", "flash_tr", "pointnet_bf16", "gate_bf16", "ln_resid" 0|1   bf16 modes: tensor formats and kernels (0: the
  *                         fp32 forms) -- every one parity-tested both ways (tests/test_hip_forward.py);
  *   "flash_bq_big" 0|1    half-row edge attention, plans whose scenes all have >= 4096 edges: 256 queries per block (default) or 128;

@@ -712,6 +712,20 @@ def test_gemm_fp16_half_row_tables(lib, M):
         assert torch.isfinite(a).all() and torch.equal(a, c), extra
     ref = torch.relu(torch.relu(A).double() @ Wc.cpu().to(torch.bfloat16).double().t() + tab16.double()[gi0.cpu().long(), :Nc] + tab16.double()[gi1.cpu().long(), Nc:])
     assert float((a.double() - ref).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
+    # ---- the whole output as fp16 half rows (the out-projection of the single-rounded edge attention; 8-phase kernel CF = 3 for the large M) ----
+    def whole(f):
+        C = torch.full((M, Nc), float("nan"), device=DEV)
+        lib.check(l.vlsat_k_gemm_planes(Ah.data_ptr(), K, Wc.data_ptr(), hic.data_ptr(), lo.data_ptr(), K, C.data_ptr(), Nc, M, Nc, K, b.data_ptr(),
+                                        0, 0, 0.0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, -1, f, 1.0, lib.stream_ptr()))
+        _sync()
+        return C.cpu()
+    for extra in (0, 16 | (1 << 12)):
+        f32out, f16out = whole(32 | 1 | extra), whole(32 | 1 | extra | ((Nc // 256) << 25))
+        got16 = f16out.view(torch.float16).view(M, 2 * Nc)[:, :Nc].float()
+        assert bool(torch.isnan(f16out[:, Nc // 2:]).all())        # the upper half of every row is not written
+        d = (got16 - f32out).abs()
+        assert bool((d <= 2.0 ** -11 * f32out.abs() + 1e-7).all()), float(d.max())       # one fp16 rounding of the fp32 launch's value
+        assert torch.equal(got16, f32out.half().float()) or float((got16 != f32out.half().float()).float().mean()) < 1e-3
     # misuse is refused: fp16 tables next to a residual
     C = torch.empty(M, Nc, device=DEV)
     r = l.vlsat_k_gemm_planes(Ah.data_ptr(), K, Wc.data_ptr(), hic.data_ptr(), lo.data_ptr(), K, C.data_ptr(), Nc, M, Nc, K, 0, C.data_ptr(), Nc, 1.0,

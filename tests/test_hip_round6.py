@@ -149,3 +149,28 @@ def test_fp16_node_tables_of_nn_edge_0():
             assert not same(outs["bf16_mixed", 0], outs["bf16_mixed", 1]) and not same(outs["bf16x3", 0], outs["bf16x3", 1])
             diff = max(float((x - y).abs().max()) for x, y in zip(outs["bf16_mixed", 0], outs["bf16_mixed", 1]))
             assert diff < 1e-2, diff               # (two realisations of the mode's rounding noise: each inside 1e-2 of the oracle above)
+
+
+def test_fp16_out_projection_of_the_single_rounded_edge_attention():
+    """"outproj_f16": the out-projection of the edge cross-attention (reference transformer/attention.py:77,121-122) hands its rows to the
+    LayerNorm as fp16 half rows where the attention runs single-rounded (bf16_mixed, bf16x3_attn1): both settings inside the mode's tolerance
+    against the CPU oracle, different from each other (the switch reaches the kernels: 8-phase epilogue for E = 68 640, the 64 x 64 kernels
+    for a one-scene plan); bf16x3 and fp32 have no such launch and ignore the switch bit for bit."""
+    from oracle import vlsat_oracle as O
+    cfg = VLSATConfig(N_LAYERS=2)
+    w = synth.make_weights(cfg)
+    same = lambda a, b_: all(torch.equal(x, y) for x, y in zip(a, b_))
+    for b, d in (_batch(44, 40, 32, seed0=4600), _batch(1, 26, 32, seed0=4601)):
+        c = {k: torch.from_numpy(v) for k, v in b.items()}
+        ref = O.forward(O.to_torch(w), cfg, c["obj_points"], c["obj_2d_feats"], c["edge_indices"], c["descriptor"], c["batch_ids"])
+        for precision, tol, touched in (("bf16_mixed", 1e-2, True), ("bf16x3_attn1", 1e-2, True), ("bf16x3", 1e-3, False), ("fp32", 1e-3, False)):
+            outs = {}
+            for v in (0, 1):
+                m = VLSATModel(cfg, DEV).load_state(w).eval().set_gemm_precision(precision).debug_option("outproj_f16", v)
+                outs[v] = _run(m, d)
+                m.close()
+                for n, g, x in zip(NAMES, outs[v], ref):
+                    assert float((g.cpu() - x).abs().max()) < tol, (precision, v, n)
+            assert same(outs[0], outs[1]) != touched, precision
+            if touched:                                    # 3D outputs never read the 2D edge attention's result ... which is where the switch acts
+                assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][2], outs[1][2])
