@@ -314,6 +314,19 @@ def eval_leg(model, scenes, d, n_obj, dev):
     # the reference-compatible form of the same step: numpy rank lists per batch on the host like Mmgnet.process_val, host counting
     summ_h, cold_h, warm_h = leg()
     assert all(float(summ_h[k]) == float(summ[k]) for k in summ), "device counts and host rank lists disagree"
+    # ... and as a loop over a dataset runs it: 8 such batches per call of evaluate.validation -- one all-reduce and one host read for all of
+    # them -- with one and with two batches in flight (workers = 2: a replica of the model on a second stream and host thread)
+    loop = {}
+    for w in (1, 2):
+        EV.validation(model, [b] * 4, dev, workers=w)                 # (replica, plans and scratch of this worker count warm)
+        torch.cuda.synchronize()
+        vdist.barrier()
+        t2 = time.perf_counter()
+        many = EV.validation(model, [b] * 8, dev, workers=w)
+        torch.cuda.synchronize()
+        dt8 = vdist.max_over_ranks(time.perf_counter() - t2, dev)
+        assert all(abs(float(many[k]) - float(summ[k])) < 1e-9 for k in summ if k != "scenes"), "the loop's percentages differ from one batch's"
+        loop[f"workers_{w}"] = {"scenes_per_s_per_gpu": round(8 * len(scenes) / dt8, 1), "ms_per_batch": round(dt8 / 8 * 1e3, 2)}
     keep = ("scenes", "obj_acc@1_3d", "obj_acc@5_3d", "rel_acc@1_3d", "rel_acc@3_3d", "tri_acc@50_3d", "tri_acc@100_3d",
             "mean_recall@50_3d", "obj_acc@1_2d", "rel_acc@1_2d", "tri_acc@50_2d", "mean_recall@50_2d")
     return {"what": "forward + GPU ranking + the additive counts vector of evaluate.validation (device-side: vlsat_process_val_counts), one "
@@ -326,6 +339,8 @@ def eval_leg(model, scenes, d, n_obj, dev):
                                                         "(evaluate.validation(workers=0)): identical summary, host-side counting",
                                                 "ms_forward_plus_ranking": round(warm_h, 2),
                                                 "scenes_per_s_per_gpu": round(len(scenes) / warm_h * 1e3, 1)},
+            "loop_of_8_batches": dict(loop, what="evaluate.validation over 8 such batches in one call (device counts; one all-reduce and one host "
+                                                  "read at the end), 1 / 2 batches in flight"),
             "metrics": {k: round(float(summ[k]), 4) for k in keep if k in summ}}
 
 
@@ -473,7 +488,7 @@ def main():
                 pipelined = two_in_flight(model, d, n_scenes, args.steps, args.warmup, dev)
             if mode == "bf16_mixed":             # the step after the path behind the fastest forward (there the ranking weighs most)
                 ev = eval_leg(model, list(scenes), d, args.objects, dev)
-                ev_mode = {k: ev[k] for k in ("what", "ms_forward_plus_ranking", "scenes_per_s_per_gpu", "reference_compatible_rank_lists")}
+                ev_mode = {k: ev[k] for k in ("what", "ms_forward_plus_ranking", "scenes_per_s_per_gpu", "reference_compatible_rank_lists", "loop_of_8_batches")}
             extra.append({"workload": f"BASELINE configs[2]: 64 scenes x 40 objects x 256 pts, L=3, {mode}", "dtype": MODE_DTYPE[mode], "evaluation": ev_mode, "two_steps_in_flight": pipelined,
                           "timing": "value: steps without events on the shipped schedule; roofline: the same steps profiled on one stream",
                           "tolerance": 1e-2, "value": round(v, 2), "unit": "scenes/s", "ms_per_step": round(r["dt"] / args.steps * 1e3, 3),
