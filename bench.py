@@ -37,12 +37,13 @@ SUSTAINED_BF16_MFMA_TFLOPS = 1800.0
 SUSTAINED_FP32_MFMA_TFLOPS = 136.0
 # peak of the mode's matrix work counted in ALGORITHMIC flops: split-bf16 issues three bf16 MFMAs per product
 MODE_PEAK = {"fp32": PEAK_FP32_MFMA_TFLOPS, "bf16x3": PEAK_BF16_MFMA_TFLOPS / 3, "bf16": PEAK_BF16_MFMA_TFLOPS,
-             "bf16_mixed": PEAK_BF16_MFMA_TFLOPS, "bf16x3_attn1": PEAK_BF16_MFMA_TFLOPS / 3}
+             "bf16_mixed": PEAK_BF16_MFMA_TFLOPS, "bf16x3_attn1": PEAK_BF16_MFMA_TFLOPS / 3, "fp16_mixed": PEAK_BF16_MFMA_TFLOPS}
 MODE_DTYPE = {"fp32": "f32",
               "bf16x3": "bf16x3 (split-bf16 MFMA operands, 3 MFMAs per product, f32 accumulate; softmax/LN and HBM tensors f32)",
               "bf16": "bf16 (single-rounded bf16 MFMA operands, f32 accumulate; softmax/LN and HBM tensors f32)",
               "bf16_mixed": "bf16 on edge-row matrix work + bf16x3 on node rows (f32 accumulate; softmax/LN and HBM tensors f32)",
-              "bf16x3_attn1": "bf16x3 everywhere except a single-rounded bf16 edge cross-attention (f32 accumulate; softmax/LN f32)"}
+              "bf16x3_attn1": "bf16x3 everywhere except a single-rounded bf16 edge cross-attention (f32 accumulate; softmax/LN f32)",
+              "fp16_mixed": "f16 on edge-row matrix work (v_mfma_f32_32x32x16_f16: the bf16 rate) + bf16x3 on node rows (f32 accumulate; softmax/LN f32)"}
 
 
 def f_alg(n, p, e, l):
@@ -101,7 +102,7 @@ def cpu_baseline(cfg, n_obj, n_pts, budget_s=12.0, max_scenes=96, sweep_s=5.0):
                       f"{ncpu}-cpu host; torch {torch.__version__} CPU fp32"}, first
 
 
-PMC_TAG = {("cfg2", "fp32"): "_bench_pmc.json", ("cfg2", "bf16x3"): "_cfg3_bf16x3_pmc.json", ("cfg2", "bf16_mixed"): "_cfg3_bf16_mixed_pmc.json", ("cfg2", "bf16x3_attn1"): "_cfg3_bf16x3_attn1_pmc.json",
+PMC_TAG = {("cfg2", "fp32"): "_bench_pmc.json", ("cfg2", "bf16x3"): "_cfg3_bf16x3_pmc.json", ("cfg2", "bf16_mixed"): "_cfg3_bf16_mixed_pmc.json", ("cfg2", "bf16x3_attn1"): "_cfg3_bf16x3_attn1_pmc.json", ("cfg2", "fp16_mixed"): "_cfg3_fp16_mixed_pmc.json",
            ("cfg5", "fp32"): "_cfg5_fp32_pmc.json", ("cfg5", "bf16_mixed"): "_cfg5_bf16_mixed_pmc.json"}
 
 
@@ -179,9 +180,9 @@ def roofline_of(classes, mode, steps, falg, value, world, traffic=None, traffic_
     # projections around it (q, k|v, out: 2 x 512 x 2048 of the 2 x 512 x (2 x 2560 + 2048 + heads) flops an edge row costs per layer)
     # run single-rounded, everything else split -- the attention class is priced against the full 2.5 PF, the GEMM class against the
     # flop-weighted blend (2.5 PF / 3 for whichever class dominated overstated the fraction by up to 3x)
-    mfma_per_product = {"fp32": 1.0, "bf16": 1.0, "bf16_mixed": 1.0, "bf16x3": 3.0}.get(mode)
+    mfma_per_product = {"fp32": 1.0, "bf16": 1.0, "bf16_mixed": 1.0, "bf16x3": 3.0, "fp16_mixed": 1.0}.get(mode)
     note = {"fp32": "v_mfma_f32_32x32x2_f32", "bf16x3": "2.5 PF bf16 dense / 3 MFMAs per product", "bf16": "2.5 PF bf16 dense",
-            "bf16_mixed": "2.5 PF bf16 dense"}.get(mode)
+            "bf16_mixed": "2.5 PF bf16 dense", "fp16_mixed": "2.5 PF f16 dense (the bf16 rate on CDNA4)"}.get(mode)
     if mode == "bf16x3_attn1":
         if dom.startswith("flash"):
             mfma_per_product, note = 1.0, "2.5 PF bf16 dense (mode 4: the edge attention runs single-rounded)"
@@ -371,7 +372,7 @@ def main():
                          "instead of torch.distributed.all_reduce")
     ap.add_argument("--debug-option", action="append", default=[], metavar="NAME=VALUE",
                     help="experiment switch of the library (vlsat_debug_option), e.g. node_attn_split=0; repeatable")
-    ap.add_argument("--gemm-precision", default="fp32", choices=["fp32", "bf16x3", "bf16_mixed", "bf16", "bf16x3_attn1"],
+    ap.add_argument("--gemm-precision", default="fp32", choices=["fp32", "bf16x3", "bf16_mixed", "bf16", "bf16x3_attn1", "fp16_mixed"],
                     help="fp32 = BASELINE configs[1] (default, the headline); bf16x3 / bf16_mixed = configs[2] "
                          "(split-bf16 MFMA: <=1e-3; mixed single/split bf16: <=1e-2)")
     ap.add_argument("--lib", default="", help="another build of libvlsat_hip.so to load instead of the in-tree one (same-box A/B of a kernel change)")

@@ -29,6 +29,18 @@ template <int TERMS, int KS, bool TWIN = false>
 __global__ __launch_bounds__(256, TERMS == 1 ? 4 : 2) void edge_gate_bf16_kernel(GateArgs pa, GateArgs pb) {
     const GateArgs& p = (TWIN && blockIdx.y != 0) ? pb : pa;
     constexpr int PL = TERMS == 1 ? 1 : 2;
+    constexpr bool F16 = KS == 3;                 // KS 3: kproj holds fp16 half rows, the whole gate runs on fp16 operands (precision mode fp16_mixed; TERMS = 1)
+    auto cv4 = [](const f32x4& x) {               // four fp32 -> four 16-bit operands (bf16, or fp16 clamped)
+        if constexpr (F16) {
+            typedef _Float16 f16x4_g __attribute__((ext_vector_type(4)));
+            f32x4 y;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) y[c] = __builtin_amdgcn_fmed3f(x[c], -65504.f, 65504.f);
+            return __builtin_bit_cast(bf16x4, __builtin_convertvector(y, f16x4_g));
+        } else {
+            return __builtin_convertvector(x, bf16x4);
+        }
+    };
     constexpr int W0B = 128 * GB_P0, W3B = 32 * GB_P3;
     __shared__ __attribute__((aligned(16))) char smem[PL * (W0B + W3B) + 4 * AG_WAVE_BYTES];     // + the fused aggregation's wave buffers (gate_agg.h)
     char* sW0 = smem;                    // [PL][128][144]
@@ -39,14 +51,14 @@ __global__ __launch_bounds__(256, TERMS == 1 ? 4 : 2) void edge_gate_bf16_kernel
     for (int i = tid; i < 128 * 16; i += 256) {           // four fp32 -> four bf16 (8 B) per plane
         const int r = i >> 4, c4 = (i & 15) * 4;
         const f32x4 x = *reinterpret_cast<const f32x4*>(p.w0k + r * 64 + c4);
-        const bf16x4 h = __builtin_convertvector(x, bf16x4);
+        const bf16x4 h = cv4(x);
         *reinterpret_cast<bf16x4*>(sW0 + r * GB_P0 + c4 * 2) = h;
         if (PL == 2) *reinterpret_cast<bf16x4*>(sW0 + W0B + r * GB_P0 + c4 * 2) = __builtin_convertvector(x - __builtin_convertvector(h, f32x4), bf16x4);
     }
     for (int i = tid; i < 32 * 32; i += 256) {
         const int r = i >> 5, c4 = (i & 31) * 4;
         const f32x4 x = *reinterpret_cast<const f32x4*>(p.w3 + r * 128 + c4);
-        const bf16x4 h = __builtin_convertvector(x, bf16x4);
+        const bf16x4 h = cv4(x);
         *reinterpret_cast<bf16x4*>(sW3 + r * GB_P3 + c4 * 2) = h;
         if (PL == 2) *reinterpret_cast<bf16x4*>(sW3 + W3B + r * GB_P3 + c4 * 2) = __builtin_convertvector(x - __builtin_convertvector(h, f32x4), bf16x4);
     }
@@ -72,7 +84,7 @@ __global__ __launch_bounds__(256, TERMS == 1 ? 4 : 2) void edge_gate_bf16_kernel
             const float* zrow = p.kproj + (size_t)e * 512 + h * 64 + 8 * hi;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                if (KS == 2) {                            // eight bf16 = one 16-byte load
+                if (KS >= 2) {                            // eight bf16 (fp16) = one 16-byte load
                     zh[ks] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(p.kproj + (size_t)e * 512) + (h * 64 + 8 * hi + 16 * ks) * 2);
                     zl[ks] = zh[ks];
                     continue;
@@ -116,7 +128,7 @@ __global__ __launch_bounds__(256, TERMS == 1 ? 4 : 2) void edge_gate_bf16_kernel
                         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, zh[ks], acc, 0, 0, 0);
                         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, zl[ks], acc, 0, 0, 0);
                     }
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, zh[ks], acc, 0, 0, 0);
+                    acc = mfma_h<F16>(ah, zh[ks], acc);
                 }
             }
             // hidden = relu(acc + Gq[src, h*128 + o]),  o = to*32 + 8*r4 + 4*hi + c  (registers r = 4 r4 + c)
@@ -132,7 +144,7 @@ __global__ __launch_bounds__(256, TERMS == 1 ? 4 : 2) void edge_gate_bf16_kernel
                 f32x4 p0, p1;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) { p0[c] = hid[8 * half + c]; p1[c] = hid[8 * half + 4 + c]; }
-                const bf16x4 h0 = __builtin_convertvector(p0, bf16x4), h1 = __builtin_convertvector(p1, bf16x4);
+                const bf16x4 h0 = cv4(p0), h1 = cv4(p1);
                 const bf16x8 hh = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
                 // W3[m = li][o = to*32 + 16 half + 4 hi + {0..3}] and the same + 8
                 const char* wp = sW3 + li * GB_P3 + (to * 32 + 16 * half + 4 * hi) * 2;
@@ -147,7 +159,7 @@ __global__ __launch_bounds__(256, TERMS == 1 ? 4 : 2) void edge_gate_bf16_kernel
                     lg = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, hh, lg, 0, 0, 0);
                     lg = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, hl, lg, 0, 0, 0);
                 }
-                lg = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, hh, lg, 0, 0, 0);
+                lg = mfma_h<F16>(wh, hh, lg);
             }
         }
         // softmax over the 32 channels m = crow32(r, hi) (+ the other 16 in lane^32), times value
@@ -203,9 +215,9 @@ int launch_edge_gate_bf16(const GateArgs& a, int terms, int kproj_split, hipStre
     const int grid = n_groups < cap ? n_groups : cap;
 #define VLSAT_GB(T, K) do { if (twin) hipLaunchKernelGGL((edge_gate_bf16_kernel<T, K, true>), dim3(grid, 2), dim3(256), 0, s, a, b); \
                             else hipLaunchKernelGGL((edge_gate_bf16_kernel<T, K, false>), dim3(grid), dim3(256), 0, s, a, a); } while (0)
-    if (kproj_split == 2 && terms != 1) return fail(-1, "edge_gate_bf16: half-row kproj needs terms = 1");
+    if (kproj_split >= 2 && terms != 1) return fail(-1, "edge_gate_bf16: half-row kproj needs terms = 1");
     if (terms == 3) { if (kproj_split) VLSAT_GB(3, 1); else VLSAT_GB(3, 0); }
-    else            { if (kproj_split == 2) VLSAT_GB(1, 2); else if (kproj_split) VLSAT_GB(1, 1); else VLSAT_GB(1, 0); }
+    else            { if (kproj_split == 3) VLSAT_GB(1, 3); else if (kproj_split == 2) VLSAT_GB(1, 2); else if (kproj_split) VLSAT_GB(1, 1); else VLSAT_GB(1, 0); }       // (3: fp16 half rows)
 #undef VLSAT_GB
     VLSAT_LAUNCH_CHECK("edge_gate_bf16");
     return 0;

@@ -127,9 +127,11 @@ struct vlsat_ctx {
     // GEMM operand precision: 0 exact fp32 MFMA, 1 bf16, 3 split-bf16 (vlsat_set_gemm_precision); prec_edge / prec_node
     // are what the edge-row / node-row launches actually use (mode 2 = mixed: bf16 on edge rows, bf16x3 on node rows)
     int prec = 0, prec_edge = 0, prec_node = 0;
+    int half_f16 = 0;        // mode 5 ("fp16_mixed"): mode 2 with fp16 in the half rows and on the matrix cores of the edge-row kernels (v_mfma_f32_32x32x16_f16)
     int prec_attn = 0;       // ... and what the edge cross-attention (its three projections and the attention kernel) uses: prec_edge, except in
                              // mode 4 = split-bf16 with a single-rounded edge attention (1)
     std::map<const float*, std::pair<uint16_t*, uint16_t*>> split;
+    std::map<const float*, uint16_t*> f16w;        // fp16 planes of the same matrices (made when mode 5 is set)
     // workspace arenas of destroyed plans, re-used by the next plan that fits (an eval loop may build one plan per
     // scene; hipMalloc/hipFree per scene would dominate small scenes), pinned upload buffers, spare events
     std::vector<vlsat::Arena> arena_pool;

@@ -101,6 +101,17 @@ static int gemm_resolve(vlsat_ctx* h, int ws_lane, GemmArgs& a, int prec_overrid
         a.Whi = it->second.first;
         a.Wlo = it->second.second;
     }
+    if (h->half_f16) {                      // mode 5: the half-row format is fp16 (engine.h)
+        if (a.r_split == 2) return fail(VLSAT_ESTATE, "gemm: a half-row residual is not built on fp16 (the LayerNorm adds it)");
+        if (a.a_split == 2) {               // fp16 operands: fp16 weight plane, f16 MFMA
+            if (prec != 1) return fail(VLSAT_ESTATE, "gemm: half-row operands need the single-rounding precision");
+            auto f = h->f16w.find(a.W);
+            if (f == h->f16w.end()) return fail(VLSAT_ESTATE, "gemm: weight has no fp16 plane");
+            a.Whi = f->second;
+            a.half_f16 = 1;
+        }
+        if (a.c_split == 2) { a.c_split = 0; a.c_f16_cols = a.N; }      // half-row outputs: fp16, whatever the operands were
+    }
     a.no_dma = h->gemm_no_dma;
     a.no_p8 = h->gemm_no_p8;
     a.p8_part_min = h->gemm_p8_part_min;
@@ -223,6 +234,7 @@ int gcn_block(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const GcnW& w, float
         const double dk = D / h->H, dox = A / h->H;
         // the gate at 8 x (64, 32) in any precision, max aggregation, no debug tap: the aggregation happens inside the gate kernel (no [E, 256]
         // tensor of gated messages, no aggregate launch); the start values go in first
+        if (h->half_f16 && gate16h) return fail(VLSAT_ESTATE, "gate: the head-geometry template has no fp16 variant (precision mode 5 runs the shipped gate kernel)");
         const bool shipped_kernel = !gate16h && default_heads(h) && !(h->gate_heads_mfma == 2 && !gate16);     // edge_gate.hip / edge_gate_bf16.hip
         // (fp32: measured neutral -- 2196-2201 vs 2195 scenes/s -- and it moves waiting time into the GEMM class of the two-stream
         //  profile, so the exact-fp32 mode keeps the separate aggregate launch unless "gate_fuse_agg" is 2)
@@ -240,7 +252,7 @@ int gcn_block(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const GcnW& w, float
             if (r < 0) return r;
             if (r) RUN(launch_edge_gate_generic(g, h->H, D / h->H, A / h->H, s));
         }
-        else if (gate16) RUN(launch_edge_gate_bf16(g, h->prec_edge == 3 ? 3 : 1, S, s));
+        else if (gate16) RUN(launch_edge_gate_bf16(g, h->prec_edge == 3 ? 3 : 1, (S == 2 && h->half_f16) ? 3 : S, s));
         else RUN(launch_edge_gate(g, s));
     }
     if (!fused_agg) {
@@ -345,7 +357,7 @@ int gcn_block_pair(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const GcnW& w3,
     }
     {
         Scope scope(h, s, PC_GATE, 2.0 * (double)E * h->H * (2.0 * dk * 2 * dk + 2.0 * 2 * dk * dox));
-        if (gate16) RUN(launch_edge_gate_bf16(g3, h->prec_edge == 3 ? 3 : 1, S, s, &g2));
+        if (gate16) RUN(launch_edge_gate_bf16(g3, h->prec_edge == 3 ? 3 : 1, (S == 2 && h->half_f16) ? 3 : S, s, &g2));
         else RUN(launch_edge_gate(g3, s, &g2));
     }
     if (!fused_agg) {
@@ -573,8 +585,15 @@ static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const fl
         if (h->prec_edge && h->pointnet_bf16) {     // point rows count as edge-class work: the bf16 matrix cores
             auto w2 = h->split.find(h->pn_w2), w3 = h->split.find(h->pn_w3);
             if (w2 == h->split.end() || w3 == h->split.end()) return fail(VLSAT_ESTATE, "pointnet: weights have no bf16 planes");
-            RUN(launch_pointnet_bf16(pts, N, p->P, h->d.dim_point, h->pn_w1, h->pn_b1, w2->second.first, w2->second.second, h->pn_b2,
-                                     w3->second.first, w3->second.second, h->pn_b3, h->C_pt, h->prec_edge == 3 ? 3 : 1, p->F, s));
+            const uint16_t *w2h = w2->second.first, *w3h = w3->second.first;
+            int terms = h->prec_edge == 3 ? 3 : 1;
+            if (h->half_f16) {                       // mode 5: single-rounded fp16 operands (fp16 planes of conv2 / conv3)
+                auto f2 = h->f16w.find(h->pn_w2), f3 = h->f16w.find(h->pn_w3);
+                if (f2 == h->f16w.end() || f3 == h->f16w.end()) return fail(VLSAT_ESTATE, "pointnet: weights have no fp16 planes");
+                w2h = f2->second; w3h = f3->second; terms = 2;
+            }
+            RUN(launch_pointnet_bf16(pts, N, p->P, h->d.dim_point, h->pn_w1, h->pn_b1, w2h, w2->second.second, h->pn_b2,
+                                     w3h, w3->second.second, h->pn_b3, h->C_pt, terms, p->F, s));
         } else {
             RUN(launch_pointnet(pts, N, p->P, h->d.dim_point, h->pn_w1, h->pn_b1, h->pn_w2, h->pn_b2, h->pn_w3, h->pn_b3, h->C_pt, p->F, s));
         }
@@ -745,7 +764,7 @@ static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const fl
                     const bool big = SA == 2 && dh == 64 && p->n_tiles_big && h->flash_tr && h->flash_dma == 1 && h->flash_bq_big;
                     if (big) sp.bq = FLASH_BQ_BIG;
                     RUN(launch_flash_attn_bf16(p->Qe, D, kve, kve + (SA == 2 ? D / 2 : D), 2 * D, p->Oe, D, big ? p->d_tiles_big : p->d_tiles, big ? p->n_tiles_big : p->n_tiles,
-                                               sc2e, PA == 3 ? 3 : 1, h->flash_tr ? (h->flash_dma >= 3 ? h->flash_dma : h->flash_dma ? 1 : 2) : 0, SA, fs, &sp, h->flash_pv_terms, dh));    // (half rows: V starts at byte 2 D)
+                                               sc2e, PA == 3 ? 3 : 1, h->flash_tr ? (h->flash_dma >= 3 ? h->flash_dma : h->flash_dma ? 1 : 2) : 0, (SA == 2 && h->half_f16) ? 3 : SA, fs, &sp, h->flash_pv_terms, dh));    // (half rows: V starts at byte 2 D)
                 }
                 else
                     RUN(launch_flash_attn(p->Qe, D, kve, kve + D, 2 * D, p->Oe, D, p->d_tiles, p->n_tiles, sc2e, fs, &sp, dh));   // (head dims 32 / 128: NUM_HEADS 16 / 4)
@@ -757,7 +776,7 @@ static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const fl
             // out-projection 60 % slower there -- 397 vs 243 us at the bench size -- against +1 KB per row in the LayerNorm).
             float* pre_ln = S ? p->Qe : p->E2;
             // Half rows: the same (the 8-phase GEMM has no fast accumulator-init path).
-            const bool ln_resid = (S == 1 || (S == 2 && !h->gemm_no_p8)) && h->ln_resid;
+            const bool ln_resid = ((S == 1 || (S == 2 && !h->gemm_no_p8)) && h->ln_resid) || (S == 2 && h->half_f16);      // (mode 5: always -- no GEMM reads an fp16 residual)
             GemmArgs o = G(p->Oe, D, w.wo, D, pre_ln, D, E, D, w.bo);
             if (!ln_resid) { o.resid = p->E2; o.ldr = D; o.r_split = S; }
             o.a_split = SA;
@@ -768,7 +787,8 @@ static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const fl
             RUN(gemm(h, fs, o, PA));
             {
                 Scope sc(h, fs, PC_LAYERNORM, 0);
-                RUN(launch_layernorm_to(pre_ln, D, p->E2, D, E, D, w.lng, w.lnb, inter, S, fs, ln_resid ? p->E2 : nullptr, D, S, o16 ? 1 : 0));
+                const int SL = (S == 2 && h->half_f16) ? 4 : S;          // (mode 5: the half rows the LayerNorm reads and writes hold fp16)
+                RUN(launch_layernorm_to(pre_ln, D, p->E2, D, E, D, w.lng, w.lnb, inter, SL, fs, ln_resid ? p->E2 : nullptr, D, SL, o16 ? 1 : 0));
             }
             if (pair) RUN(after(t, &edge_done));
         }

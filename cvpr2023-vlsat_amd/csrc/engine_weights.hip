@@ -220,6 +220,15 @@ int split_all_weights(vlsat_ctx* h) {
         h->split.emplace(gw.first, std::make_pair(hi, lo));
         any = true;
     }
+    if (h->half_f16)
+        for (auto& gw : h->gemm_w) {
+            if (h->f16w.count(gw.first)) continue;
+            uint16_t* f = nullptr;
+            VLSAT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&f), gw.second * 2 + 256));
+            RUN(launch_to_f16(gw.first, gw.second, f, nullptr));
+            h->f16w.emplace(gw.first, f);
+            any = true;
+        }
     if (any) VLSAT_HIP_CHECK(hipDeviceSynchronize());
     return 0;
 }
@@ -228,7 +237,7 @@ int split_all_weights(vlsat_ctx* h) {
 // ============================================================================================
 extern "C" {
 
-const char* vlsat_version(void) { return "vlsat-hip gfx950 r4 (fp32-mfma | bf16x3 | bf16_mixed | bf16)"; }
+const char* vlsat_version(void) { return "vlsat-hip gfx950 r6 (fp32-mfma | bf16x3 | bf16x3_attn1 | bf16_mixed | fp16_mixed | bf16)"; }
 
 int vlsat_create(const VlsatDims* d, vlsat_handle* out) {
     if (!d || !out) return fail(VLSAT_EINVAL, "vlsat_create: null argument");
@@ -261,6 +270,8 @@ static void free_device_weights(vlsat_ctx* h) {
     h->gemm_w.clear();
     for (auto& kv : h->split) { hipFree(kv.second.first); hipFree(kv.second.second); }
     h->split.clear();
+    for (auto& kv : h->f16w) hipFree(kv.second);
+    h->f16w.clear();
     h->trip = TripletW{};
 }
 
@@ -447,9 +458,14 @@ int vlsat_finalize_weights(vlsat_handle h) {
 // The bf16 hi/lo copies of all weight matrices are made here, eagerly, not inside a forward.
 int vlsat_set_gemm_precision(vlsat_handle h, int32_t mode) {
     if (!h) return fail(VLSAT_EINVAL, "null handle");
-    if (mode < 0 || mode > 4) return fail(VLSAT_EINVAL, "gemm precision must be 0 (fp32), 1 (bf16), 2 (mixed), 3 (bf16x3) or 4 (bf16x3 with a single-rounded edge attention)");
+    if (mode < 0 || mode > 5) return fail(VLSAT_EINVAL, "gemm precision must be 0 (fp32), 1 (bf16), 2 (mixed), 3 (bf16x3), 4 (bf16x3 with a single-rounded edge attention) or 5 (mixed on fp16)");
+    // mode 5: mode 2 with fp16 half rows and v_mfma_f32_32x32x16_f16 on the edge-row kernels (GEMM, attention, gate): the same rate, 2^-12 instead of
+    // 2^-9 per stored value and operand; built for the default head geometry (8 heads, DIM_ATTEN 256)
+    if (mode == 5 && !(h->H == 8 && h->A == 256)) return fail(VLSAT_EINVAL, "gemm precision 5 (fp16_mixed) is built for NUM_HEADS 8, DIM_ATTEN 256");
     ++h->config_epoch;
     h->prec = mode;
+    h->half_f16 = mode == 5;
+    if (mode == 5) mode = 2;
     h->prec_edge = mode == 2 ? 1 : mode == 4 ? 3 : mode;
     h->prec_node = mode == 2 || mode == 4 ? 3 : mode;
     h->prec_attn = mode == 4 ? 1 : h->prec_edge;

@@ -93,7 +93,7 @@ __device__ __forceinline__ void planes4(const f32x4& x, bf16x4& hi, bf16x4& lo) 
 // 2 half rows (8 bytes: four bf16, returned in the low half of the f32x4)
 template <int IO>
 __device__ __forceinline__ f32x4 load4(const float* row, size_t col) {
-    if (IO == 2) {
+    if (IO >= 2) {
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         const f32x2 v = *reinterpret_cast<const f32x2*>(reinterpret_cast<const char*>(row) + col * 2);
         return f32x4{v[0], v[1], 0.f, 0.f};
@@ -102,7 +102,7 @@ __device__ __forceinline__ f32x4 load4(const float* row, size_t col) {
 }
 template <int IO>
 __device__ __forceinline__ void planes_of(const f32x4& x, bf16x4& hi, bf16x4& lo) {
-    if (IO == 2) {
+    if (IO >= 2) {
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         hi = __builtin_bit_cast(bf16x4, f32x2{x[0], x[1]});
         lo = hi;                                   // (never read: TERMS = 1)
@@ -146,7 +146,9 @@ __global__ __launch_bounds__(64 * BQW, 2) void flash_attn_bf16_kernel(
     constexpr int FB_VPLANE = NSUB * FB_VSUB;
     constexpr int FB_OPITCH = FB_D + 4;            // floats per query row of the output transpose
     constexpr bool DMA = RING != 0;           // RING: tile buffers of the LDS-direct K/V ring (0: register-staged double buffer)
-    static_assert(!DMA || (TERMS == 1 && IO == 2 && TR), "LDS-direct K/V staging: half rows, single rounding");
+    static_assert(!DMA || (TERMS == 1 && IO >= 2 && TR), "LDS-direct K/V staging: half rows, single rounding");
+    constexpr bool F16 = IO == 3;                  // IO 3: the half rows hold fp16, QK^T and PV run on the f16 MFMA (precision mode fp16_mixed)
+    static_assert(!F16 || (TERMS == 1 && DMA), "fp16 half rows: the LDS-direct single-rounding kernel");
     // (DMA) K image: 64 rows of ROWB = 2 FB_D bytes, unpadded (an LDS-direct load writes lane-linear), 16-byte chunks XOR-swizzled with
     // KSWZ(row) on the global side and on the fragment reads: 64-byte rows (row >> 2) & 3, 128-byte rows (row >> 1) & 7, 256-byte rows row & 15
     constexpr int ROWB = 2 * FB_D, CPR = ROWB / 16, RPI = 1024 / ROWB;          // bytes per K row, chunks per row, rows per load instruction
@@ -332,8 +334,8 @@ __global__ __launch_bounds__(64 * BQW, 2) void flash_attn_bf16_kernel(
                         asm volatile("" :: "v"(kh0), "v"(kh1));
                         continue;
                     }
-                    s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh0, qh[ks], s[0], 0, 0, 0);
-                    s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh1, qh[ks], s[1], 0, 0, 0);
+                    s[0] = mfma_h<F16>(kh0, qh[ks], s[0]);
+                    s[1] = mfma_h<F16>(kh1, qh[ks], s[1]);
                 }
             }
             // The first readers of the score registers below are inline-asm VALU instructions, which hipcc's hazard recogniser
@@ -405,8 +407,14 @@ __global__ __launch_bounds__(64 * BQW, 2) void flash_attn_bf16_kernel(
 #pragma unroll
                 for (int c = 0; c < 4; ++c) { p0[c] = s[kb][8 * half + c]; p1[c] = s[kb][8 * half + 4 + c]; }
                 bf16x4 h0, l0, h1, l1;
-                split4(p0, h0, l0);
-                split4(p1, h1, l1);
+                if constexpr (F16) {              // probabilities in [0, 1]: fp16, no clamp needed
+                    typedef _Float16 f16x4_p __attribute__((ext_vector_type(4)));
+                    h0 = l0 = __builtin_bit_cast(bf16x4, __builtin_convertvector(p0, f16x4_p));
+                    h1 = l1 = __builtin_bit_cast(bf16x4, __builtin_convertvector(p1, f16x4_p));
+                } else {
+                    split4(p0, h0, l0);
+                    split4(p1, h1, l1);
+                }
                 const bf16x8 ph = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
                 const bf16x8 pl = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
                 const int k0 = 32 * kb + 16 * half + 4 * hi;          // first key of this lane half's k-slots (then +8)
@@ -447,7 +455,7 @@ __global__ __launch_bounds__(64 * BQW, 2) void flash_attn_bf16_kernel(
                     continue;
                 }
 #pragma unroll
-                for (int db = 0; db < NO; ++db) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db][0], ph, o[db], 0, 0, 0);
+                for (int db = 0; db < NO; ++db) o[db] = mfma_h<F16>(vf[db][0], ph, o[db]);
             }
         }   // wave_active
         if (DMA) {
@@ -500,7 +508,13 @@ __global__ __launch_bounds__(64 * BQW, 2) void flash_attn_bf16_kernel(
         if (qr < n_tok) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(so + r * FB_OPITCH + c4);
             float* orow = O + (size_t)(row_base + qr) * ldo;
-            if (IO == 2 && !split)
+            if (IO == 3 && !split) {
+                typedef _Float16 f16x4_o __attribute__((ext_vector_type(4)));
+                f32x4 vc;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) vc[c] = __builtin_amdgcn_fmed3f(v[c], -65504.f, 65504.f);
+                *reinterpret_cast<f16x4_o*>(reinterpret_cast<char*>(orow) + (col0 + c4) * 2) = __builtin_convertvector(vc, f16x4_o);
+            } else if (IO == 2 && !split)
                 *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(orow) + (col0 + c4) * 2) = __builtin_convertvector(v, bf16x4);
             else
                 *reinterpret_cast<f32x4*>(orow + col0 + c4) = v;
@@ -517,7 +531,7 @@ bool flash_attn_bf16_supports(int head_dim, int terms, int use_tr, int io_split)
     if (head_dim == 64) return true;
     if (head_dim != 32 && head_dim != 128) return false;
     if (!use_tr || !io_split) return false;
-    if (io_split == 2 && terms != 1) return false;
+    if (io_split >= 2 && terms != 1) return false;
     return head_dim == 32 || terms == 1;
 }
 
@@ -529,6 +543,8 @@ int launch_flash_attn_bf16(const float* Q, int ldq, const float* K, const float*
     if (!flash_attn_bf16_supports(head_dim, terms, use_tr, io_split)) return fail(-1, "flash_attn_bf16: head dim / format combination not built");
     if ((ldq | ldkv | ldo) & 3) return fail(-1, "flash_attn: leading dims must be multiples of 4");
     if (terms != 1 && terms != 3) return fail(-1, "flash_attn_bf16: terms must be 1 or 3");
+    if (io_split == 3 && (FB_D != 64 || !(split && split->rows > 0 && (size_t)split->rows * (size_t)ldkv * 4 < (1ull << 32))))
+        return fail(-1, "flash_attn_bf16: fp16 half rows are built for head dim 64 and scenes addressable with 32-bit offsets");
     FlashSplit sp{};
     if (split && split->parts > 1) {
         sp = *split;
@@ -536,7 +552,7 @@ int launch_flash_attn_bf16(const float* Q, int ldq, const float* K, const float*
             return fail(-1, "flash_attn: incomplete split-key workspace");
     }
     if (split) { sp.ablate = split->ablate; sp.bq = split->bq; sp.rows = split->rows; }
-    if (sp.bq != FLASH_BQ && !(sp.bq == FLASH_BQ_BIG && FB_D == 64 && io_split == 2 && use_tr == 1 && sp.parts <= 1 && sp.rows > 0 &&
+    if (sp.bq != FLASH_BQ && !(sp.bq == FLASH_BQ_BIG && FB_D == 64 && io_split >= 2 && use_tr == 1 && sp.parts <= 1 && sp.rows > 0 &&
                                (size_t)sp.rows * (size_t)ldkv * 4 < (1ull << 32)))
         return fail(-1, "flash_attn_bf16: 256-query tiles are built for half rows, head dim 64, the LDS-direct kernel, no key split");
     // The LDS-direct K / V staging addresses a scene with 32-bit byte offsets (buffer descriptor of n_tok * ldkv * 4 bytes, row * ld4
@@ -558,6 +574,13 @@ int launch_flash_attn_bf16(const float* Q, int ldq, const float* K, const float*
         } else {
             if (io_split == 2) VLSAT_FAD(1, 2, 3, 128); else VLSAT_FAD(1, 1, 3, 128);
         }
+    } else
+    if (io_split == 3) {                 // fp16 half rows (precision mode fp16_mixed): the two shipped forms of the LDS-direct kernel
+        if (!use_tr || terms != 1 || use_tr == 2 || use_tr >= 3) return fail(-1, "flash_attn_bf16: fp16 half rows are built for the LDS-direct single-rounding kernel only");
+        if (sp.bq == FLASH_BQ_BIG)
+            hipLaunchKernelGGL((flash_attn_bf16_kernel<1, true, 3, 3, 64, 2, 8>), dim3(n_tiles), dim3(512), 0, s, Q, K, V, O, ldq, ldkv, ldo, tiles, n_tiles, scale_log2e, sp);
+        else
+            hipLaunchKernelGGL((flash_attn_bf16_kernel<1, true, 3, 3, 64, 2>), dim3(n_tiles), dim3(256), 0, s, Q, K, V, O, ldq, ldkv, ldo, tiles, n_tiles, scale_log2e, sp);
     } else
     if (io_split == 2) {
         if (!use_tr || terms != 1) return fail(-1, "flash_attn_bf16: half-row tensors need terms = 1 and the transpose-read path");

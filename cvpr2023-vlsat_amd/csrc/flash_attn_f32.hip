@@ -225,6 +225,13 @@ __global__ __launch_bounds__(256) void flash_merge_kernel(float* __restrict__ O,
         acc[c] *= inv;
         if (out_split == 1) acc[c] = pack_split(acc[c]);
     }
+    if (out_split == 3) {                               // half rows of fp16
+        typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_fmed3f(acc[c], -65504.f, 65504.f);
+        *reinterpret_cast<f16x4_t*>(reinterpret_cast<char*>(O + row * ldo) + c4 * 8) = __builtin_convertvector(acc, f16x4_t);
+        return;
+    }
     if (out_split == 2) {                               // half rows
         typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
         *reinterpret_cast<bf16x4_t*>(reinterpret_cast<char*>(O + row * ldo) + c4 * 8) = __builtin_convertvector(acc, bf16x4_t);

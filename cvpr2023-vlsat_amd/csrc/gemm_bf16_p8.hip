@@ -75,8 +75,8 @@ enum { P8_MID = 0, P8_LAST = 1, P8_FIRST = 2, P8_SECOND = 3, P8_FIRST0 = 4 };   
 //  profiles/r06_probes/p8_dedup_krot_{kernel,step}_ab.txt)
 template <int MODE, int ADD, bool RELU, int CF, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmArgs p, int n_tiles, int nbn) {
-    constexpr bool F32 = MODE == 1, X3 = MODE == 2, WORDS = MODE != 0;      // WORDS: 4-byte A elements, K-tiles of 32
-    static_assert(MODE == 0 ? (CF == 0 || CF == 2 || CF == 3) : F32 ? CF == 0 : (CF == 0 || CF == 1), "output format of the mode");
+    constexpr bool F32 = MODE == 1, X3 = MODE == 2, H16 = MODE == 3, WORDS = F32 || X3;      // WORDS: 4-byte A elements, K-tiles of 32; H16: MODE 0 on fp16 (GemmArgs::half_f16)
+    static_assert(MODE == 3 ? (CF == 0 || CF == 3) : MODE == 0 ? (CF == 0 || CF == 2 || CF == 3) : F32 ? CF == 0 : (CF == 0 || CF == 1), "output format of the mode");
     __shared__ __attribute__((aligned(16))) char smem[10 * P8_HALF];
     typedef short s16x8 __attribute__((ext_vector_type(8)));
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -207,16 +207,24 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmArgs p, int n_tiles
     bf16x8 wb[2], ones;
     f32x4 biasr[2];                               // fp32: the lane's bias values in the layout AFTER the transposition
     if (!WORDS) {
-        const __bf16 z = (__bf16)0.f, o = hi ? z : (__bf16)1.f;
-        ones = bf16x8{o, o, o, z, z, z, z, z};
+        // (H16: the same three-term bias on fp16 operands -- the sum of three fp16 terms is exact for |b| in fp16's normal range)
+        auto pack3 = [&](float x0, float x1, float x2) {
+            if constexpr (H16) {
+                const _Float16 z = (_Float16)0.f;
+                return __builtin_bit_cast(bf16x8, f16x8{(_Float16)x0, (_Float16)x1, (_Float16)x2, z, z, z, z, z});
+            } else {
+                const __bf16 z = (__bf16)0.f;
+                return bf16x8{(__bf16)x0, (__bf16)x1, (__bf16)x2, z, z, z, z, z};
+            }
+        };
+        auto rnd = [&](float x) { if constexpr (H16) return (float)(_Float16)x; else return (float)(__bf16)x; };
+        const float o = hi ? 0.f : 1.f;
+        ones = pack3(o, o, o);
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn) {
             const float b = (p.bias && !hi) ? p.bias[n0 + (wc * 2 + tn) * 32 + li] : 0.f;
-            const __bf16 b0 = (__bf16)b;
-            const float r1 = b - (float)b0;
-            const __bf16 b1 = (__bf16)r1;
-            const __bf16 b2 = (__bf16)(r1 - (float)b1);
-            wb[tn] = bf16x8{b0, b1, b2, z, z, z, z, z};
+            const float b0 = rnd(b), b1 = rnd(b - b0), b2 = rnd(b - b0 - b1);
+            wb[tn] = pack3(b0, b1, b2);
             asm volatile("" : "+v"(wb[tn]));     // landed before the pipeline starts: no compiler-inserted wait inside it
         }
     } else {
@@ -281,7 +289,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmArgs p, int n_tiles
             if (INIT) {
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
-                    acc[2 * ah + mt][bh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[bh], ones, ADD != 0 ? acc[2 * ah + mt][bh] : zero, 0, 0, 0);
+                    acc[2 * ah + mt][bh] = mfma_h<H16>(wb[bh], ones, ADD != 0 ? acc[2 * ah + mt][bh] : zero);
             }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
@@ -289,7 +297,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(GemmArgs p, int n_tiles
                 for (int mt = 0; mt < 2; ++mt) {
                     bf16x8 a = af[mt][ks];
                     if (RELU) a = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, a), s16x8{0, 0, 0, 0, 0, 0, 0, 0}));
-                    acc[2 * ah + mt][bh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ks], a, acc[2 * ah + mt][bh], 0, 0, 0);
+                    acc[2 * ah + mt][bh] = mfma_h<H16>(w[ks], a, acc[2 * ah + mt][bh]);
                 }
         }
         if (!(ABL & 128)) __builtin_amdgcn_s_setprio(0);
@@ -576,8 +584,9 @@ int launch_gemm_p8(const GemmArgs& a, int n_tiles, int grid, hipStream_t s) {
     if (grid % 8 || (grid / 8) % nbn) return 1;      // the kernel keeps one column tile per block (bias registers)
 #define VLSAT_P8(MODE, ADD, RELU, CF) hipLaunchKernelGGL((gemm_p8_kernel<MODE, ADD, RELU, CF>), dim3(grid), dim3(512), 0, s, a, n_tiles, nbn)
 #define VLSAT_P8_ABL(X) hipLaunchKernelGGL((gemm_p8_kernel<0, 0, false, 2, X>), dim3(grid), dim3(512), 0, s, a, n_tiles, nbn)
-    const bool c16 = a.c_f16_cols > 0;            // (the whole output as fp16 half rows: half-row launches without additive operands only)
-    if (c16 && (a.c_f16_cols != a.N || f32 || x3 || add || a.c_split || a.relu_a)) return 1;
+    const bool c16 = a.c_f16_cols > 0;            // (the whole output as fp16 half rows: half-row launches only)
+    if (c16 && (a.c_f16_cols != a.N || f32 || x3 || a.c_split)) return 1;
+    if (a.half_f16 && (f32 || x3 || a.c_split)) return 1;         // (fp16 operands: half-row launches; their half-row outputs come as c_f16_cols == N)
     const int key = add * 4 + (a.relu_a ? 2 : 0) + (a.c_split ? 1 : 0);
     if (f32) {
         switch (key) {
@@ -621,6 +630,17 @@ int launch_gemm_p8(const GemmArgs& a, int n_tiles, int grid, hipStream_t s) {
         }
 #endif
     } else {
+        if (a.half_f16) {                     // MODE 3: fp16 operands; output fp32 (CF 0) or fp16 half rows (CF 3)
+            switch (add * 4 + (a.relu_a ? 2 : 0) + (c16 ? 1 : 0)) {
+                case 0: VLSAT_P8(3, 0, false, 0); break;
+                case 1: VLSAT_P8(3, 0, false, 3); break;
+                case 2: VLSAT_P8(3, 0, true, 0); break;
+                case 3: VLSAT_P8(3, 0, true, 3); break;
+                case 25: VLSAT_P8(3, 6, false, 3); break;
+                case 27: VLSAT_P8(3, 6, true, 3); break;
+                default: return 1;
+            }
+        } else
         switch (key) {
             case 0: if (c16) VLSAT_P8(0, 0, false, 3); else VLSAT_P8(0, 0, false, 0); break;
             case 1: VLSAT_P8(0, 0, false, 2); break;

@@ -47,17 +47,17 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // floor, together 60 %).  The loop is unrolled by two so that the two sets are compile-time registers.
 template <int TERMS, int AFMT, int ADD, int RBN, int RBK = 32, bool DB = false>
 __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmArgs p, int n_tiles, int nbn) {
-    static_assert(RBK == 32 || (RBK == 64 && AFMT == 2 && TERMS == 1), "64-wide slices: half-row A, one plane");
+    static_assert(RBK == 32 || (RBK == 64 && AFMT >= 2 && TERMS == 1), "64-wide slices: half-row A, one plane");
     static_assert(!DB || RBK == 64, "double-buffered fragments: built for the 64-wide slices");
     // (the split-bf16 variants have no registers left for a second fragment set: 76-197 spilled registers when tried)
     constexpr int BK = RBK;                                  // (shadows the library-wide slice length inside this kernel)
     constexpr bool LR = RBK == 64;                           // long rows: 128 bytes per operand row and slice
     constexpr int RBM = 32768 / RBN;
     using Frag = PipeSplitDma<128, 128, TERMS, AFMT>;        // fragment-side helpers only (split8 / frag_half)
-    constexpr bool AH = AFMT == 2;                           // A as half rows (bf16): 64-byte slices like the weight planes
+    constexpr bool AH = AFMT >= 2;                           // A as half rows (bf16; 3: fp16 operands, GemmArgs::half_f16): 64-byte slices like the weight planes
     constexpr int PL = TERMS == 1 ? 1 : 2;
     constexpr int TM = 2, TN = 2, WR = LR ? RBN / 64 : RBN / 128;      // (WR: instruction rounds of a weight-plane slice)
-    constexpr int AR = (AFMT == 2 && !LR) ? RBM / 128 : RBM / 64;      // instruction rounds of an A slice (128 | 64 rows each)
+    constexpr int AR = (AH && !LR) ? RBM / 128 : RBM / 64;      // instruction rounds of an A slice (128 | 64 rows each)
     constexpr int A_BYTES = AH ? RBM * BK * 2 : RBM * BK * 4, W_PLANE = RBN * BK * 2;
     constexpr int STAGE = A_BYTES + PL * W_PLANE;            // 48 KB (40 KB with one plane, 24 KB with half-row A)
     constexpr int LPS = AR + PL * WR;                        // LDS-direct loads per wave per slice
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmArgs p, int n_til
                 for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn)
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.w[ks][tn], a[tm], acc[tm][tn], 0, 0, 0);
+                        acc[tm][tn] = mfma_h<AFMT == 3>(f.w[ks][tn], a[tm], acc[tm][tn]);
             }
         };
         // one pipeline step: the slice that goes into `fill` has landed -> barrier (everyone is done reading the slice
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmArgs p, int n_til
 
 template <int T, int S, int ADD>
 static void ring_launch(bool wide, const GemmArgs& a, int n_tiles, int nbn, int grid, hipStream_t s) {
-    if constexpr (T == 1 && S == 2) {          // half-row A, one plane: 64-wide slices whenever K allows
+    if constexpr (T == 1 && S >= 2) {          // half-row A, one plane: 64-wide slices whenever K allows
         if (!wide && a.K % 128 == 0 && !a.ring_bk32 && !a.ring_nodb) {
             hipLaunchKernelGGL((gemm_ring_kernel<T, S, ADD, 128, 64, true>), dim3(grid), dim3(512), 0, s, a, n_tiles, nbn);
             return;
@@ -337,7 +337,7 @@ int launch_gemm_ring(const GemmArgs& a, int rbn, int n_tiles, int grid, hipStrea
         if (a.a_split == 2) return 1;
         if (a.a_split) { VLSAT_RING_ADD(3, 1) } else { VLSAT_RING_ADD(3, 0) }
     } else {
-        if (a.a_split == 2) { VLSAT_RING_ADD(1, 2) } else if (a.a_split) { VLSAT_RING_ADD(1, 1) } else { VLSAT_RING_ADD(1, 0) }
+        if (a.a_split == 2 && a.half_f16) { VLSAT_RING_ADD(1, 3) } else if (a.a_split == 2) { VLSAT_RING_ADD(1, 2) } else if (a.a_split) { VLSAT_RING_ADD(1, 1) } else { VLSAT_RING_ADD(1, 0) }
     }
 #undef VLSAT_RING_ADD
 #undef VLSAT_RING

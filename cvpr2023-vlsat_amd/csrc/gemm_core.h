@@ -150,7 +150,7 @@ __device__ __forceinline__ void tile_init(const GemmArgs& p, int m0, int n0, int
 template <int TM, int TN, bool PLAIN = false>
 __device__ __forceinline__ void tile_epilogue(const GemmArgs& p, int m0, int n0, int BM, int BN, int wm, int wn, int lane,
                                               f32x16 (&acc)[TM][TN]) {
-    const bool c_f16 = !PLAIN && p.c_f16_cols > 0 && n0 + BN <= p.c_f16_cols;      // this block tile's columns are fp16 half rows (GemmArgs::c_f16_cols)
+    const bool c_f16 = !PLAIN && p.c_f16_cols > 0 && (n0 + BN <= p.c_f16_cols || p.c_f16_cols >= p.N);      // (c_f16_cols == N: the whole output, whatever N is)      // this block tile's columns are fp16 half rows (GemmArgs::c_f16_cols)
     const int c_split = PLAIN ? 0 : p.c_split;
     int ldc = p.ldc, lv = lane;
     asm volatile("" : "+s"(ldc), "+v"(lv));                          // see tile_init: no LICM of the store offsets
@@ -506,6 +506,13 @@ struct PipeF32Dma {
 // LDS: bf16 planes [rows][32] with an 80-byte row pitch (conflict-free ds_read_b128 of 8 k).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// 16-bit operand MFMA on registers declared as bf16x8: F16 reinterprets the same bits as fp16 (GemmArgs::half_f16)
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma_h(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
 
 template <int BM, int BN, int TERMS>
 struct PipeBF16 {
@@ -609,7 +616,8 @@ struct PipeBF16 {
 template <int BM, int BN, int TERMS, int AFMT = 0>
 struct PipeSplitDma {
     static constexpr bool AS = AFMT == 1;
-    static constexpr bool AH = AFMT == 2;
+    static constexpr bool AH = AFMT >= 2;             // (3: the half rows and the weight plane hold fp16, products on the f16 MFMA)
+    static constexpr bool F16 = AFMT == 3;
     static_assert(!AH || TERMS == 1, "half-row operands carry no low part");
     // With bf16 MFMAs a k-slice is 256 (bf16) to 768 (bf16x3) matrix-pipe cycles per wave, far less than the latency of
     // an A line that comes from HBM / the Infinity Cache, and LDS cannot hold enough slices in flight to cover it: the
@@ -746,18 +754,18 @@ struct PipeSplitDma {
                 for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn)
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0][tn], a[1][tm], acc[tm][tn], 0, 0, 0);
+                        acc[tm][tn] = mfma_h<F16>(w[0][tn], a[1][tm], acc[tm][tn]);
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn)
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[PL - 1][tn], a[0][tm], acc[tm][tn], 0, 0, 0);
+                        acc[tm][tn] = mfma_h<F16>(w[PL - 1][tn], a[0][tm], acc[tm][tn]);
             }
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn)
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0][tn], a[0][tm], acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = mfma_h<F16>(w[0][tn], a[0][tm], acc[tm][tn]);
         }
     }
 };
@@ -770,5 +778,6 @@ template <int BM, int BN> struct PipeSel<BM, BN, 7> { using type = PipeSplitDma<
 template <int BM, int BN> struct PipeSel<BM, BN, 9> { using type = PipeSplitDma<BM, BN, 1, 1>; };   // ... A in split-pair format
 template <int BM, int BN> struct PipeSel<BM, BN, 11> { using type = PipeSplitDma<BM, BN, 3, 1>; };
 template <int BM, int BN> struct PipeSel<BM, BN, 13> { using type = PipeSplitDma<BM, BN, 1, 2>; };  // ... A as half rows (bf16)
+template <int BM, int BN> struct PipeSel<BM, BN, 15> { using type = PipeSplitDma<BM, BN, 1, 3>; };  // ... A as half rows of fp16, fp16 weight plane
 
 }  // namespace vlsat

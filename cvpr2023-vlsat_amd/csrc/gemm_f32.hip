@@ -191,10 +191,11 @@ static int launch_t(const GemmArgs& a, int n_tiles, int grid, hipStream_t s) {
         return fail(-1, "gemm: operand formats and c_scale exist in the bf16 modes only");      // (the fp32 kernels fold them away)
     if (prec == 0 && dma_ok && !a.relu_a) prec = 4;
     if (a.a_split == 2 && !(prec == 1 && dma_ok)) return fail(-1, "gemm: half-row A needs the single-rounding bf16 precision and the LDS-direct pipe");
-    if ((prec == 1 || prec == 3) && dma_ok) prec += a.a_split == 2 ? 12 : a.a_split ? 8 : 4;   // bf16 modes: A split on the fragment-read side, so ReLU-on-A is fine
+    if ((prec == 1 || prec == 3) && dma_ok) prec += a.a_split == 2 ? (a.half_f16 ? 14 : 12) : a.a_split ? 8 : 4;   // bf16 modes: A split on the fragment-read side, so ReLU-on-A is fine
     else if (a.a_split) return fail(-1, "gemm: split-pair A needs a bf16 precision and the LDS-direct pipe");
     switch (prec * 8 + add) {
         VLSAT_GEMM_CASE(0, 13) VLSAT_GEMM_CASE(1, 13) VLSAT_GEMM_CASE(6, 13)
+        VLSAT_GEMM_CASE(0, 15) VLSAT_GEMM_CASE(6, 15)
         VLSAT_GEMM_CASE(0, 9) VLSAT_GEMM_CASE(1, 9) VLSAT_GEMM_CASE(6, 9)
         VLSAT_GEMM_CASE(0, 11) VLSAT_GEMM_CASE(1, 11) VLSAT_GEMM_CASE(6, 11)
         VLSAT_GEMM_CASE(0, 4) VLSAT_GEMM_CASE(1, 4) VLSAT_GEMM_CASE(6, 4)
@@ -254,7 +255,7 @@ static bool twin_shapes(const GemmArgs& a, const GemmArgs& b) {
            a.ldg0 == b.ldg0 && a.ldg1 == b.ldg1 && a.act == b.act && a.prec == b.prec && a.a_split == b.a_split && a.r_split == b.r_split &&
            a.c_split == b.c_split && a.c_scale == b.c_scale && a.resid_scale == b.resid_scale && !a.bias == !b.bias && !a.resid == !b.resid &&
            !a.g0 == !b.g0 && !a.g1 == !b.g1 && !a.rowscale == !b.rowscale && a.no_dma == b.no_dma && a.no_ring == b.no_ring &&
-           a.no_p8 == b.no_p8 && a.k_rot == b.k_rot && a.c_f16_cols == b.c_f16_cols && a.g_f16 == b.g_f16 && !a.force_tile && !b.force_tile && !a.ablate && !b.ablate && a.prefetch == b.prefetch;
+           a.no_p8 == b.no_p8 && a.k_rot == b.k_rot && a.c_f16_cols == b.c_f16_cols && a.g_f16 == b.g_f16 && a.half_f16 == b.half_f16 && !a.force_tile && !b.force_tile && !a.ablate && !b.ablate && a.prefetch == b.prefetch;
 }
 // single round of 64 x 64 tiles, two k-slices per step (what run_tiled<64, 64> launches for T <= G), grid.y = 2
 static int launch_t_twin(const GemmArgs& a, const GemmArgs& b, int n_tiles, int grid, hipStream_t s) {
@@ -268,10 +269,11 @@ static int launch_t_twin(const GemmArgs& a, const GemmArgs& b, int n_tiles, int 
     if (prec == 0 && (a.a_split || a.r_split || a.c_split || a.c_scale != 1.f)) return 1;
     if (prec == 0 && dma_ok && !(a.relu_a || b.relu_a)) prec = 4;     // (ReLU-on-A of either problem: the VGPR-staged pipe for both -- same products)
     if (a.a_split == 2 && !(prec == 1 && dma_ok)) return 1;
-    if ((prec == 1 || prec == 3) && dma_ok) prec += a.a_split == 2 ? 12 : a.a_split ? 8 : 4;
+    if ((prec == 1 || prec == 3) && dma_ok) prec += a.a_split == 2 ? (a.half_f16 ? 14 : 12) : a.a_split ? 8 : 4;
     else if (a.a_split) return 1;
     switch (prec * 8 + add) {
         VLSAT_GEMM_CASE(0, 13) VLSAT_GEMM_CASE(1, 13) VLSAT_GEMM_CASE(6, 13)
+        VLSAT_GEMM_CASE(0, 15) VLSAT_GEMM_CASE(6, 15)
         VLSAT_GEMM_CASE(0, 9) VLSAT_GEMM_CASE(1, 9) VLSAT_GEMM_CASE(6, 9)
         VLSAT_GEMM_CASE(0, 11) VLSAT_GEMM_CASE(1, 11) VLSAT_GEMM_CASE(6, 11)
         VLSAT_GEMM_CASE(0, 4) VLSAT_GEMM_CASE(1, 4) VLSAT_GEMM_CASE(6, 4)
@@ -333,8 +335,9 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
         return fail(-1, "gemm: rowscale cannot be combined with resid/g0/g1 (additive operands are accumulator inits)");
     if ((reinterpret_cast<uintptr_t>(a.A) & 15) || (reinterpret_cast<uintptr_t>(a.W) & 15))
         return fail(-1, "gemm: A/W must be 16-byte aligned");
+    if (a.half_f16 && (a.prec != 1 || a.a_split != 2 || a.c_split || a.r_split)) return fail(-1, "gemm: fp16 operands are half-row A launches of the single-rounding precision; their half-row output is c_f16_cols == N");
     if ((a.c_f16_cols || a.g_f16) && a.prec == 0) return fail(-1, "gemm: fp16 half-row columns / tables belong to the bf16 modes (the exact-fp32 kernels read and write fp32)");
-    if (a.c_f16_cols && (a.c_f16_cols % 256 || a.c_f16_cols > a.N || a.c_split)) return fail(-1, "gemm: c_f16_cols must be a multiple of 256 within N of an fp32 output");
+    if (a.c_f16_cols && ((a.c_f16_cols != a.N && a.c_f16_cols % 256) || a.c_f16_cols > a.N || a.c_split)) return fail(-1, "gemm: c_f16_cols must be N or a multiple of 256 within N, of an fp32 output");
     if (a.g_f16 && (a.resid || !(a.g0 || a.g1) || a.N % 256 || ((a.ldg0 | a.ldg1) & 1) || ((reinterpret_cast<uintptr_t>(a.g0) | reinterpret_cast<uintptr_t>(a.g1)) & 7)))
         return fail(-1, "gemm: g_f16 needs gathered rows, no residual, N % 256 == 0 and 8-byte aligned tables");
     const int G = slots();
@@ -346,7 +349,7 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t s) {
     // Large M; exact fp32, single-rounding bf16 with half-row operands or split-bf16 with split-pair operands: the full rounds of 256 x 256 tiles go to the 8-phase
     // kernel (gemm_bf16_p8.hip: one 8-wave block per CU), the remaining row panels to the kernels below
     if (((a.prec == 1 && a.a_split == 2) || (a.prec == 3 && a.a_split == 1) || (a.prec == 0 && !a.a_split && !a.c_split && !a.r_split)) && !a.no_dma && !a.no_ring &&
-        !a.no_p8 && !a.rowscale && !a.clock_probe && (!a.c_f16_cols || (a.c_f16_cols == a.N && a.prec == 1 && !a.resid && !a.g0 && !a.g1 && !a.relu_a)) && a.N % 256 == 0 && a.K % 128 == 0 &&
+        !a.no_p8 && !a.rowscale && !a.clock_probe && (!a.c_f16_cols || (a.c_f16_cols == a.N && a.prec == 1 && !a.resid && (a.half_f16 || (!a.g0 && !a.g1 && !a.relu_a)))) && a.N % 256 == 0 && a.K % 128 == 0 &&
         ((size_t)a.M + 256) * a.lda * 4 < (1ull << 32) && ((size_t)a.M + 256) * a.ldc * 4 < (1ull << 32) &&
         ((size_t)a.N + 256) * a.ldw * 4 < (1ull << 32)) {
         const int G1 = G / 2;

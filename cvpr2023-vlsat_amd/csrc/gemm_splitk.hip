@@ -131,7 +131,7 @@ int launch_gemm_splitk(const GemmArgs& a, int slots, hipStream_t s, const GemmAr
     const bool dma_ok = !a.no_dma && ((size_t)a.M + 256) * a.lda * 4 < (1ull << 32) && ((size_t)a.N + 256) * a.ldw * 4 < (1ull << 32);
     if (prec == 0 && dma_ok && !relu_a) prec = 4;
     if (a.a_split == 2 && !(prec == 1 && dma_ok)) return 1;
-    if ((prec == 1 || prec == 3) && dma_ok) prec += a.a_split == 2 ? 12 : a.a_split ? 8 : 4;
+    if ((prec == 1 || prec == 3) && dma_ok) prec += a.a_split == 2 ? (a.half_f16 ? 14 : 12) : a.a_split ? 8 : 4;
     else if (a.a_split) return 1;
     const int grid = (int)((T + 7) / 8) * 8 * ks;
     const GemmArgs& b = twin ? *twin : a;
@@ -142,7 +142,7 @@ int launch_gemm_splitk(const GemmArgs& a, int slots, hipStream_t s, const GemmAr
         break;
     switch (prec) {
         VLSAT_SK_CASE(0) VLSAT_SK_CASE(1) VLSAT_SK_CASE(3) VLSAT_SK_CASE(4) VLSAT_SK_CASE(5) VLSAT_SK_CASE(7)
-        VLSAT_SK_CASE(9) VLSAT_SK_CASE(11) VLSAT_SK_CASE(13)
+        VLSAT_SK_CASE(9) VLSAT_SK_CASE(11) VLSAT_SK_CASE(13) VLSAT_SK_CASE(15)
         default: return 1;
     }
 #undef VLSAT_SK_CASE

@@ -43,6 +43,9 @@ struct GemmArgs {
     // stored as fp16 HALF ROWS (element n at byte 2 n of the fp32-pitched row, values clamped to +-65504) -- what the node-side projection
     // writes for [P_i | P_j]; g_f16: g0 / g1 are such half rows (launches without a residual).  Halves the bytes nn_edge.0 gathers per edge.
     int c_f16_cols = 0, g_f16 = 0;
+    // fp16 half-row OPERANDS (precision mode "fp16_mixed"): A (a_split == 2) holds fp16 instead of bf16, Whi is an fp16 plane, the products run on
+    // v_mfma_f32_32x32x16_f16 (same rate as bf16 on CDNA4, 2^-12 instead of 2^-9 per operand); half-row outputs then go through c_f16_cols == N
+    int half_f16 = 0;
     int force_tile = 0;                         // experiment (tools/gemm_tile_sweep.py): 1 = 128x128, 2 = 128x64, 3 = 64x128, 4 = 64x64 tiles of gemm_f32_kernel, whatever the heuristic says
     int prefetch = -1;                          // bf16 LDS-direct pipe: slices of look-ahead of the A-panel prefetch (0 off, -1 default)
     int no_dma = 0;                             // debug: VGPR-staged fp32 operands instead of LDS-direct (vlsat_debug_option "gemm_dma")
@@ -197,6 +200,7 @@ int launch_aggregate(const float* gated, int n_ch, const int32_t* rowptr, const 
 
 // w[i] -> bf16 hi[i] + bf16 lo[i] (split-bf16 GEMM weights, one-time)
 int launch_split_bf16(const float* w, size_t n, uint16_t* hi, uint16_t* lo, hipStream_t s);
+int launch_to_f16(const float* w, size_t n, uint16_t* out, hipStream_t s);        // fp16 plane (precision mode fp16_mixed)
 
 // ---- eval ranking step: softmax + top-k ranks by counting ----
 int launch_softmax_rows(const float* x, int ld, int rows, int cols, float* out, int log_out, hipStream_t s);

@@ -28,8 +28,17 @@ constexpr int PB_W = 128 * PB_PW2;        // bytes of one W2 plane
 constexpr int PB_W3 = 128 * PB_PW3;       // bytes of one W3 slice plane
 constexpr int PB_MAXNC = 6;
 
-template <int PL>
+template <int PL, bool F16 = false>
 __device__ __forceinline__ void store8(char* plane0, int plane_stride, int off, const f32x4& a, const f32x4& b) {
+    if constexpr (F16) {                     // (TERMS = 2: single-rounded fp16 operands, precision mode fp16_mixed)
+        typedef _Float16 f16x4_s __attribute__((ext_vector_type(4)));
+        f32x4 ca, cb;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { ca[c] = __builtin_amdgcn_fmed3f(a[c], -65504.f, 65504.f); cb[c] = __builtin_amdgcn_fmed3f(b[c], -65504.f, 65504.f); }
+        const bf16x4 g0 = __builtin_bit_cast(bf16x4, __builtin_convertvector(ca, f16x4_s)), g1 = __builtin_bit_cast(bf16x4, __builtin_convertvector(cb, f16x4_s));
+        *reinterpret_cast<bf16x8*>(plane0 + off) = __builtin_shufflevector(g0, g1, 0, 1, 2, 3, 4, 5, 6, 7);
+        return;
+    }
     const bf16x4 h0 = __builtin_convertvector(a, bf16x4), h1 = __builtin_convertvector(b, bf16x4);
     *reinterpret_cast<bf16x8*>(plane0 + off) = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
     if (PL == 2) {
@@ -45,7 +54,8 @@ __global__ __launch_bounds__(512, 2) void pointnet_bf16_kernel(
     const uint16_t* __restrict__ w2h, const uint16_t* __restrict__ w2l, const float* __restrict__ b2,
     const uint16_t* __restrict__ w3h, const uint16_t* __restrict__ w3l, const float* __restrict__ b3, int n_out,
     float* __restrict__ out, int nsplit) {
-    constexpr int PL = TERMS == 1 ? 1 : 2;
+    constexpr int PL = TERMS == 3 ? 2 : 1;
+    constexpr bool F16 = TERMS == 2;             // fp16 operands (w2h / w3h are then fp16 planes)
     constexpr int S1 = (CIN + 4) & ~3;
     constexpr int WREG = 2 * PL * PB_W3 > PL * PB_W ? 2 * PL * PB_W3 : PL * PB_W;      // conv2: [PL][128][144]; conv3: 2 stages of [PL][128][80]
     __shared__ __attribute__((aligned(16))) char smem[PL * PB_H + WREG + 64 * S1 * 4];
@@ -111,8 +121,8 @@ __global__ __launch_bounds__(512, 2) void pointnet_bf16_kernel(
                     for (int k = CIN - 1; k >= 0; --k) a = fmaf(w[k], xin[k], a);
                     hq[c4][c] = fmaxf(a, 0.f);
                 }
-            store8<PL>(sH, PB_H, pp * PB_P1 + cg * 2, hq[0], hq[1]);
-            store8<PL>(sH, PB_H, pp * PB_P1 + cg * 2 + 16, hq[2], hq[3]);
+            store8<PL, F16>(sH, PB_H, pp * PB_P1 + cg * 2, hq[0], hq[1]);
+            store8<PL, F16>(sH, PB_H, pp * PB_P1 + cg * 2 + 16, hq[2], hq[3]);
         }
         // ---- W2 planes [128][64] -> LDS (pitch 144): 128 rows x 8 pieces = 1024 pieces per plane ----
 #pragma unroll
@@ -142,7 +152,7 @@ __global__ __launch_bounds__(512, 2) void pointnet_bf16_kernel(
                         acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[tn], 0, 0, 0);
                         acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[tn], 0, 0, 0);
                     }
-                    acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[tn], 0, 0, 0);
+                    acc[tn] = mfma_h<F16>(ah, bh, acc[tn]);
                 }
             }
         }
@@ -156,8 +166,9 @@ __global__ __launch_bounds__(512, 2) void pointnet_bf16_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float v = fmaxf(acc[tn][r] + bb, 0.f);
-                const __bf16 h = (__bf16)v;
                 char* dst = sH + (wm * 32 + crow32(r, hi)) * PB_P2 + col * 2;
+                if constexpr (F16) { *reinterpret_cast<_Float16*>(dst) = (_Float16)fminf(v, 65504.f); continue; }
+                const __bf16 h = (__bf16)v;
                 *reinterpret_cast<__bf16*>(dst) = h;
                 if (PL == 2) *reinterpret_cast<__bf16*>(dst + PB_H) = (__bf16)(v - (float)h);
             }
@@ -189,7 +200,7 @@ __global__ __launch_bounds__(512, 2) void pointnet_bf16_kernel(
                         acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[tn], 0, 0, 0);
                         acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[tn], 0, 0, 0);
                     }
-                    acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[tn], 0, 0, 0);
+                    acc[tn] = mfma_h<F16>(ah, bh, acc[tn]);
                 }
             }
             if (k4 == 3) {
@@ -237,7 +248,7 @@ int launch_pointnet_bf16(const float* pts, int n_obj, int n_points, int cin, con
     if (n_obj <= 0) return 0;
     if (n_points <= 0) return fail(-1, "pointnet: n_points must be > 0");
     if (n_out % 128 || n_out > 128 * PB_MAXNC) return fail(-1, "pointnet: n_out must be a multiple of 128, <= 768");
-    if (terms != 1 && terms != 3) return fail(-1, "pointnet_bf16: terms must be 1 or 3");
+    if (terms != 1 && terms != 2 && terms != 3) return fail(-1, "pointnet_bf16: terms must be 1, 3 or 2 (single-rounded fp16)");
     const int n_chunks = (n_points + PB_M - 1) / PB_M;
     int nsplit = (256 + n_obj - 1) / n_obj;
     if (nsplit > n_chunks) nsplit = n_chunks;
@@ -245,7 +256,7 @@ int launch_pointnet_bf16(const float* pts, int n_obj, int n_points, int cin, con
     if (nsplit > 1 && launch_zero_f32(out, (size_t)n_obj * n_out, s)) return -1;
 #define VLSAT_PB(CIN, T) hipLaunchKernelGGL((pointnet_bf16_kernel<CIN, T>), dim3(n_obj * nsplit), dim3(512), 0, s, pts, n_points, w1, b1, \
                                             w2h, w2l, b2, w3h, w3l, b3, n_out, out, nsplit)
-#define VLSAT_PB_CASE(CIN) case CIN: if (terms == 3) VLSAT_PB(CIN, 3); else VLSAT_PB(CIN, 1); break;
+#define VLSAT_PB_CASE(CIN) case CIN: if (terms == 3) VLSAT_PB(CIN, 3); else if (terms == 2) VLSAT_PB(CIN, 2); else VLSAT_PB(CIN, 1); break;
     switch (cin) {
         VLSAT_PB_CASE(3) VLSAT_PB_CASE(6) VLSAT_PB_CASE(9)
         default: return fail(-1, "pointnet: point channels must be 3, 6 or 9");

@@ -103,7 +103,11 @@ __global__ __launch_bounds__(256) void layernorm512_kernel(const float* __restri
     if (resid) {
         const float* r = resid + (size_t)row * ldr;
         f32x4 ra, rb;
-        if (r_split == 2) {                                // half rows: bf16 at byte 2 * column
+        if (r_split == 4) {                                // half rows of fp16 (precision mode fp16_mixed)
+            typedef _Float16 f16x4_r __attribute__((ext_vector_type(4)));
+            ra = __builtin_convertvector(reinterpret_cast<const f16x4_r*>(r)[lane], f32x4);
+            rb = __builtin_convertvector(reinterpret_cast<const f16x4_r*>(r)[64 + lane], f32x4);
+        } else if (r_split == 2) {                         // half rows: bf16 at byte 2 * column
             const uint2 ha = reinterpret_cast<const uint2*>(r)[lane], hb = reinterpret_cast<const uint2*>(r)[64 + lane];
             ra = f32x4{__uint_as_float(ha.x << 16), __uint_as_float(ha.x & 0xffff0000u), __uint_as_float(ha.y << 16), __uint_as_float(ha.y & 0xffff0000u)};
             rb = f32x4{__uint_as_float(hb.x << 16), __uint_as_float(hb.x & 0xffff0000u), __uint_as_float(hb.y << 16), __uint_as_float(hb.y & 0xffff0000u)};
@@ -139,6 +143,15 @@ __global__ __launch_bounds__(256) void layernorm512_kernel(const float* __restri
         if (out_split == 1) { a[c] = pack_split(a[c]); b[c] = pack_split(b[c]); }     // bf16 modes: the consumers are GEMM A operands
     }
     float* q = y + (size_t)row * ldy;
+    if (out_split == 4) {                                  // half rows of fp16 (clamped: the consumers are fp16 MFMA operands)
+        typedef _Float16 f16x4_o __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { a[c] = __builtin_amdgcn_fmed3f(a[c], -65504.f, 65504.f); b[c] = __builtin_amdgcn_fmed3f(b[c], -65504.f, 65504.f); }
+        f16x4_o* h = reinterpret_cast<f16x4_o*>(q);
+        h[lane] = __builtin_convertvector(a, f16x4_o);
+        h[64 + lane] = __builtin_convertvector(b, f16x4_o);
+        return;
+    }
     if (out_split == 2) {                                  // half rows: bf16 at byte 2 * column
         typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
         bf16x4_t* h = reinterpret_cast<bf16x4_t*>(q);
@@ -156,7 +169,7 @@ int launch_layernorm(float* x, int ld, int rows, int dim, const float* gamma, co
 int launch_layernorm_to(const float* x, int ld, float* y, int ldy, int rows, int dim, const float* gamma, const float* beta,
                         int relu, int out_split, hipStream_t s, const float* resid, int ldr, int r_split, int x_f16) {
     if (rows <= 0) return 0;
-    if (dim != 512 || (ld & 3) || (ldy & 3) || (resid && ((ldr & 3) || r_split > 2)))
+    if (dim != 512 || (ld & 3) || (ldy & 3) || (resid && ((ldr & 3) || (r_split > 2 && r_split != 4))))
         return fail(-1, "layernorm: dim must be 512, ld a multiple of 4, residual fp32, split pairs or half rows");
     hipLaunchKernelGGL(layernorm512_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, ld, y, ldy, rows, gamma, beta, relu, out_split,
                        resid, ldr, r_split, x_f16);
@@ -562,6 +575,18 @@ __global__ void split_bf16_kernel(const float* __restrict__ w, size_t n, uint16_
     const __bf16 l = (__bf16)(x - (float)h);
     hi[i] = __builtin_bit_cast(uint16_t, h);
     lo[i] = __builtin_bit_cast(uint16_t, l);
+}
+// fp16 plane of a weight matrix (precision mode fp16_mixed): rne, clamped to the finite range
+__global__ void to_f16_kernel(const float* __restrict__ w, size_t n, uint16_t* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = __builtin_bit_cast(uint16_t, (_Float16)fminf(fmaxf(w[i], -65504.f), 65504.f));
+}
+int launch_to_f16(const float* w, size_t n, uint16_t* out, hipStream_t s) {
+    if (!n) return 0;
+    hipLaunchKernelGGL(to_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, n, out);
+    VLSAT_LAUNCH_CHECK("to_f16");
+    return 0;
 }
 int launch_split_bf16(const float* w, size_t n, uint16_t* hi, uint16_t* lo, hipStream_t s) {
     if (!n) return 0;

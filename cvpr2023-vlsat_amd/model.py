@@ -71,7 +71,7 @@ class VLSATModel:
         # attributes MMGNet.validation reads on the model object (reference src/model/model.py:255,361)
         self.iteration, self.eva_res, self.epoch = 0, 0, -1
 
-    PRECISIONS = {"fp32": 0, "bf16": 1, "bf16_mixed": 2, "bf16x3": 3, "bf16x3_attn1": 4}
+    PRECISIONS = {"fp32": 0, "bf16": 1, "bf16_mixed": 2, "bf16x3": 3, "bf16x3_attn1": 4, "fp16_mixed": 5}
 
     def set_gemm_precision(self, mode: str):
         """'fp32' (default, exact-fp32 MFMA: BASELINE configs[1]) | 'bf16x3' (split-bf16 MFMA, three bf16 MFMAs per
@@ -80,7 +80,9 @@ class VLSATModel:
         on the object logits, outside that tolerance -- kept for comparison) | 'bf16x3_attn1' (split-bf16 everywhere except the
         edge cross-attention -- its three projections and the attention itself -- which is single-rounded: the 3D outputs never
         see that block and keep the split-bf16 accuracy, the 2D outputs hold 1e-2 on weights where 'bf16_mixed' does not,
-        profiles/r05_probes/precision_mix_study.txt).  Softmax/LN and HBM tensors stay fp32."""
+        profiles/r05_probes/precision_mix_study.txt) | 'fp16_mixed' ('bf16_mixed' with fp16 instead of bf16 in the half-row tensors and on the
+        matrix cores of the edge-row kernels -- the same MFMA rate, eight times finer rounding; values beyond +-65504 saturate; default head
+        geometry only).  Softmax/LN and HBM tensors stay fp32."""
         if mode not in self.PRECISIONS:
             raise L.VlsatError(f"gemm precision must be one of {sorted(self.PRECISIONS)}")
         L.check(self._lib.vlsat_set_gemm_precision(self._h, self.PRECISIONS[mode]))
@@ -90,14 +92,16 @@ class VLSATModel:
 
     @torch.no_grad()
     def auto_precision(self, obj_points, obj_2d_feats, edge_indices, descriptor=None, batch_ids=None, tol: float = 1e-2,
-                       margin: float = 0.5, candidates: Sequence[str] = ("bf16_mixed", "bf16x3_attn1", "bf16x3")) -> dict:
+                       margin: float = 0.5, candidates: Sequence[str] = ("bf16_mixed", "fp16_mixed", "bf16x3_attn1", "bf16x3")) -> dict:
         """Pick the fastest bf16 mode whose outputs stay inside ``tol`` on THIS checkpoint: one calibration batch is run in
         split-bf16 ('bf16x3', ~1e-5 from fp32 at Xavier scale and 1e-3 up to twice that) as the
         reference and in each faster candidate; the first candidate whose largest output difference is below ``margin * tol``
         is set (the margin covers batches the calibration did not see).  'bf16_mixed' holds BASELINE configs[2]'s 1e-2 on
         Xavier-scale weights with a 2x margin but not on a network whose weights amplify roundoff (LayerNorm gains above
         ~1.5, section 8): the error of the single-rounding modes is the rounding of the MFMA operands themselves (storing the
-        edge tensors as hi/lo pairs instead of bf16 leaves it unchanged, measured), so the remedy is the mode, not a format.
+        edge tensors as hi/lo pairs instead of bf16 leaves it unchanged, measured), so the remedy is the mode, not a format:
+        'fp16_mixed' (the same kernels on fp16 operands: 1/8 of the rounding, 3-4 % slower, default head geometry only -- skipped elsewhere),
+        then 'bf16x3_attn1', then split-bf16.
         Returns {'mode', 'errors': {candidate: max-abs difference}}.  Costs one forward per candidate plus one reference."""
         prev = self.gemm_precision
         self.set_gemm_precision("bf16x3")
@@ -108,6 +112,8 @@ class VLSATModel:
                 errors[mode] = 0.0
                 chosen = mode
                 break
+            if mode == "fp16_mixed" and not (self.config.NUM_HEADS == 8 and self.config.DIM_ATTEN == 256):
+                continue                        # (built for the default head geometry)
             self.set_gemm_precision(mode)
             got = self.forward(obj_points, obj_2d_feats, edge_indices, descriptor, batch_ids)
             errors[mode] = max(float((g - r).abs().max()) if g.numel() else 0.0 for g, r in zip(got, ref))

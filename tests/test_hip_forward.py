@@ -200,7 +200,7 @@ def test_random_graphs_vs_oracle(seed):
     _check(run_hip(cfg, b), run_oracle(cfg, b), TIGHT, f"random graph batch #{seed} ({len(scenes)} scenes, E={len(perm)})")
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16_mixed", "bf16x3_attn1"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16_mixed", "bf16x3_attn1", "fp16_mixed"])
 def test_two_stream_mode_is_bit_identical(precision):
     """Two-stream plans run the forward on up to three lanes (engine_forward.hip): the dependency-exact schedule of round 5
     ("sched" = 1: 3D chain / 2D edge chain / 2D node chain, coupled by one event per data-flow edge, the 3D chain up to a layer
@@ -435,7 +435,7 @@ def test_cfg3_split_bf16_gemms(golden_dir):
     m2.close()
 
 
-@pytest.mark.parametrize("mode,tol", [("bf16x3", 1e-3), ("bf16_mixed", 1e-2), ("bf16x3_attn1", 1e-2)])
+@pytest.mark.parametrize("mode,tol", [("bf16x3", 1e-3), ("bf16_mixed", 1e-2), ("bf16x3_attn1", 1e-2), ("fp16_mixed", 2e-3)])
 def test_cfg3_full_batch_all_scenes(bench_batch_oracle, mode, tol):
     """BASELINE configs[2] at the config's own batch (64 scenes x 40 x 256, L=3): every scene against the fp32 oracle.
     bf16x3 (three bf16 MFMAs per product) must stay inside the fp32 contract (1e-3); the mixed mode (single-rounded bf16
@@ -459,7 +459,7 @@ def test_cfg3_full_batch_all_scenes(bench_batch_oracle, mode, tol):
             alt = [o.cpu() for o in m(d["obj_points"], d["obj_2d_feats"], d["edge_indices"], d["descriptor"], d["batch_ids"])]
             pa = _per_scene_err(alt, ref, S, N, E)
             print(f"{mode} with {opt}=0: worst scene at {float(pa.max()):.2e}")
-            assert float(pa.max()) < tol, (mode, opt)
+            assert float(pa.max()) < (1e-2 if mode == "fp16_mixed" else tol), (mode, opt)      # (fp16_mixed without its tensor formats / kernels is bf16_mixed: that mode's contract)
             m.debug_option(opt, 1)
     finally:
         m.close()

@@ -71,7 +71,7 @@ def test_fused_gate_aggregation_is_bit_identical(mode, fuse):
     m.close()
 
 
-@pytest.mark.parametrize("precision,sched", [("fp32", -1), ("bf16_mixed", -1), ("bf16_mixed", 1), ("fp32", 1), ("bf16x3_attn1", 1)])
+@pytest.mark.parametrize("precision,sched", [("fp32", -1), ("bf16_mixed", -1), ("bf16_mixed", 1), ("fp32", 1), ("bf16x3_attn1", 1), ("fp16_mixed", 1)])
 def test_replicas_on_threads_are_bit_identical_to_the_single_threaded_forward(precision, sched):
     """Model replicas driven from several host threads on several streams (evaluate.validation(workers=K)) must give, scene by
     scene, the bits of the single-threaded forward -- no host wait between the forwards of a thread.  (The 1-in-20 000 fault

@@ -29,7 +29,7 @@ for sc in [float(x) for x in a.scales.split(",")]:
         c = {k: torch.from_numpy(v) for k, v in synth.collate([scenes[s]]).items()}
         refs[s] = O.forward(w64, cfg, c["obj_points"].double(), c["obj_2d_feats"].double(), c["edge_indices"], c["descriptor"].double(), c["batch_ids"])
     m = VLSATModel(cfg, "cuda:0").load_state(w).eval()
-    for mode, opts in (("fp32", {}), ("bf16x3", {}), ("bf16_mixed", {}), ("bf16_mixed", {"half_fmt": 0}), ("bf16", {})):
+    for mode, opts in (("fp32", {}), ("bf16x3", {}), ("bf16_mixed", {}), ("fp16_mixed", {}), ("bf16x3_attn1", {}), ("bf16_mixed", {"half_fmt": 0}), ("bf16", {})):
         m.set_gemm_precision(mode)
         try:
             for k, v in opts.items():
