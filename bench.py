@@ -476,7 +476,7 @@ def main():
                 model.debug_option("prof_dual", 1)
             r["classes"] = cl
             return r
-        for mode in ("bf16x3", "bf16x3_attn1", "bf16_mixed"):
+        for mode in ("bf16x3", "bf16x3_attn1", "bf16_mixed", "fp16_mixed"):
             model.set_gemm_precision(mode)
             r = two_runs(d, n_scenes, args.steps, args.warmup)
             v = n_scenes * args.steps / r["dt"]
@@ -490,7 +490,7 @@ def main():
             if mode == "bf16_mixed":             # the step after the path behind the fastest forward (there the ranking weighs most)
                 ev = eval_leg(model, list(scenes), d, args.objects, dev)
                 ev_mode = {k: ev[k] for k in ("what", "ms_forward_plus_ranking", "scenes_per_s_per_gpu", "reference_compatible_rank_lists", "loop_of_8_batches")}
-            extra.append({"workload": f"BASELINE configs[2]: 64 scenes x 40 objects x 256 pts, L=3, {mode}", "dtype": MODE_DTYPE[mode], "evaluation": ev_mode, "two_steps_in_flight": pipelined,
+            extra.append({"workload": f"BASELINE configs[2]{' on fp16 instead of bf16' if mode == 'fp16_mixed' else ''}: 64 scenes x 40 objects x 256 pts, L=3, {mode}", "dtype": MODE_DTYPE[mode], "evaluation": ev_mode, "two_steps_in_flight": pipelined,
                           "timing": "value: steps without events on the shipped schedule; roofline: the same steps profiled on one stream",
                           "tolerance": 1e-2, "value": round(v, 2), "unit": "scenes/s", "ms_per_step": round(r["dt"] / args.steps * 1e3, 3),
                           "median_ms_per_step": round(r["median_ms"], 3), "steps": args.steps, "max_abs_err_vs_cpu_oracle": e,

@@ -15,6 +15,7 @@ tools/profile_run.sh r06/prof_fp32 --no-extra > /dev/null 2>&1
 tools/profile_run.sh r06/prof_cfg3 --gemm-precision bf16x3 --no-extra > /dev/null 2>&1
 tools/profile_run.sh r06/prof_cfg3_mixed --gemm-precision bf16_mixed --no-extra > /dev/null 2>&1
 tools/profile_run.sh r06/prof_cfg3_attn1 --gemm-precision bf16x3_attn1 --no-extra > /dev/null 2>&1
+tools/profile_run.sh r06/prof_cfg3_f16 --gemm-precision fp16_mixed --no-extra > /dev/null 2>&1
 fi
 if [[ $PART == *b* ]]; then
 tools/profile_run.sh r06/prof_cfg5_fp32 --scenes 1 --objects 200 --points 1024 --no-extra > /dev/null 2>&1
@@ -73,6 +74,7 @@ python tools/fuzz_forward.py --iters 120 > "$OUT/fuzz_forward.txt" 2>&1
 python tools/soak_forward.py > "$OUT/soak_forward.txt" 2>&1
 python tools/replica_race_probe.py --scenes 120 --passes 3 > "$OUT/replica_race_fp32.txt" 2>&1
 python tools/replica_race_probe.py --scenes 120 --passes 3 --gemm-precision bf16_mixed > "$OUT/replica_race_bf16_mixed.txt" 2>&1
+python tools/replica_race_probe.py --scenes 120 --passes 2 --gemm-precision fp16_mixed > "$OUT/replica_race_fp16_mixed.txt" 2>&1
 python -m pytest tests -q -m gpu -rf 2>&1 | grep -E "^FAILED|passed|failed|error" | tail -12 > "$OUT/tests_gpu.log"
 fi
 du -sh "$OUT"; ls "$OUT"

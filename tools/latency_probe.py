@@ -26,7 +26,7 @@ def main():
     ap.add_argument("--scenes", type=int, default=60)
     ap.add_argument("--points", type=int, default=256)
     ap.add_argument("--layers", type=int, default=3)
-    ap.add_argument("--gemm-precision", default="fp32", choices=["fp32", "bf16x3", "bf16_mixed", "bf16"])
+    ap.add_argument("--gemm-precision", default="fp32", choices=["fp32", "bf16x3", "bf16_mixed", "bf16", "fp16_mixed", "bf16x3_attn1"])
     ap.add_argument("--debug-option", action="append", default=[], metavar="NAME=VALUE")
     ap.add_argument("--single-only", action="store_true", help="skip the all-scenes-in-one-call comparison (clean kernel traces)")
     a = ap.parse_args()

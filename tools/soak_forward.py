@@ -25,7 +25,7 @@ def main():
     batch = synth.collate([synth.make_scene(40, 256, 1000 + s) for s in range(a.scenes)])
     small = [synth.collate([synth.make_scene(n, 128, 3000 + n)]) for n in (9, 23, 40, 57, 80)]
     bad_total = 0
-    for mode in ("fp32", "bf16x3", "bf16_mixed"):
+    for mode in ("fp32", "bf16x3", "bf16_mixed", "fp16_mixed"):
         m = VLSATModel(cfg, "cuda:0").load_state(w).eval().set_gemm_precision(mode)
         d = {k: torch.from_numpy(v).to("cuda:0") for k, v in batch.items()}
         ds = [{k: torch.from_numpy(v).to("cuda:0") for k, v in b.items()} for b in small]

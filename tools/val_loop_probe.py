@@ -27,7 +27,7 @@ def main():
     ap.add_argument("--points", type=int, default=256)
     ap.add_argument("--layers", type=int, default=3)
     ap.add_argument("--objects", default="9,80", help="range of objects per scene (3RScan: 9..80), or one number")
-    ap.add_argument("--gemm-precision", default="fp32", choices=["fp32", "bf16x3", "bf16_mixed"])
+    ap.add_argument("--gemm-precision", default="fp32", choices=["fp32", "bf16x3", "bf16_mixed", "fp16_mixed", "bf16x3_attn1"])
     ap.add_argument("--workers", default="1,2,4,6,8")
     ap.add_argument("--merge", default="4,8,16", help="also: K workers each collating B consecutive one-scene batches into one call (evaluate.merge_batches)")
     ap.add_argument("--debug-option", action="append", default=[], metavar="NAME=VALUE", help="vlsat_debug_option of the model (replicas inherit it)")
