@@ -499,7 +499,7 @@ def main():
         db = {k: torch.from_numpy(v).to(dev) for k, v in big.items()}
         falg5 = f_alg(200, 1024, 200 * 199, args.layers)
         gold = os.path.join(ROOT, "tests", "golden", "cfg5_n200_p1024_l3_sub.npz")
-        for mode in ("fp32", "bf16_mixed"):
+        for mode in ("fp32", "bf16_mixed", "fp16_mixed"):
             model.set_gemm_precision(mode)
             r = two_runs(db, 1, 5, 2)
             v = 5 / r["dt"]

@@ -209,3 +209,18 @@ def test_fp16_mixed_has_the_margin_bf16_mixed_lacks():
         print(f"stress x{scale}: fp16_mixed {worst['fp16_mixed']:.2e}, bf16_mixed {worst['bf16_mixed']:.2e}")
         assert worst["fp16_mixed"] < tol16, (scale, worst)
         assert worst["bf16_mixed"] > bf_above, (scale, worst)          # (the margin is the point: if bf16_mixed ever gets here, tighten tol16)
+
+
+def test_fp16_mixed_is_refused_where_it_is_not_built():
+    """Mode 5 exists for the default head geometry (NUM_HEADS 8, DIM_ATTEN 256: the shipped gate and attention kernels); elsewhere the
+    library says so instead of running bf16 kernels on fp16 bits, and auto_precision skips the candidate."""
+    from vlsat_amd import lib as L
+    for kw in (dict(NUM_HEADS=4), dict(NUM_HEADS=16), dict(DIM_ATTEN=512)):
+        cfg = VLSATConfig(N_LAYERS=1, **kw)
+        m = VLSATModel(cfg, DEV).load_state(synth.make_weights(cfg)).eval()
+        with pytest.raises(L.VlsatError, match="fp16_mixed"):
+            m.set_gemm_precision("fp16_mixed")
+        b, d = _batch(2, 9, 32, seed0=4800)
+        r = m.auto_precision(d["obj_points"], d["obj_2d_feats"], d["edge_indices"], d["descriptor"], d["batch_ids"], tol=1e-2)
+        assert "fp16_mixed" not in r["errors"] and r["mode"] in ("bf16_mixed", "bf16x3_attn1", "bf16x3"), r
+        m.close()
