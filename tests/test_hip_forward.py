@@ -416,6 +416,10 @@ def test_cfg3_split_bf16_gemms(golden_dir):
         got = [o.cpu() for o in m(d["obj_points"], d["obj_2d_feats"], d["edge_indices"], d["descriptor"], d["batch_ids"])]
         errs = _check(got, [z[n] for n in NAMES], 1e-2, "cfg3 bf16x3 vs reference golden")
         assert max(errs.values()) < 1e-3, errs                  # in practice fp32-tolerance too
+        for mode, tol in (("bf16_mixed", 1e-2), ("bf16x3_attn1", 1e-2), ("fp16_mixed", 2e-3)):       # the faster modes against the same reference-made golden
+            m.set_gemm_precision(mode)
+            gm = [o.cpu() for o in m(d["obj_points"], d["obj_2d_feats"], d["edge_indices"], d["descriptor"], d["batch_ids"])]
+            _check(gm, [z[n] for n in NAMES], tol, f"cfg3 {mode} vs reference golden")
         m.set_gemm_precision("bf16")
         got1 = [o.cpu() for o in m(d["obj_points"], d["obj_2d_feats"], d["edge_indices"], d["descriptor"], d["batch_ids"])]
         _check(got1, [z[n] for n in NAMES], 1e-1, "single-rounding bf16 vs reference golden (informational)")
