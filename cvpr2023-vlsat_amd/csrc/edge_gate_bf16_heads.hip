@@ -24,6 +24,18 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 template <int TERMS, int KS, int DK, int DOX>
 __global__ __launch_bounds__(DK == 128 ? 512 : 256, DK == 128 ? 1 : 2) void edge_gate_bf16_hd_kernel(GateArgs p, int n_heads) {
     constexpr int PL = TERMS == 1 ? 1 : 2;
+    constexpr bool F16 = KS == 3;                 // KS 3: fp16 half rows and fp16 operands (precision mode fp16_mixed; TERMS = 1), as in edge_gate_bf16.hip
+    auto cv4 = [](const f32x4& x) {
+        if constexpr (F16) {
+            typedef _Float16 f16x4_g __attribute__((ext_vector_type(4)));
+            f32x4 y;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) y[c] = __builtin_amdgcn_fmed3f(x[c], -65504.f, 65504.f);
+            return __builtin_bit_cast(bf16x4, __builtin_convertvector(y, f16x4_g));
+        } else {
+            return __builtin_convertvector(x, bf16x4);
+        }
+    };
     constexpr int HID = 2 * DK, TO = HID / 32, MO = (DOX + 31) / 32, NK1 = DK / 16;
     constexpr int P0 = 2 * DK + 16, P3 = 2 * HID + 8;        // plane row pitches in bytes
     constexpr int W0B = HID * P0, W3B = MO * 32 * P3;
@@ -39,7 +51,7 @@ __global__ __launch_bounds__(DK == 128 ? 512 : 256, DK == 128 ? 1 : 2) void edge
     for (int i = tid; i < HID * (DK / 4); i += NT) {      // four fp32 -> four bf16 (8 B) per plane
         const int r = i / (DK / 4), c4 = (i % (DK / 4)) * 4;
         const f32x4 x = *reinterpret_cast<const f32x4*>(p.w0k + r * DK + c4);
-        const bf16x4 h = __builtin_convertvector(x, bf16x4);
+        const bf16x4 h = cv4(x);
         *reinterpret_cast<bf16x4*>(sW0 + r * P0 + c4 * 2) = h;
         if (PL == 2) *reinterpret_cast<bf16x4*>(sW0 + W0B + r * P0 + c4 * 2) = __builtin_convertvector(x - __builtin_convertvector(h, f32x4), bf16x4);
     }
@@ -47,7 +59,7 @@ __global__ __launch_bounds__(DK == 128 ? 512 : 256, DK == 128 ? 1 : 2) void edge
         const int r = i / (HID / 4), c4 = (i % (HID / 4)) * 4;
         f32x4 x = {0.f, 0.f, 0.f, 0.f};
         if (r < DOX) x = *reinterpret_cast<const f32x4*>(p.w3 + r * HID + c4);
-        const bf16x4 h = __builtin_convertvector(x, bf16x4);
+        const bf16x4 h = cv4(x);
         *reinterpret_cast<bf16x4*>(sW3 + r * P3 + c4 * 2) = h;
         if (PL == 2) *reinterpret_cast<bf16x4*>(sW3 + W3B + r * P3 + c4 * 2) = __builtin_convertvector(x - __builtin_convertvector(h, f32x4), bf16x4);
     }
@@ -68,7 +80,7 @@ __global__ __launch_bounds__(DK == 128 ? 512 : 256, DK == 128 ? 1 : 2) void edge
             const float* zrow = p.kproj + (size_t)e * 512 + h * DK + 8 * hi;
 #pragma unroll
             for (int ks = 0; ks < NK1; ++ks) {
-                if (KS == 2) {                            // eight bf16 = one 16-byte load
+                if (KS >= 2) {                            // eight bf16 (fp16) = one 16-byte load
                     zh[ks] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(p.kproj + (size_t)e * 512) + (h * DK + 8 * hi + 16 * ks) * 2);
                     zl[ks] = zh[ks];
                     continue;
@@ -119,7 +131,7 @@ __global__ __launch_bounds__(DK == 128 ? 512 : 256, DK == 128 ? 1 : 2) void edge
                         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, zh[ks], acc, 0, 0, 0);
                         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, zl[ks], acc, 0, 0, 0);
                     }
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, zh[ks], acc, 0, 0, 0);
+                    acc = mfma_h<F16>(ah, zh[ks], acc);
                 }
             }
             // hidden = relu(acc + Gq[src, h*HID + o]),  o = to*32 + 8*r4 + 4*hi + c  (registers r = 4 r4 + c)
@@ -135,7 +147,7 @@ __global__ __launch_bounds__(DK == 128 ? 512 : 256, DK == 128 ? 1 : 2) void edge
                 f32x4 p0, p1;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) { p0[c] = hid[8 * half + c]; p1[c] = hid[8 * half + 4 + c]; }
-                const bf16x4 h0 = __builtin_convertvector(p0, bf16x4), h1 = __builtin_convertvector(p1, bf16x4);
+                const bf16x4 h0 = cv4(p0), h1 = cv4(p1);
                 const bf16x8 hh = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
                 bf16x8 hl = hh;
                 if (PL == 2) {
@@ -155,7 +167,7 @@ __global__ __launch_bounds__(DK == 128 ? 512 : 256, DK == 128 ? 1 : 2) void edge
                         lg[mo] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, hh, lg[mo], 0, 0, 0);
                         lg[mo] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, hl, lg[mo], 0, 0, 0);
                     }
-                    lg[mo] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, hh, lg[mo], 0, 0, 0);
+                    lg[mo] = mfma_h<F16>(wh, hh, lg[mo]);
                 }
             }
         }
@@ -218,7 +230,7 @@ int pick(const GateArgs& a, int n_heads, int terms, int ks, hipStream_t s) {
         if constexpr (DK == 128) return 1;                 // (two plane sets do not fit the LDS)
         else return ks ? run<3, 1, DK, DOX>(a, n_heads, s) : run<3, 0, DK, DOX>(a, n_heads, s);
     }
-    return ks == 2 ? run<1, 2, DK, DOX>(a, n_heads, s) : ks ? run<1, 1, DK, DOX>(a, n_heads, s) : run<1, 0, DK, DOX>(a, n_heads, s);
+    return ks == 3 ? run<1, 3, DK, DOX>(a, n_heads, s) : ks == 2 ? run<1, 2, DK, DOX>(a, n_heads, s) : ks ? run<1, 1, DK, DOX>(a, n_heads, s) : run<1, 0, DK, DOX>(a, n_heads, s);
 }
 
 }  // namespace
@@ -235,7 +247,7 @@ int launch_edge_gate_bf16_heads(const GateArgs& a, int n_heads, int dk, int dox,
     if (a.n_edges <= 0) return 0;
     if ((a.ld_node & 3) || (a.gq_off & 3) || (a.v_off & 3)) return fail(-1, "edge_gate: ld_node/gq_off/v_off must be multiples of 4");
     if (terms != 1 && terms != 3) return fail(-1, "edge_gate_bf16: terms must be 1 or 3");
-    if (kproj_split == 2 && terms != 1) return fail(-1, "edge_gate_bf16: half-row kproj needs terms = 1");
+    if (kproj_split >= 2 && terms != 1) return fail(-1, "edge_gate_bf16: half-row kproj needs terms = 1");
     if (n_heads * dk != 512) return 1;
     int r = 1;
 #define VLSAT_GH(DK, DOX) if (dk == DK && dox == DOX) r = pick<DK, DOX>(a, n_heads, terms, kproj_split, s)

@@ -234,7 +234,6 @@ int gcn_block(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const GcnW& w, float
         const double dk = D / h->H, dox = A / h->H;
         // the gate at 8 x (64, 32) in any precision, max aggregation, no debug tap: the aggregation happens inside the gate kernel (no [E, 256]
         // tensor of gated messages, no aggregate launch); the start values go in first
-        if (h->half_f16 && gate16h) return fail(VLSAT_ESTATE, "gate: the head-geometry template has no fp16 variant (precision mode 5 runs the shipped gate kernel)");
         const bool shipped_kernel = !gate16h && default_heads(h) && !(h->gate_heads_mfma == 2 && !gate16);     // edge_gate.hip / edge_gate_bf16.hip
         // (fp32: measured neutral -- 2196-2201 vs 2195 scenes/s -- and it moves waiting time into the GEMM class of the two-stream
         //  profile, so the exact-fp32 mode keeps the separate aggregate launch unless "gate_fuse_agg" is 2)
@@ -246,7 +245,7 @@ int gcn_block(vlsat_ctx* h, vlsat_plan_s* p, hipStream_t s, const GcnW& w, float
         }
         Scope scope(h, s, PC_GATE, (double)E * h->H * (2.0 * dk * 2 * dk + 2.0 * 2 * dk * dox));
         if (gate16h) {
-            RUN(launch_edge_gate_bf16_heads(g, h->H, D / h->H, A / h->H, h->prec_edge == 3 ? 3 : 1, S, s));
+            RUN(launch_edge_gate_bf16_heads(g, h->H, D / h->H, A / h->H, h->prec_edge == 3 ? 3 : 1, (S == 2 && h->half_f16) ? 3 : S, s));
         } else if (!default_heads(h) || (h->gate_heads_mfma == 2 && !gate16)) {     // (2: the shipped geometry on the template as well -- A/B)
             int r = h->gate_heads_mfma ? launch_edge_gate_heads(g, h->H, D / h->H, A / h->H, s) : 1;
             if (r < 0) return r;

@@ -460,8 +460,7 @@ int vlsat_set_gemm_precision(vlsat_handle h, int32_t mode) {
     if (!h) return fail(VLSAT_EINVAL, "null handle");
     if (mode < 0 || mode > 5) return fail(VLSAT_EINVAL, "gemm precision must be 0 (fp32), 1 (bf16), 2 (mixed), 3 (bf16x3), 4 (bf16x3 with a single-rounded edge attention) or 5 (mixed on fp16)");
     // mode 5: mode 2 with fp16 half rows and v_mfma_f32_32x32x16_f16 on the edge-row kernels (GEMM, attention, gate): the same rate, 2^-12 instead of
-    // 2^-9 per stored value and operand; built for the default head geometry (8 heads, DIM_ATTEN 256)
-    if (mode == 5 && !(h->H == 8 && h->A == 256)) return fail(VLSAT_EINVAL, "gemm precision 5 (fp16_mixed) is built for NUM_HEADS 8, DIM_ATTEN 256");
+    // 2^-9 per stored value and operand
     ++h->config_epoch;
     h->prec = mode;
     h->half_f16 = mode == 5;

@@ -543,8 +543,8 @@ int launch_flash_attn_bf16(const float* Q, int ldq, const float* K, const float*
     if (!flash_attn_bf16_supports(head_dim, terms, use_tr, io_split)) return fail(-1, "flash_attn_bf16: head dim / format combination not built");
     if ((ldq | ldkv | ldo) & 3) return fail(-1, "flash_attn: leading dims must be multiples of 4");
     if (terms != 1 && terms != 3) return fail(-1, "flash_attn_bf16: terms must be 1 or 3");
-    if (io_split == 3 && (FB_D != 64 || !(split && split->rows > 0 && (size_t)split->rows * (size_t)ldkv * 4 < (1ull << 32))))
-        return fail(-1, "flash_attn_bf16: fp16 half rows are built for head dim 64 and scenes addressable with 32-bit offsets");
+    if (io_split == 3 && !(split && split->rows > 0 && (size_t)split->rows * (size_t)ldkv * 4 < (1ull << 32)))
+        return fail(-1, "flash_attn_bf16: fp16 half rows are built for scenes addressable with 32-bit offsets (the LDS-direct kernel)");
     FlashSplit sp{};
     if (split && split->parts > 1) {
         sp = *split;
@@ -563,6 +563,11 @@ int launch_flash_attn_bf16(const float* Q, int ldq, const float* K, const float*
 #define VLSAT_FA(T, R, S) hipLaunchKernelGGL((flash_attn_bf16_kernel<T, R, S>), dim3(n_tiles), dim3(256), 0, s, Q, K, V, O, ldq, ldkv, ldo, tiles, n_tiles, scale_log2e, sp)
 #define VLSAT_FAD(T, S, P, D) hipLaunchKernelGGL((flash_attn_bf16_kernel<T, true, S, P, D>), dim3(n_tiles), dim3(256), 0, s, Q, K, V, O, ldq, ldkv, ldo, tiles, n_tiles, scale_log2e, sp)
     if (FB_D != 64) {          // 16 / 4 heads: the formats the forward uses (the transpose-read path; split-bf16 only at 32)
+        if (io_split == 3) {                         // fp16 half rows
+            if (use_tr == 2 || !use_tr || terms != 1) return fail(-1, "flash_attn_bf16: fp16 half rows are built for the LDS-direct single-rounding kernel only");
+            if (FB_D == 32) hipLaunchKernelGGL((flash_attn_bf16_kernel<1, true, 3, 3, 32, 2>), dim3(n_tiles), dim3(256), 0, s, Q, K, V, O, ldq, ldkv, ldo, tiles, n_tiles, scale_log2e, sp);
+            else hipLaunchKernelGGL((flash_attn_bf16_kernel<1, true, 3, 3, 128, 2>), dim3(n_tiles), dim3(256), 0, s, Q, K, V, O, ldq, ldkv, ldo, tiles, n_tiles, scale_log2e, sp);
+        } else
         if (io_split == 2 && use_tr != 2) {          // half rows: LDS-direct K/V staging, one tile ahead
             if (FB_D == 32) hipLaunchKernelGGL((flash_attn_bf16_kernel<1, true, 2, 3, 32, 2>), dim3(n_tiles), dim3(256), 0, s, Q, K, V, O, ldq, ldkv, ldo, tiles, n_tiles, scale_log2e, sp);
             else hipLaunchKernelGGL((flash_attn_bf16_kernel<1, true, 2, 3, 128, 2>), dim3(n_tiles), dim3(256), 0, s, Q, K, V, O, ldq, ldkv, ldo, tiles, n_tiles, scale_log2e, sp);

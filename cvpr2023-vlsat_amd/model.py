@@ -81,8 +81,7 @@ class VLSATModel:
         edge cross-attention -- its three projections and the attention itself -- which is single-rounded: the 3D outputs never
         see that block and keep the split-bf16 accuracy, the 2D outputs hold 1e-2 on weights where 'bf16_mixed' does not,
         profiles/r05_probes/precision_mix_study.txt) | 'fp16_mixed' ('bf16_mixed' with fp16 instead of bf16 in the half-row tensors and on the
-        matrix cores of the edge-row kernels -- the same MFMA rate, eight times finer rounding; values beyond +-65504 saturate; default head
-        geometry only).  Softmax/LN and HBM tensors stay fp32."""
+        matrix cores of the edge-row kernels -- the same MFMA rate, eight times finer rounding; values beyond +-65504 saturate).  Softmax/LN and HBM tensors stay fp32."""
         if mode not in self.PRECISIONS:
             raise L.VlsatError(f"gemm precision must be one of {sorted(self.PRECISIONS)}")
         L.check(self._lib.vlsat_set_gemm_precision(self._h, self.PRECISIONS[mode]))
@@ -100,7 +99,7 @@ class VLSATModel:
         Xavier-scale weights with a 2x margin but not on a network whose weights amplify roundoff (LayerNorm gains above
         ~1.5, section 8): the error of the single-rounding modes is the rounding of the MFMA operands themselves (storing the
         edge tensors as hi/lo pairs instead of bf16 leaves it unchanged, measured), so the remedy is the mode, not a format:
-        'fp16_mixed' (the same kernels on fp16 operands: 1/8 of the rounding, 3-4 % slower, default head geometry only -- skipped elsewhere),
+        'fp16_mixed' (the same kernels on fp16 operands: 1/8 of the rounding, 3-4 % slower),
         then 'bf16x3_attn1', then split-bf16.
         Returns {'mode', 'errors': {candidate: max-abs difference}}.  Costs one forward per candidate plus one reference."""
         prev = self.gemm_precision
@@ -112,8 +111,6 @@ class VLSATModel:
                 errors[mode] = 0.0
                 chosen = mode
                 break
-            if mode == "fp16_mixed" and not (self.config.NUM_HEADS == 8 and self.config.DIM_ATTEN == 256):
-                continue                        # (built for the default head geometry)
             self.set_gemm_precision(mode)
             got = self.forward(obj_points, obj_2d_feats, edge_indices, descriptor, batch_ids)
             errors[mode] = max(float((g - r).abs().max()) if g.numel() else 0.0 for g, r in zip(got, ref))

@@ -148,8 +148,7 @@ int vlsat_forward_train(vlsat_handle h, vlsat_plan p,
  * 1e-2 on weights where mode 2 does not;
  * 5 = mode 2 on FP16: the half-row tensors between the edge-row kernels hold fp16 instead of bf16 and those kernels (8-phase / ring / small
  * GEMMs, edge attention, gate, PointNet) run v_mfma_f32_32x32x16_f16 -- the bf16 rate on CDNA4, 2^-12 instead of 2^-9 per stored value and
- * operand: 7e-4 where mode 2 has 5e-3, 3-4 % slower (the chip is power-limited and fp16 multipliers draw more); values beyond +-65504 saturate;
- * NUM_HEADS 8 / DIM_ATTEN 256 only.
+ * operand: 7e-4 where mode 2 has 5e-3, 3-4 % slower (the chip is power-limited and fp16 multipliers draw more); values beyond +-65504 saturate.
  * Activations in HBM, softmax and LayerNorm stay fp32 in every mode.  May be changed between forwards; the bf16
  * planes of the weights are made inside this call (it waits for the device), never inside a forward. */
 int vlsat_set_gemm_precision(vlsat_handle h, int32_t mode);

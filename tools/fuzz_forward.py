@@ -40,8 +40,6 @@ def main():
                   WITH_BN=bool(g.integers(0, 2)), multi_rel_outputs=bool(g.integers(0, 4) > 0),
                   USE_RGB=bool(g.integers(0, 3) == 0), USE_NORMAL=bool(g.integers(0, 3) == 0),
                   feature_transform=bool(g.integers(0, 6) == 0))
-        if mode == "fp16_mixed":               # (built for the default head geometry)
-            kw.update(NUM_HEADS=8, DIM_ATTEN=256)
         cfg = VLSATConfig(**kw)
         n_pts = int(g.integers(1, 300))
         scenes = []
