@@ -112,6 +112,7 @@ struct vlsat_ctx {
     float* sk_ws[3] = {nullptr, nullptr, nullptr};    // its workspace + counters, one set per lane: [0] launch stream, [1] / [2] the side streams
     unsigned* sk_cnt[3] = {nullptr, nullptr, nullptr};
     int flash_bq_big_min = 4096;             // ... and the smallest scene (edges) from which a plan gets them (debug option "flash_bq_big_min": plans created afterwards)
+    int flash_qg = 0;                        // 64 queries per wave in the half-row bf16 edge attention (debug option "flash_qg" 1 | 2; FlashSplit::qg)
     int flash_bq_big = 1;                    // 256-query tiles for plans whose scenes all have >= 4096 edges (debug option "flash_bq_big" 0: always 128)
     int flash_dma = 1;                       // half-row bf16 edge attention: K / V by LDS-direct loads, one tile ahead (0: register-staged, round 3; 3 | 4: rings of three / four tile buffers)
     int gate_fuse_agg = 1;                   // gate at the default head geometry, GCN_AGGR = max: aggregation fused into the gate kernel: 0 never, 1 the bf16 modes, 2 fp32 as well ("gate_fuse_agg")

@@ -88,6 +88,7 @@ int vlsat_debug_option(vlsat_handle h, const char* name, int32_t value) {
     else if (k == "gate_bf16") h->gate_bf16 = value != 0;
     else if (k == "flash_tr") h->flash_tr = value != 0;
     else if (k == "flash_bq_big") h->flash_bq_big = value != 0;
+    else if (k == "flash_qg") h->flash_qg = value < 0 || value > 2 ? 0 : value;
     else if (k == "flash_bq_big_min") h->flash_bq_big_min = value < 256 ? 256 : value;
 #ifdef VLSAT_EXPERIMENTS
     else if (k == "gate_grid") h->gate_grid = value > 0 ? value : 0;

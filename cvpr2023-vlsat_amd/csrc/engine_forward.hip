@@ -762,6 +762,7 @@ static int forward_body(vlsat_handle h, vlsat_plan p, const float* pts, const fl
                 else if (fa16) {
                     const bool big = SA == 2 && dh == 64 && p->n_tiles_big && h->flash_tr && h->flash_dma == 1 && h->flash_bq_big;
                     if (big) sp.bq = FLASH_BQ_BIG;
+                    sp.qg = h->flash_qg;
                     RUN(launch_flash_attn_bf16(p->Qe, D, kve, kve + (SA == 2 ? D / 2 : D), 2 * D, p->Oe, D, big ? p->d_tiles_big : p->d_tiles, big ? p->n_tiles_big : p->n_tiles,
                                                sc2e, PA == 3 ? 3 : 1, h->flash_tr ? (h->flash_dma >= 3 ? h->flash_dma : h->flash_dma ? 1 : 2) : 0, (SA == 2 && h->half_f16) ? 3 : SA, fs, &sp, h->flash_pv_terms, dh));    // (half rows: V starts at byte 2 D)
                 }

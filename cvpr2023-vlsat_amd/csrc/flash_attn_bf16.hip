@@ -134,7 +134,13 @@ __device__ __forceinline__ void planes_of(const f32x4& x, bf16x4& hi, bf16x4& lo
 //  four blocks per CU, no vmcnt wait left inside the iteration: 9844-9894 vs 9822-9870 scenes/s in the cfg 3 step (+0.2 %), 80.4-81.0 vs
 //  80.7-81.7 at cfg 5 (-0.7...-1.2 %): with K / V resident in L2 the loads have landed by then, and the fixed read order costs more than
 //  the compiler's.  profiles/r06_probes/krot_asmv_step_ab.txt)
-template <int TERMS, bool TR, int IO, int PVT = 3, int FB_D = 64, int RING = 0, int BQW = 4, int ABL = 0>
+// QG (round 6): 32-query groups per WAVE.  2 = a wave owns 64 queries: every K and V fragment it reads from LDS feeds
+// two MFMAs (half the fragment reads, address arithmetic, waits and loop control per product), Q and O of both groups stay in
+// registers (~200 VGPRs: two waves per SIMD where QG = 1 has four of 120).  A query's arithmetic is the same instruction sequence on
+// the same keys in the same order, so the outputs equal QG = 1 BIT FOR BIT (tests/test_hip_round6.py).  Block = BQW waves x 32 QG
+// queries: (BQW 2, QG 2) serves the 128-query tile table, (4, 2) the 256-query one.  ORD 1: the P.V product of group 0 is issued
+// in front of group 1's softmax (its V fragments are then read twice).
+template <int TERMS, bool TR, int IO, int PVT = 3, int FB_D = 64, int RING = 0, int BQW = 4, int ABL = 0, int QG = 1, int ORD = 0>
 __global__ __launch_bounds__(64 * BQW, 2) void flash_attn_bf16_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
     float* __restrict__ O, int ldq, int ldkv, int ldo, const int4* __restrict__ tiles, int n_tiles,
@@ -152,12 +158,13 @@ __global__ __launch_bounds__(64 * BQW, 2) void flash_attn_bf16_kernel(
     // (DMA) K image: 64 rows of ROWB = 2 FB_D bytes, unpadded (an LDS-direct load writes lane-linear), 16-byte chunks XOR-swizzled with
     // KSWZ(row) on the global side and on the fragment reads: 64-byte rows (row >> 2) & 3, 128-byte rows (row >> 1) & 7, 256-byte rows row & 15
     constexpr int ROWB = 2 * FB_D, CPR = ROWB / 16, RPI = 1024 / ROWB;          // bytes per K row, chunks per row, rows per load instruction
-    static_assert(BQW == 4 || (BQW == 8 && RING != 0 && FB_D == 64), "eight waves: the LDS-direct variant at head dim 64");
+    static_assert(QG == 1 || (QG == 2 && RING != 0 && FB_D == 64 && (BQW == 2 || BQW == 4)), "two query groups per wave: the LDS-direct variant at head dim 64");
+    static_assert(BQW == 4 || (BQW == 8 && RING != 0 && FB_D == 64) || (BQW == 2 && QG == 2), "eight waves: the LDS-direct variant at head dim 64");
     constexpr int KI = FB_KV / RPI / BQW, VI = 2 * NSUB / BQW, LPT = KI + VI;      // load instructions per wave and tile: K, V, both
     constexpr int KBYTES = FB_KV * ROWB;
     constexpr int BUF = DMA ? KBYTES + FB_VPLANE : PL * (FB_KPLANE + FB_VPLANE);
     constexpr int NBUF = DMA ? RING : 2, LA = NBUF - 1;           // (DMA) tiles of look-ahead
-    constexpr int SMEM = NBUF * BUF > BQW * 32 * FB_OPITCH * 4 ? NBUF * BUF : BQW * 32 * FB_OPITCH * 4;
+    constexpr int SMEM = NBUF * BUF > BQW * QG * 32 * FB_OPITCH * 4 ? NBUF * BUF : BQW * QG * 32 * FB_OPITCH * 4;
     __shared__ __attribute__((aligned(16))) char smem[SMEM];
 
     const int tile_id = xcd_remap(blockIdx.x, n_tiles);
@@ -170,12 +177,14 @@ __global__ __launch_bounds__(64 * BQW, 2) void flash_attn_bf16_kernel(
     const int li = lane & 31, hi = lane >> 5;
     const size_t col0 = (size_t)head * FB_D;
 
-    const bool wave_active = q0 + wave * 32 < n_tok;
-    int qrow = q0 + wave * 32 + li;
-    if (qrow >= n_tok) qrow = n_tok - 1;      // clamped rows are computed but never stored
-    // ---- this lane's query: d = 16 ks + 8 hi + e, pre-scaled, split into bf16 hi / lo ----
-    bf16x8 qh[NKS], ql[NKS];
-    {
+    const bool wave_active = q0 + wave * QG * 32 < n_tok;     // (QG = 2: a wave whose second group lies past the scene computes it on clamped rows)
+    // ---- this lane's query (one per group): d = 16 ks + 8 hi + e, pre-scaled, split into bf16 hi / lo ----
+    bf16x8 qhg[QG][NKS], ql[NKS];
+#pragma unroll
+    for (int g = 0; g < QG; ++g) {
+        int qrow = q0 + (wave * QG + g) * 32 + li;
+        if (qrow >= n_tok) qrow = n_tok - 1;      // clamped rows are computed but never stored
+        bf16x8 (&qh)[NKS] = qhg[g];
         const float* qrowp = Q + (size_t)(row_base + qrow) * ldq;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
@@ -192,12 +201,16 @@ __global__ __launch_bounds__(64 * BQW, 2) void flash_attn_bf16_kernel(
         }
     }
 
-    f32x16 o[NO];
+    f32x16 og[QG][NO];
+#pragma unroll
+    for (int g = 0; g < QG; ++g)
 #pragma unroll
     for (int b = 0; b < NO; ++b)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[b][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
+        for (int r = 0; r < 16; ++r) og[g][b][r] = 0.f;
+    float m_rung[QG], l_rung[QG];
+#pragma unroll
+    for (int g = 0; g < QG; ++g) { m_rung[g] = -INFINITY; l_rung[g] = 0.f; }
     // (tried in round 4 and dropped: the row sums of P through the matrix pipe -- one more MFMA per 16 keys with an all-ones A
     //  operand instead of 32 fp32 adds per lane and tile: 735 vs 790 TFLOP/s on the same box, profiles/r04_probes/flash_bf16_dma_ab.txt)
 
@@ -309,10 +322,12 @@ __global__ __launch_bounds__(64 * BQW, 2) void flash_attn_bf16_kernel(
         } else if (more && !(kExperiments && (sp.ablate & 1))) load_tile((kt + 1) * FB_KV);
 
         if (wave_active) {
-            // ---- S^T[key][query] = sum_d K[key][d] * Q[query][d], two blocks of 32 keys ----
-            f32x16 s[2];
+            // ---- S^T[key][query] = sum_d K[key][d] * Q[query][d], two blocks of 32 keys (per query group) ----
+            f32x16 sg[QG][2];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[0][r] = 0.f; s[1][r] = 0.f; }
+            for (int g = 0; g < QG; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sg[g][0][r] = 0.f; sg[g][1][r] = 0.f; }
             {
                 // the two 32-key blocks alternate, so consecutive MFMAs never wait for each other's accumulator
                 const char* kp = sK + li * FB_KPITCH + 16 * hi;
@@ -325,17 +340,20 @@ __global__ __launch_bounds__(64 * BQW, 2) void flash_attn_bf16_kernel(
                     if (PL == 2) {
                         const bf16x8 kl0 = *reinterpret_cast<const bf16x8*>(kp + FB_KPLANE + 32 * ks);
                         const bf16x8 kl1 = *reinterpret_cast<const bf16x8*>(kp + FB_KPLANE + 32 * FB_KPITCH + 32 * ks);
-                        s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl0, qh[ks], s[0], 0, 0, 0);
-                        s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl1, qh[ks], s[1], 0, 0, 0);
-                        s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh0, ql[ks], s[0], 0, 0, 0);
-                        s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh1, ql[ks], s[1], 0, 0, 0);
+                        sg[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl0, qhg[0][ks], sg[0][0], 0, 0, 0);
+                        sg[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl1, qhg[0][ks], sg[0][1], 0, 0, 0);
+                        sg[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh0, ql[ks], sg[0][0], 0, 0, 0);
+                        sg[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh1, ql[ks], sg[0][1], 0, 0, 0);
                     }
                     if ((ABL & 64)) {           // no QK MFMAs (the fragments stay read)
                         asm volatile("" :: "v"(kh0), "v"(kh1));
                         continue;
                     }
-                    s[0] = mfma_h<F16>(kh0, qh[ks], s[0]);
-                    s[1] = mfma_h<F16>(kh1, qh[ks], s[1]);
+#pragma unroll
+                    for (int g = 0; g < QG; ++g) {
+                        sg[g][0] = mfma_h<F16>(kh0, qhg[g][ks], sg[g][0]);
+                        sg[g][1] = mfma_h<F16>(kh1, qhg[g][ks], sg[g][1]);
+                    }
                 }
             }
             // The first readers of the score registers below are inline-asm VALU instructions, which hipcc's hazard recogniser
@@ -343,9 +361,17 @@ __global__ __launch_bounds__(64 * BQW, 2) void flash_attn_bf16_kernel(
             // hardware has no interlock there) are inserted by hand.  The asm names the accumulators, so it cannot move above the
             // MFMAs, and everything that reads them is ordered behind it.  (Found by the kernel tests: without it the maxima were
             // taken from stale registers.)
-            asm volatile("s_nop 15\n\ts_nop 3" : "+v"(s[0]), "+v"(s[1]));
-            // keys outside [key_lo, key_hi): beyond the scene's tokens (last tile) or another part's (split mode)
+            if (QG == 2) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(sg[0][0]), "+v"(sg[0][1]), "+v"(sg[QG - 1][0]), "+v"(sg[QG - 1][1]));
+            else asm volatile("s_nop 15\n\ts_nop 3" : "+v"(sg[0][0]), "+v"(sg[0][1]));
             const int kv0 = kt * FB_KV;
+            // ---- online softmax for this lane's query ----
+            // The kernel is bound by VALU issue at head dim 64 (round 4 PMC: matrix pipe 35 % busy; per tile and wave 512 MFMA cycles
+            // against ~1100 of VALU), so the softmax is written for instruction count (round 5): the maximum of the 32 scores with
+            // v_max3_f32 (two new values per instruction; fmaxf costs a canonicalising v_max per MFMA result on top of the max itself:
+            // 54 -> 16 instructions), score - m and the row sum as packed fp32 pairs (v_pk_add_f32: 33 + 33 -> 16 + 16); the 32
+            // quarter-rate v_exp_f32 stay.
+            auto softmax_group = [&](f32x16 (&s)[2], f32x16 (&o)[NO], float& m_run, float& l_run) __attribute__((always_inline)) {
+            // keys outside [key_lo, key_hi): beyond the scene's tokens (last tile) or another part's (split mode)
             if (kv0 < key_lo || kv0 + FB_KV > key_hi) {
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
@@ -355,12 +381,6 @@ __global__ __launch_bounds__(64 * BQW, 2) void flash_attn_bf16_kernel(
                         if (key < key_lo || key >= key_hi) s[kb][r] = -INFINITY;
                     }
             }
-            // ---- online softmax for this lane's query ----
-            // The kernel is bound by VALU issue at head dim 64 (round 4 PMC: matrix pipe 35 % busy; per tile and wave 512 MFMA cycles
-            // against ~1100 of VALU), so the softmax is written for instruction count (round 5): the maximum of the 32 scores with
-            // v_max3_f32 (two new values per instruction; fmaxf costs a canonicalising v_max per MFMA result on top of the max itself:
-            // 54 -> 16 instructions), score - m and the row sum as packed fp32 pairs (v_pk_add_f32: 33 + 33 -> 16 + 16); the 32
-            // quarter-rate v_exp_f32 stay.
             float mx;
             {
                 float ma = max3f(s[0][0], s[0][1], s[0][2]), mb = max3f(s[1][0], s[1][1], s[1][2]);    // two chains: no max waits for its predecessor
@@ -399,13 +419,19 @@ __global__ __launch_bounds__(64 * BQW, 2) void flash_attn_bf16_kernel(
 #pragma unroll
                     for (int r = 0; r < 16; ++r) o[b][r] *= alpha;
             }
-            // ---- O^T[d][query] += sum_key V[key][d] * P[key][query] ----
+            };
+            // ---- O^T[d][query] += sum_key V[key][d] * P[key][query]: groups [G0, G1) share every V fragment ----
+            auto pv_groups = [&](auto g0c, auto g1c) __attribute__((always_inline)) {
+            constexpr int G0 = decltype(g0c)::value, G1 = decltype(g1c)::value;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int kb = j >> 1, half = j & 1;
+                bf16x8 phg[QG], pl;
+#pragma unroll
+                for (int g = G0; g < G1; ++g) {
                 f32x4 p0, p1;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) { p0[c] = s[kb][8 * half + c]; p1[c] = s[kb][8 * half + 4 + c]; }
+                for (int c = 0; c < 4; ++c) { p0[c] = sg[g][kb][8 * half + c]; p1[c] = sg[g][kb][8 * half + 4 + c]; }
                 bf16x4 h0, l0, h1, l1;
                 if constexpr (F16) {              // probabilities in [0, 1]: fp16, no clamp needed
                     typedef _Float16 f16x4_p __attribute__((ext_vector_type(4)));
@@ -415,8 +441,11 @@ __global__ __launch_bounds__(64 * BQW, 2) void flash_attn_bf16_kernel(
                     split4(p0, h0, l0);
                     split4(p1, h1, l1);
                 }
-                const bf16x8 ph = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
-                const bf16x8 pl = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+                phg[g] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+                pl = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+                const bf16x8 ph = phg[G0];
+                f32x16 (&o)[NO] = og[G0];
                 const int k0 = 32 * kb + 16 * half + 4 * hi;          // first key of this lane half's k-slots (then +8)
                 bf16x8 vf[NO][PL];
 #pragma unroll
@@ -455,7 +484,23 @@ __global__ __launch_bounds__(64 * BQW, 2) void flash_attn_bf16_kernel(
                     continue;
                 }
 #pragma unroll
-                for (int db = 0; db < NO; ++db) o[db] = mfma_h<F16>(vf[db][0], ph, o[db]);
+                for (int g = G0; g < G1; ++g)
+#pragma unroll
+                for (int db = 0; db < NO; ++db) og[g][db] = mfma_h<F16>(vf[db][0], phg[g], og[g][db]);
+            }
+            };
+            typedef std::integral_constant<int, 0> I0;
+            typedef std::integral_constant<int, 1> I1;
+            typedef std::integral_constant<int, QG> IQ;
+            if constexpr (QG == 2 && ORD == 1) {
+                softmax_group(sg[0], og[0], m_rung[0], l_rung[0]);
+                pv_groups(I0{}, I1{});
+                softmax_group(sg[QG - 1], og[QG - 1], m_rung[QG - 1], l_rung[QG - 1]);
+                pv_groups(I1{}, IQ{});
+            } else {
+#pragma unroll
+                for (int g = 0; g < QG; ++g) softmax_group(sg[g], og[g], m_rung[g], l_rung[g]);
+                pv_groups(I0{}, IQ{});
             }
         }   // wave_active
         if (DMA) {
@@ -481,30 +526,37 @@ __global__ __launch_bounds__(64 * BQW, 2) void flash_attn_bf16_kernel(
     // ---- normalise (or, in split mode, keep un-normalised and record m, l), transpose through LDS
     //      (wave-private [32 q][68]), coalesced store ----
     const bool split = sp.parts > 1;
-    const float inv_l = split ? 1.f : 1.f / l_run;
-    if (split) {
-        O = sp.o_part + (size_t)kr.z * sp.part_stride;
-        const int qr = q0 + wave * 32 + li;
-        if (hi == 0 && qr < n_tok) {
-            const size_t i = ((size_t)kr.z * sp.rows + row_base + qr) * sp.heads + head;
-            sp.m_part[i] = m_run;
-            sp.l_part[i] = l_run;
+    if (split) O = sp.o_part + (size_t)kr.z * sp.part_stride;
+#pragma unroll
+    for (int g = 0; g < QG; ++g) {
+        const float m_run = m_rung[g], l_run = l_rung[g];
+        const float inv_l = split ? 1.f : 1.f / l_run;
+        if (split) {
+            const int qr = q0 + (wave * QG + g) * 32 + li;
+            if (hi == 0 && qr < n_tok) {
+                const size_t i = ((size_t)kr.z * sp.rows + row_base + qr) * sp.heads + head;
+                sp.m_part[i] = m_run;
+                sp.l_part[i] = l_run;
+            }
         }
+        float* so = reinterpret_cast<float*>(smem) + (wave * QG + g) * (32 * FB_OPITCH);
+#pragma unroll
+        for (int b = 0; b < NO; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float a = og[g][b][r] * inv_l;
+                so[li * FB_OPITCH + 32 * b + crow32(r, hi)] = (IO == 1 && !split) ? pack_split(a) : a;   // (split-key partials stay fp32: the merge packs)
+            }
     }
-    float* so = reinterpret_cast<float*>(smem) + wave * (32 * FB_OPITCH);
-#pragma unroll
-    for (int b = 0; b < NO; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float a = o[b][r] * inv_l;
-            so[li * FB_OPITCH + 32 * b + crow32(r, hi)] = (IO == 1 && !split) ? pack_split(a) : a;   // (split-key partials stay fp32: the merge packs)
-        }
     __syncthreads();
+#pragma unroll
+    for (int g = 0; g < QG; ++g) {
+    const float* so = reinterpret_cast<const float*>(smem) + (wave * QG + g) * (32 * FB_OPITCH);
 #pragma unroll
     for (int i = 0; i < FB_D / 8; ++i) {
         const int idx = lane + 64 * i;             // 8 FB_D float4 = 32 rows x FB_D / 4
         const int r = idx / (FB_D / 4), c4 = (idx % (FB_D / 4)) * 4;
-        const int qr = q0 + wave * 32 + r;
+        const int qr = q0 + (wave * QG + g) * 32 + r;
         if (qr < n_tok) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(so + r * FB_OPITCH + c4);
             float* orow = O + (size_t)(row_base + qr) * ldo;
@@ -519,6 +571,7 @@ __global__ __launch_bounds__(64 * BQW, 2) void flash_attn_bf16_kernel(
             else
                 *reinterpret_cast<f32x4*>(orow + col0 + c4) = v;
         }
+    }
     }
 }
 
@@ -551,7 +604,7 @@ int launch_flash_attn_bf16(const float* Q, int ldq, const float* K, const float*
         if (!sp.krange || !sp.o_part || !sp.m_part || !sp.l_part || sp.heads * FB_D > ldo)
             return fail(-1, "flash_attn: incomplete split-key workspace");
     }
-    if (split) { sp.ablate = split->ablate; sp.bq = split->bq; sp.rows = split->rows; }
+    if (split) { sp.ablate = split->ablate; sp.bq = split->bq; sp.rows = split->rows; sp.qg = split->qg; }
     if (sp.bq != FLASH_BQ && !(sp.bq == FLASH_BQ_BIG && FB_D == 64 && io_split >= 2 && use_tr == 1 && sp.parts <= 1 && sp.rows > 0 &&
                                (size_t)sp.rows * (size_t)ldkv * 4 < (1ull << 32)))
         return fail(-1, "flash_attn_bf16: 256-query tiles are built for half rows, head dim 64, the LDS-direct kernel, no key split");
@@ -602,6 +655,14 @@ int launch_flash_attn_bf16(const float* Q, int ldq, const float* K, const float*
         VLSAT_FA_ABL(4) VLSAT_FA_ABL(8) VLSAT_FA_ABL(16) VLSAT_FA_ABL(28) VLSAT_FA_ABL(32) VLSAT_FA_ABL(64) VLSAT_FA_ABL(96) VLSAT_FA_ABL(256) VLSAT_FA_ABL(124) VLSAT_FA_ABL(380)
 #undef VLSAT_FA_ABL
 #endif
+        else if (use_tr != 2 && sp.bq == FLASH_BQ_BIG && sp.qg == 1)
+            hipLaunchKernelGGL((flash_attn_bf16_kernel<1, true, 2, 3, 64, 2, 4, 0, 2, 0>), dim3(n_tiles), dim3(256), 0, s, Q, K, V, O, ldq, ldkv, ldo, tiles, n_tiles, scale_log2e, sp);
+        else if (use_tr != 2 && sp.bq == FLASH_BQ_BIG && sp.qg == 2)
+            hipLaunchKernelGGL((flash_attn_bf16_kernel<1, true, 2, 3, 64, 2, 4, 0, 2, 1>), dim3(n_tiles), dim3(256), 0, s, Q, K, V, O, ldq, ldkv, ldo, tiles, n_tiles, scale_log2e, sp);
+        else if (use_tr != 2 && sp.qg == 1 && sp.parts <= 1)
+            hipLaunchKernelGGL((flash_attn_bf16_kernel<1, true, 2, 3, 64, 2, 2, 0, 2, 0>), dim3(n_tiles), dim3(128), 0, s, Q, K, V, O, ldq, ldkv, ldo, tiles, n_tiles, scale_log2e, sp);
+        else if (use_tr != 2 && sp.qg == 2 && sp.parts <= 1)
+            hipLaunchKernelGGL((flash_attn_bf16_kernel<1, true, 2, 3, 64, 2, 2, 0, 2, 1>), dim3(n_tiles), dim3(128), 0, s, Q, K, V, O, ldq, ldkv, ldo, tiles, n_tiles, scale_log2e, sp);
         else if (use_tr != 2 && sp.bq == FLASH_BQ_BIG)
             hipLaunchKernelGGL((flash_attn_bf16_kernel<1, true, 2, 3, 64, 2, 8>), dim3(n_tiles), dim3(512), 0, s, Q, K, V, O, ldq, ldkv, ldo, tiles, n_tiles, scale_log2e, sp);
         else if (use_tr != 2)       // (use_tr = 2: the register-staged kernel of round 3, for A/B -- "flash_dma" 0)

@@ -96,6 +96,7 @@ struct FlashSplit {
     size_t part_stride = 0;      // floats between parts of o_part (= rows * ldo)
     int rows = 0, heads = 0;
     int ablate = 0;              // timing experiments (garbage results): bit 0 no K/V loads after the first tile, bit 1 no LDS stores of them either
+    int qg = 0;                  // half rows, head dim 64, LDS-direct kernel, no key split: 1 | 2 = 64 queries per wave (flash_attn_bf16.hip QG = 2; 2 = ORD 1), 0 = 32
     int bq = 128;                // queries per block of the tile table handed in: FLASH_BQ, or FLASH_BQ_BIG (half rows, head dim 64, LDS-direct kernel only)
 };
 int launch_flash_attn(const float* Q, int ldq, const float* K, const float* V, int ldkv, float* O, int ldo,

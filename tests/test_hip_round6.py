@@ -234,3 +234,27 @@ def test_fp16_mixed_on_the_other_head_geometries():
             m.close()
         print(kw, {k: f"{v:.2e}" for k, v in errs.items()})
         assert errs["fp16_mixed"] < 0.5 * errs["bf16_mixed"], (kw, errs)
+
+
+@pytest.mark.parametrize("mode", ["bf16_mixed", "bf16x3_attn1"])
+@pytest.mark.parametrize("sizes", [(66, 67, 70, 65, 72, 66, 69, 68), (40, 9, 23, 40, 31, 12, 40, 17, 40, 3, 40, 26)])
+def test_64_queries_per_wave_edge_attention_is_bit_identical(mode, sizes):
+    """"flash_qg" 1 | 2: the half-row edge attention (reference transformer/attention.py:60-76 as called from
+    network_MMG.py:231) with TWO 32-query groups per wave -- every K / V fragment read from LDS feeds two MFMAs, Q and O of both groups
+    register-resident (flash_attn_bf16.hip QG = 2; 2 = the P.V product of the first group issued in front of the second group's
+    softmax).  A query sees the same keys in the same order through the same instructions, so the outputs must equal the shipped kernel
+    BIT FOR BIT: on the 256-query tile table (scenes of >= 4096 edges: four waves per block) and on the 128-query one (two waves
+    per block; scene sizes that leave the second group of a wave partly or wholly past the scene's last edge)."""
+    cfg = VLSATConfig(N_LAYERS=2)
+    w = synth.make_weights(cfg, seed=5)
+    scenes = [synth.make_scene(n, 64, 900 + i) for i, n in enumerate(sizes)]
+    d = {k: torch.from_numpy(v).to(DEV) for k, v in synth.collate(scenes).items()}
+    m = VLSATModel(cfg, DEV).load_state(w).eval().set_gemm_precision(mode)
+    m.debug_option("flash_split", 0)
+    base = _run(m, d)
+    for qg in (1, 2):
+        m.debug_option("flash_qg", qg)
+        got = _run(m, d)
+        for n, a, b in zip(NAMES, base, got):
+            assert torch.equal(a, b), (qg, n, float((a - b).abs().max()))
+    m.close()
