@@ -418,6 +418,9 @@ int vlsat_debug_gemm_clock_probe(int64_t* buf);
  *   "flash_bq_big" 0|1    half-row edge attention, plans whose scenes all have >= 4096 edges: 256 queries per block (default) or 128;
  *   "flash_bq_big_min" n  ... that bound (plans created afterwards).  At the bench batch (1560 edges per scene) 256-query tiles are 1 %
  *                         slower per step than 128-query ones (profiles/r06_probes/ab_flash_bq_big_min.txt): the default stays 4096;
+ *   "flash_qg" 0|1|2      half-row edge attention at head dim 64, no key split: 64 queries per wave (two 32-query groups share every K / V
+ *                         fragment; 2 = group 0's P.V product in front of group 1's softmax).  Bit-identical to 0; 4-7 % slower per step
+ *                         at BASELINE configs[2] and configs[4] (profiles/r06_probes/ab_flash_qg.txt): default 0;
  *   "flash_pv_terms" 3|2  split-bf16 edge attention: MFMAs per P.V product;  "gate_fuse_agg" 0|1|2: max aggregation inside the gate
  *                         kernel (never / bf16 modes / fp32 too);  "gate_row_map" 0|1, "gate_heads_mfma" 0|1|2: gate kernel variants.
  * Lab switches ("gate_grid", "gate_heads_bf16", "flash_heads_bf16", "node_attn_split", "half_fmt", "flash_dma", "flash_ablate" -- the
