@@ -44,6 +44,20 @@ int fail(int code, const std::string& msg);
 // Column is lane & 31.  (cdna_hip_programming.md §3: row = (r&3) + 8*(r>>2) + 4*hi.)
 __device__ __forceinline__ int crow32(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
+// Reductions across the two 32-lane halves of a wave with the gfx950 register swap (v_permlane32_swap_b32 a, b exchanges lanes
+// 32..63 of a with lanes 0..31 of b: from a = b = x every lane of a then holds the LOWER half's value of its column and every lane
+// of b the UPPER half's) instead of __shfl_xor(x, 32), which hipcc turns into a ds_bpermute_b32: an LDS-queue instruction with an
+// address register and an lgkmcnt wait behind whatever fragment reads are in flight.  max and + are commutative, so the results
+// equal fmaxf(x, __shfl_xor(x, 32)) / x + __shfl_xor(x, 32) bit for bit in both halves.
+__device__ __forceinline__ void half_swap(float x, float& lo, float& hi) {
+    typedef unsigned u32x2_hs __attribute__((ext_vector_type(2)));
+    const u32x2_hs r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    lo = __uint_as_float(r[0]);
+    hi = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float half_max(float x) { float a, b; half_swap(x, a, b); return fmaxf(a, b); }
+__device__ __forceinline__ float half_sum(float x) { float a, b; half_swap(x, a, b); return a + b; }
+
 // XCD-aware bijective block remap: hardware round-robins consecutive block ids over the 8
 // XCDs; this gives every XCD a contiguous range of virtual ids so neighbouring tiles (which
 // share an operand panel) hit the same L2.

@@ -112,14 +112,14 @@ __global__ __launch_bounds__(256, 2) void edge_gate_kernel(GateArgs pa, GateArgs
         float mx = lg[0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) mx = fmaxf(mx, lg[r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        mx = half_max(mx);
         float sum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             lg[r] = __expf(lg[r] - mx);
             sum += lg[r];
         }
-        sum += __shfl_xor(sum, 32);
+        sum = half_sum(sum);
         const float inv = 1.f / sum;
         if (FUSED && p.agg) {                  // fused max aggregation: the gated rows are never stored (gate_agg.h)
             gate_aggregate_max(sAgg + wave * AG_WAVE_BYTES, lg, inv, p.node + (size_t)dn * p.ld_node + p.v_off + h * 32 + 4 * hi, valid ? sn : -1,

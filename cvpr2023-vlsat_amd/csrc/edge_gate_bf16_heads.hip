@@ -178,7 +178,7 @@ __global__ __launch_bounds__(DK == 128 ? 512 : 256, DK == 128 ? 1 : 2) void edge
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 if (mo * 32 + 8 * (r >> 2) < DOX) mx = fmaxf(mx, lg[mo][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        mx = half_max(mx);
         float sum = 0.f;
 #pragma unroll
         for (int mo = 0; mo < MO; ++mo)
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(DK == 128 ? 512 : 256, DK == 128 ? 1 : 2) void edge
                     lg[mo][r] = __expf(lg[mo][r] - mx);
                     sum += lg[mo][r];
                 }
-        sum += __shfl_xor(sum, 32);
+        sum = half_sum(sum);
         const float inv = 1.f / sum;
         if (valid) {
             const float* vrow = p.node + (size_t)dn * p.ld_node + p.v_off + h * DOX + 4 * hi;

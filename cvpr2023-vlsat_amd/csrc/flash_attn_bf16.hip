@@ -389,7 +389,7 @@ __global__ __launch_bounds__(64 * BQW, 2) void flash_attn_bf16_kernel(
                 mx = max3f(ma, mb, s[0][15]);
                 mx = max3f(mx, s[1][15], s[1][15]);
             }
-            if (!((ABL & 16))) mx = max3f(mx, __shfl_xor(mx, 32), mx);       // (ablate 16: no cross-half exchanges)
+            if (!((ABL & 16))) { float ha, hb; half_swap(mx, ha, hb); mx = max3f(ha, hb, hb); }       // (ablate 16: no cross-half exchanges)
             if ((ABL & 8)) mx = 0.f;                                        // (ablate 8: no maximum at all)
             const float m_new = max3f(m_run, mx, mx);
             // (a part whose first tile is fully masked for this query keeps m = -inf; exp2(-inf - -inf) must not be NaN)
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(64 * BQW, 2) void flash_attn_bf16_kernel(
                     s[kb][r + 1] = x[1];
                 }
             float rs = rs2[0] + rs2[1];
-            if (!((ABL & 16))) rs += __shfl_xor(rs, 32);
+            if (!((ABL & 16))) rs = half_sum(rs);
             l_run = l_run * alpha + rs;
             m_run = m_new;
             if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_f32_kernel(
         float mx = s[0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        mx = half_max(mx);
         const float m_new = fmaxf(m_run, mx);
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         float rs = 0.f;
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_f32_kernel(
             s[r] = __builtin_amdgcn_exp2f(s[r] - m_new);
             rs += s[r];
         }
-        rs += __shfl_xor(rs, 32);
+        rs = half_sum(rs);
         l_run = l_run * alpha + rs;
         m_run = m_new;
         // rescale the running output only when some query's maximum moved (alpha == 1 exactly otherwise: after the

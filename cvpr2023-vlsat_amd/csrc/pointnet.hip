@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256, 2) void pointnet_kernel(
                     float m = 0.f;                                   // relu folded into the max with 0
 #pragma unroll
                     for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[0][tn][r] + bb);
-                    m = fmaxf(m, __shfl_xor(m, 32));
+                    m = half_max(m);
 #pragma unroll
                     for (int q = 0; q < PN_MAXNC; ++q)               // static register index
                         if (q == nc) rmax[q][tn] = fmaxf(rmax[q][tn], m);
