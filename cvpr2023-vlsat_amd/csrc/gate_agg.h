@@ -51,22 +51,50 @@ __device__ __forceinline__ void gate_aggregate_max(char* wbuf, const f32x16& lg,
             *reinterpret_cast<f32x4*>(tb + ag_row(li) + 8 * rr + 4 * hi) = o;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // (wave-private buffer: program order + this wait)
-        int cur = -1;
-        float acc = 0.f;
+        // stage 1: the lane's eight rows -> a lead run and a trail run (one and the same when the source never changes: `ls` = -2);
+        // runs in between (two or more changes inside eight rows: not with source-major lists) go out at once
+        int cur = srow[0], ls = -2;
+        float acc = tb[ag_row(8 * q) + lc], la = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int row = 8 * q + j;
+        for (int j = 1; j < 8; ++j) {
             const int sj = srow[j];
-            const float x = tb[ag_row(row) + lc];
+            const float x = tb[ag_row(8 * q + j) + lc];
             if (sj != cur) {
-                if (cur >= 0) atomic_max_f32(agg + (size_t)cur * ld_agg + h * 32 + 16 * pass + lc, acc);
+                if (ls == -2) { ls = cur; la = acc; }
+                else if (cur >= 0) atomic_max_f32(agg + (size_t)cur * ld_agg + h * 32 + 16 * pass + lc, acc);
                 cur = sj;
                 acc = x;
             } else {
                 acc = fmaxf(acc, x);
             }
         }
-        if (cur >= 0) atomic_max_f32(agg + (size_t)cur * ld_agg + h * 32 + 16 * pass + lc, acc);
+        // stage 2 (round 6): the four row groups of a channel hand their runs to the lane of group 0 through the (now idle) buffer, which
+        // merges neighbours of the same source and issues ONE atomic per run of the 32 rows -- one or two per channel and unit on
+        // source-major lists instead of five (the atomics leave the XCD: they were 19 % of the bf16 gate's time,
+        // profiles/r06_probes/ab_gate_atomics.txt).  max is associative and commutative: the cells end up with the same bits.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // (every lane's row reads have returned: the buffer is free)
+        *reinterpret_cast<f32x4*>(tb + 4 * lane) = f32x4{__int_as_float(ls), la, __int_as_float(cur), acc};
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (q == 0) {
+            int rs = -1;
+            float ra = 0.f;
+            auto take = [&](int sx, float ax) {
+                if (sx == rs) ra = fmaxf(ra, ax);
+                else {
+                    if (rs >= 0) atomic_max_f32(agg + (size_t)rs * ld_agg + h * 32 + 16 * pass + lc, ra);
+                    rs = sx;
+                    ra = ax;
+                }
+            };
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 rec = *reinterpret_cast<const f32x4*>(tb + 4 * (lc + 16 * g));
+                const int s0 = __float_as_int(rec[0]);
+                if (s0 != -2) take(s0, rec[1]);
+                take(__float_as_int(rec[2]), rec[3]);
+            }
+            if (rs >= 0) atomic_max_f32(agg + (size_t)rs * ld_agg + h * 32 + 16 * pass + lc, ra);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // (the reads are done before the next pass overwrites)
     }
 }
